@@ -1,0 +1,115 @@
+"""ctypes binding of libeffocr_hip.so (include/effocr_hip.h) — the only door to the HIP kernels.
+
+There is deliberately no fallback: if the shared library is missing or a call fails, an exception
+is raised.  Nothing here (or anywhere in ``effocr_amd``) imports ``oracle/``.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libeffocr_hip.so")
+
+PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
+EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class EffOCRHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into effocr_amd/libeffocr_hip.so (hipcc cross-compiles
+    without a GPU).  Returns the path of the shared library."""
+    cmd = ["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    if force:
+        cmd.append("-B")
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0 or not os.path.exists(SO_PATH):
+        raise EffOCRHipError("building libeffocr_hip.so failed:\n" + res.stdout[-4000:])
+    return SO_PATH
+
+
+def _declare(lib):
+    c = ctypes
+    vp, i32, i64, sz, f32p, i64p = c.c_void_p, c.c_int, c.c_int64, c.c_size_t, c.c_void_p, c.c_void_p
+    sig = {
+        "effocr_abi_version": (i32, []),
+        "effocr_last_error": (c.c_char_p, []),
+        "effocr_encoder_create": (i32, [c.c_char_p, i32, i32, c.POINTER(vp)]),
+        "effocr_encoder_destroy": (None, [vp]),
+        "effocr_encoder_embed_dim": (i32, [vp]),
+        "effocr_encoder_num_params": (i32, [vp]),
+        "effocr_encoder_param_name": (c.c_char_p, [vp, i32]),
+        "effocr_encoder_param_numel": (i64, [vp, i32]),
+        "effocr_encoder_set_param": (i32, [vp, c.c_char_p, vp, i64]),
+        "effocr_encoder_weights_bytes": (sz, [vp]),
+        "effocr_encoder_upload": (i32, [vp, vp, sz]),
+        "effocr_encoder_workspace_bytes": (sz, [vp, i32]),
+        "effocr_encoder_forward": (i32, [vp, f32p, i32, f32p, i32, vp, sz, vp]),
+        "effocr_knn_workspace_bytes": (sz, [i64, i64, i32, i32]),
+        "effocr_knn_ip_topk": (i32, [f32p, i64, f32p, i64, i32, i32, f32p, i64p, vp, sz, vp]),
+        "effocr_l2_normalize": (i32, [f32p, i64, i32, f32p, vp]),
+        "effocr_gather_rows": (i32, [f32p, i64p, i64, i32, f32p, vp]),
+        "effocr_op_linear": (i32, [i32, i32, vp, vp, f32p, f32p, vp, i32, i32, i32, vp]),
+        "effocr_op_layernorm": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
+        "effocr_op_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTS = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the extension has not been built."""
+    global _lib, EXPORTS
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(SO_PATH):
+                raise EffOCRHipError(
+                    f"{SO_PATH} not found: the HIP extension is required (no CPU fallback). "
+                    "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C effocr_amd/csrc`.")
+            handle = ctypes.CDLL(SO_PATH)
+            EXPORTS = sorted(_declare(handle).keys())
+            if handle.effocr_abi_version() != 1:
+                raise EffOCRHipError("libeffocr_hip.so ABI version mismatch")
+            _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().effocr_last_error()
+        raise EffOCRHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(device):
+    import torch
+    if not torch.cuda.is_available():
+        raise EffOCRHipError("no ROCm GPU visible: the EffOCR HIP path has no CPU fallback")
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise EffOCRHipError(f"device {device!r} is not a GPU: the EffOCR HIP path has no CPU fallback")
+    return d

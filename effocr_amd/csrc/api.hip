@@ -1,0 +1,494 @@
+// C ABI of libeffocr_hip.so (include/effocr_hip.h): error plumbing, the encoder handle (parameter
+// table, host-side packing / BatchNorm folding, forward orchestration) and thin wrappers over the
+// kernel launchers.  All device memory is caller-owned; this file allocates host memory only.
+#include "../../include/effocr_hip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+#include <math.h>
+#include <string.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace effocr {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(EFFOCR_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  return EFFOCR_OK;
+}
+
+namespace {
+
+struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std::vector<float> data; bool set; };
+
+struct VitCfg { int D, depth, heads, mlp; };
+struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w; };
+struct ConvSpec { std::string w, bn; int cin, cout, k, stride, pad; size_t w_off, b_off; };
+
+}  // namespace
+}  // namespace effocr
+
+using namespace effocr;
+
+struct effocr_encoder {
+  std::string arch;
+  bool is_vit = false;
+  int img = 224, prec = PREC_BF16, D = 0;
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+  // ViT
+  VitCfg vit{};
+  int T = 0, P = 0;
+  size_t off_clspos0 = 0, off_pos = 0, off_patchb = 0, off_normw = 0, off_normb = 0, off_patchw = 0;
+  std::vector<VitLayerOff> layers;
+  // resnet18
+  std::vector<ConvSpec> convs;      // conv1, then per block conv1, conv2, (downsample)
+  size_t wbytes = 0;
+  const char* wdev = nullptr;       // device blob after upload
+};
+
+namespace effocr {
+namespace {
+
+int64_t prod(const std::vector<int64_t>& s) { int64_t p = 1; for (auto v : s) p *= v; return p; }
+
+void add_param(effocr_encoder* e, const std::string& name, std::vector<int64_t> shape) {
+  Param p; p.name = name; p.shape = shape; p.numel = prod(shape); p.set = false;
+  e->index[name] = (int)e->params.size();
+  e->params.push_back(std::move(p));
+}
+
+struct Alloc {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; }
+};
+
+void build_vit(effocr_encoder* e) {
+  const int D = e->vit.D, depth = e->vit.depth, mlp = e->vit.mlp;
+  e->P = (e->img / 16) * (e->img / 16);
+  e->T = e->P + 1;
+  add_param(e, "cls_token", {1, 1, D});
+  add_param(e, "pos_embed", {1, e->T, D});
+  add_param(e, "patch_embed.proj.weight", {D, 3, 16, 16});
+  add_param(e, "patch_embed.proj.bias", {D});
+  for (int i = 0; i < depth; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    add_param(e, p + "norm1.weight", {D});
+    add_param(e, p + "norm1.bias", {D});
+    add_param(e, p + "attn.qkv.weight", {3 * D, D});
+    add_param(e, p + "attn.qkv.bias", {3 * D});
+    add_param(e, p + "attn.proj.weight", {D, D});
+    add_param(e, p + "attn.proj.bias", {D});
+    add_param(e, p + "norm2.weight", {D});
+    add_param(e, p + "norm2.bias", {D});
+    add_param(e, p + "mlp.fc1.weight", {mlp, D});
+    add_param(e, p + "mlp.fc1.bias", {mlp});
+    add_param(e, p + "mlp.fc2.weight", {D, mlp});
+    add_param(e, p + "mlp.fc2.bias", {D});
+  }
+  add_param(e, "norm.weight", {D});
+  add_param(e, "norm.bias", {D});
+
+  const size_t es = prec_esize(e->prec);
+  Alloc a;
+  e->off_clspos0 = a.take((size_t)D * 4);
+  e->off_pos = a.take((size_t)e->T * D * 4);
+  e->off_patchb = a.take((size_t)D * 4);
+  e->layers.resize(depth);
+  for (int i = 0; i < depth; ++i) {
+    VitLayerOff& L = e->layers[i];
+    L.ln1w = a.take((size_t)D * 4); L.ln1b = a.take((size_t)D * 4);
+    L.qkvb = a.take((size_t)3 * D * 4); L.projb = a.take((size_t)D * 4);
+    L.ln2w = a.take((size_t)D * 4); L.ln2b = a.take((size_t)D * 4);
+    L.fc1b = a.take((size_t)mlp * 4); L.fc2b = a.take((size_t)D * 4);
+  }
+  e->off_normw = a.take((size_t)D * 4);
+  e->off_normb = a.take((size_t)D * 4);
+  e->off_patchw = a.take((size_t)D * 768 * es);
+  for (int i = 0; i < depth; ++i) {
+    VitLayerOff& L = e->layers[i];
+    L.qkvw = a.take((size_t)3 * D * D * es);
+    L.projw = a.take((size_t)D * D * es);
+    L.fc1w = a.take((size_t)mlp * D * es);
+    L.fc2w = a.take((size_t)D * mlp * es);
+  }
+  e->wbytes = a.off;
+}
+
+void add_bn(effocr_encoder* e, const std::string& p, int c) {
+  add_param(e, p + ".weight", {c}); add_param(e, p + ".bias", {c});
+  add_param(e, p + ".running_mean", {c}); add_param(e, p + ".running_var", {c});
+}
+
+constexpr int CONV1_KPAD = 160;   // 7*7*3 = 147 im2col columns padded to 5 K-stages of 32
+
+void build_resnet18(effocr_encoder* e) {
+  const int widths[4] = {64, 128, 256, 512};
+  add_param(e, "conv1.weight", {64, 3, 7, 7});
+  add_bn(e, "bn1", 64);
+  e->convs.push_back({"conv1.weight", "bn1", 3, 64, 7, 2, 3, 0, 0});
+  int cin = 64;
+  for (int li = 1; li <= 4; ++li) {
+    const int w = widths[li - 1];
+    for (int bi = 0; bi < 2; ++bi) {
+      const std::string p = "layer" + std::to_string(li) + "." + std::to_string(bi) + ".";
+      const int stride = (bi == 0 && li > 1) ? 2 : 1;
+      add_param(e, p + "conv1.weight", {w, cin, 3, 3}); add_bn(e, p + "bn1", w);
+      add_param(e, p + "conv2.weight", {w, w, 3, 3}); add_bn(e, p + "bn2", w);
+      e->convs.push_back({p + "conv1.weight", p + "bn1", cin, w, 3, stride, 1, 0, 0});
+      e->convs.push_back({p + "conv2.weight", p + "bn2", w, w, 3, 1, 1, 0, 0});
+      if (bi == 0 && li > 1) {
+        add_param(e, p + "downsample.0.weight", {w, cin, 1, 1}); add_bn(e, p + "downsample.1", w);
+        e->convs.push_back({p + "downsample.0.weight", p + "downsample.1", cin, w, 1, stride, 0, 0, 0});
+      }
+      cin = w;
+    }
+  }
+  Alloc a;
+  for (size_t i = 0; i < e->convs.size(); ++i) {
+    ConvSpec& c = e->convs[i];
+    const size_t K = (i == 0) ? (size_t)CONV1_KPAD : (size_t)c.k * c.k * c.cin;
+    c.w_off = a.take((size_t)c.cout * K * 4);
+    c.b_off = a.take((size_t)c.cout * 4);
+  }
+  e->wbytes = a.off;
+}
+
+uint16_t f32_to_bf16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+  return (uint16_t)(u >> 16);
+}
+uint16_t f32_to_f16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+
+void put_f32(std::vector<char>& blob, size_t off, const float* src, size_t n) { memcpy(blob.data() + off, src, n * 4); }
+void put_op(std::vector<char>& blob, size_t off, const float* src, size_t n, int prec) {
+  if (prec == PREC_FP32) { memcpy(blob.data() + off, src, n * 4); return; }
+  uint16_t* d = reinterpret_cast<uint16_t*>(blob.data() + off);
+  if (prec == PREC_BF16) for (size_t i = 0; i < n; ++i) d[i] = f32_to_bf16(src[i]);
+  else for (size_t i = 0; i < n; ++i) d[i] = f32_to_f16(src[i]);
+}
+
+const std::vector<float>& P(const effocr_encoder* e, const std::string& n) { return e->params[e->index.at(n)].data; }
+
+void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
+  const int D = e->vit.D;
+  std::vector<float> cp(D);
+  const auto& cls = P(e, "cls_token"); const auto& pos = P(e, "pos_embed");
+  for (int d = 0; d < D; ++d) cp[d] = cls[d] + pos[d];
+  put_f32(blob, e->off_clspos0, cp.data(), D);
+  put_f32(blob, e->off_pos, pos.data(), pos.size());
+  put_f32(blob, e->off_patchb, P(e, "patch_embed.proj.bias").data(), D);
+  put_op(blob, e->off_patchw, P(e, "patch_embed.proj.weight").data(), (size_t)D * 768, e->prec);
+  for (int i = 0; i < e->vit.depth; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    const VitLayerOff& L = e->layers[i];
+    put_f32(blob, L.ln1w, P(e, p + "norm1.weight").data(), D);
+    put_f32(blob, L.ln1b, P(e, p + "norm1.bias").data(), D);
+    put_f32(blob, L.qkvb, P(e, p + "attn.qkv.bias").data(), 3 * (size_t)D);
+    put_f32(blob, L.projb, P(e, p + "attn.proj.bias").data(), D);
+    put_f32(blob, L.ln2w, P(e, p + "norm2.weight").data(), D);
+    put_f32(blob, L.ln2b, P(e, p + "norm2.bias").data(), D);
+    put_f32(blob, L.fc1b, P(e, p + "mlp.fc1.bias").data(), e->vit.mlp);
+    put_f32(blob, L.fc2b, P(e, p + "mlp.fc2.bias").data(), D);
+    put_op(blob, L.qkvw, P(e, p + "attn.qkv.weight").data(), 3 * (size_t)D * D, e->prec);
+    put_op(blob, L.projw, P(e, p + "attn.proj.weight").data(), (size_t)D * D, e->prec);
+    put_op(blob, L.fc1w, P(e, p + "mlp.fc1.weight").data(), (size_t)e->vit.mlp * D, e->prec);
+    put_op(blob, L.fc2w, P(e, p + "mlp.fc2.weight").data(), (size_t)D * e->vit.mlp, e->prec);
+  }
+  put_f32(blob, e->off_normw, P(e, "norm.weight").data(), D);
+  put_f32(blob, e->off_normb, P(e, "norm.bias").data(), D);
+}
+
+// BatchNorm (eval, eps 1e-5) folded into the conv: w' = w * g/sqrt(v+eps), b' = beta - mean*g/sqrt(v+eps);
+// weight re-laid-out from torch [Cout,Cin,KH,KW] to [Cout][KH][KW][Cin] (K-contiguous, Cin fastest).
+void pack_resnet(const effocr_encoder* e, std::vector<char>& blob) {
+  for (size_t ci = 0; ci < e->convs.size(); ++ci) {
+    const ConvSpec& c = e->convs[ci];
+    const auto& w = P(e, c.w);
+    const auto& g = P(e, c.bn + ".weight"); const auto& bt = P(e, c.bn + ".bias");
+    const auto& mu = P(e, c.bn + ".running_mean"); const auto& var = P(e, c.bn + ".running_var");
+    const int K = c.k * c.k * c.cin;
+    const int Kp = (ci == 0) ? CONV1_KPAD : K;
+    float* wd = reinterpret_cast<float*>(blob.data() + c.w_off);
+    float* bd = reinterpret_cast<float*>(blob.data() + c.b_off);
+    for (int co = 0; co < c.cout; ++co) {
+      const double sc = (double)g[co] / sqrt((double)var[co] + 1e-5);
+      bd[co] = (float)((double)bt[co] - (double)mu[co] * sc);
+      for (int kk = 0; kk < Kp; ++kk) wd[(size_t)co * Kp + kk] = 0.f;
+      for (int ky = 0; ky < c.k; ++ky)
+        for (int kx = 0; kx < c.k; ++kx)
+          for (int cc = 0; cc < c.cin; ++cc) {
+            const float v = w[(((size_t)co * c.cin + cc) * c.k + ky) * c.k + kx];
+            wd[(size_t)co * Kp + (ky * c.k + kx) * c.cin + cc] = (float)((double)v * sc);
+          }
+    }
+  }
+}
+
+struct VitWs { size_t x, xn, qkv, att, h, total; };
+VitWs vit_ws(const effocr_encoder* e, int B) {
+  const size_t M = (size_t)B * e->T, D = e->vit.D, es = prec_esize(e->prec);
+  Alloc a; VitWs w;
+  w.x = a.take(M * D * 4);
+  w.xn = a.take(M * D * es);
+  w.qkv = a.take(M * 3 * D * es);
+  w.att = a.take(M * D * es);
+  size_t hb = M * e->vit.mlp * es, pb = (size_t)B * e->P * 768 * es;
+  w.h = a.take(hb > pb ? hb : pb);          // patches (im2col rows) alias the MLP hidden buffer
+  w.total = a.off;
+  return w;
+}
+
+int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, char* ws, hipStream_t s) {
+  const VitWs w = vit_ws(e, B);
+  const int D = e->vit.D, T = e->T, Pn = e->P, M = B * T, prec = e->prec;
+  const char* wb = e->wdev;
+  float* xs = reinterpret_cast<float*>(ws + w.x);
+  void* xn = ws + w.xn; void* qkv = ws + w.qkv; void* att = ws + w.att; void* hb = ws + w.h;
+  auto F = [&](size_t off) { return reinterpret_cast<const float*>(wb + off); };
+  int rc;
+  if ((rc = im2col_patch16(prec, x, B, e->img, e->img, hb, s))) return rc;
+  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, s))) return rc;
+  GemmArgs g{};
+  g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
+  g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn;
+  if ((rc = gemm_nt(prec, EPI_PATCH, g, s))) return rc;
+  for (int i = 0; i < e->vit.depth; ++i) {
+    const VitLayerOff& L = e->layers[i];
+    if ((rc = layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s))) return rc;
+    g = GemmArgs{};
+    g.X = xn; g.ldx = D; g.W = wb + L.qkvw; g.ldw = D; g.bias = F(L.qkvb); g.out = qkv; g.ldo = 3 * D;
+    g.M = M; g.N = 3 * D; g.K = D;
+    if ((rc = gemm_nt(prec, EPI_BIAS, g, s))) return rc;
+    if ((rc = attention(prec, qkv, att, B, T, e->vit.heads, s))) return rc;
+    g = GemmArgs{};
+    g.X = att; g.ldx = D; g.W = wb + L.projw; g.ldw = D; g.bias = F(L.projb); g.out = xs; g.ldo = D;
+    g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = D;
+    if ((rc = gemm_nt(prec, EPI_BIAS_RESID, g, s))) return rc;
+    if ((rc = layernorm_rows(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s))) return rc;
+    g = GemmArgs{};
+    g.X = xn; g.ldx = D; g.W = wb + L.fc1w; g.ldw = D; g.bias = F(L.fc1b); g.out = hb; g.ldo = e->vit.mlp;
+    g.M = M; g.N = e->vit.mlp; g.K = D;
+    if ((rc = gemm_nt(prec, EPI_BIAS_GELU, g, s))) return rc;
+    g = GemmArgs{};
+    g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
+    g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp;
+    if ((rc = gemm_nt(prec, EPI_BIAS_RESID, g, s))) return rc;
+  }
+  return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, emb, s);
+}
+
+struct ResWs { size_t col, a, b, c, total; };
+ResWs resnet_ws(const effocr_encoder* e, int B) {
+  const size_t oh = (size_t)e->img / 2;
+  Alloc al; ResWs w;
+  w.col = al.take((size_t)B * oh * oh * CONV1_KPAD * 4);
+  const size_t act = (size_t)B * oh * oh * 64 * 4;     // largest activation: conv1 output
+  w.a = al.take(act); w.b = al.take(act); w.c = al.take(act);
+  w.total = al.off;
+  return w;
+}
+
+int resnet_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, char* ws, hipStream_t s) {
+  const ResWs w = resnet_ws(e, B);
+  const char* wb = e->wdev;
+  float* col = reinterpret_cast<float*>(ws + w.col);
+  float* bufs[3] = {reinterpret_cast<float*>(ws + w.a), reinterpret_cast<float*>(ws + w.b),
+                    reinterpret_cast<float*>(ws + w.c)};
+  auto WT = [&](const ConvSpec& c) { return reinterpret_cast<const float*>(wb + c.w_off); };
+  auto BS = [&](const ConvSpec& c) { return reinterpret_cast<const float*>(wb + c.b_off); };
+  int rc;
+  int H = e->img, OH = H / 2;
+  // conv1 7x7/2 (+bn1+relu): im2col rows [B*OH*OW, 160] then a 1x1 implicit GEMM
+  if ((rc = im2col_conv1(x, col, B, H, H, OH, OH, s))) return rc;
+  ConvArgs a{};
+  a.in = col; a.w = WT(e->convs[0]); a.bias = BS(e->convs[0]); a.resid = nullptr; a.out = bufs[0];
+  a.B = B * OH * OH; a.H = 1; a.W = 1; a.Cin = CONV1_KPAD; a.Cout = 64; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.OH = 1; a.OW = 1; a.relu = 1;
+  if ((rc = conv2d_nhwc(a, s))) return rc;
+  H = OH; OH = (H + 2 - 3) / 2 + 1;
+  if ((rc = maxpool3x3s2_nhwc(bufs[0], bufs[1], B, H, H, 64, OH, OH, s))) return rc;
+  H = OH;
+  int cur = 1;                       // bufs[cur] holds the block input
+  size_t ci = 1;
+  for (int li = 1; li <= 4; ++li) {
+    for (int bi = 0; bi < 2; ++bi) {
+      const ConvSpec& c1 = e->convs[ci];
+      const ConvSpec& c2 = e->convs[ci + 1];
+      const bool down = (bi == 0 && li > 1);
+      const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+      const int OHb = (H + 2 - 3) / c1.stride + 1;
+      ConvArgs k1{};
+      k1.in = bufs[cur]; k1.w = WT(c1); k1.bias = BS(c1); k1.out = bufs[t1];
+      k1.B = B; k1.H = H; k1.W = H; k1.Cin = c1.cin; k1.Cout = c1.cout; k1.KH = 3; k1.KW = 3; k1.stride = c1.stride; k1.pad = 1;
+      k1.OH = OHb; k1.OW = OHb; k1.relu = 1;
+      if ((rc = conv2d_nhwc(k1, s))) return rc;
+      const float* idt = bufs[cur];
+      if (down) {
+        const ConvSpec& cd = e->convs[ci + 2];
+        ConvArgs kd{};
+        kd.in = bufs[cur]; kd.w = WT(cd); kd.bias = BS(cd); kd.out = bufs[t2];
+        kd.B = B; kd.H = H; kd.W = H; kd.Cin = cd.cin; kd.Cout = cd.cout; kd.KH = 1; kd.KW = 1; kd.stride = cd.stride; kd.pad = 0;
+        kd.OH = OHb; kd.OW = OHb; kd.relu = 0;
+        if ((rc = conv2d_nhwc(kd, s))) return rc;
+        idt = bufs[t2];
+      }
+      // conv2 + bn2 + identity + relu; output overwrites the block input buffer when it is not the identity
+      float* outb = down ? bufs[cur] : bufs[t2];
+      ConvArgs k2{};
+      k2.in = bufs[t1]; k2.w = WT(c2); k2.bias = BS(c2); k2.resid = idt; k2.out = outb;
+      k2.B = B; k2.H = OHb; k2.W = OHb; k2.Cin = c2.cin; k2.Cout = c2.cout; k2.KH = 3; k2.KW = 3; k2.stride = 1; k2.pad = 1;
+      k2.OH = OHb; k2.OW = OHb; k2.relu = 1;
+      if ((rc = conv2d_nhwc(k2, s))) return rc;
+      cur = down ? cur : t2;
+      H = OHb;
+      ci += down ? 3 : 2;
+    }
+  }
+  return global_avgpool_nhwc(bufs[cur], emb, B, H * H, 512, l2, s);
+}
+
+hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace
+}  // namespace effocr
+
+extern "C" {
+
+int effocr_abi_version(void) { return EFFOCR_ABI_VERSION; }
+const char* effocr_last_error(void) { return effocr::g_err.c_str(); }
+
+int effocr_encoder_create(const char* arch, int img_size, int precision, effocr_encoder_t** out) {
+  if (!arch || !out) return fail(EFFOCR_EINVAL, "encoder_create: NULL argument");
+  if (precision < 0 || precision > 2) return fail(EFFOCR_EINVAL, "encoder_create: unknown precision");
+  std::unique_ptr<effocr_encoder> e(new effocr_encoder());
+  e->arch = arch; e->img = img_size; e->prec = precision;
+  const std::string a = arch;
+  if (a == "vit_small_patch16_224") e->vit = {384, 12, 6, 1536};
+  else if (a == "vit_base_patch16_224") e->vit = {768, 12, 12, 3072};
+  else if (a == "vit_tiny_test") e->vit = {128, 2, 2, 512};
+  else if (a != "resnet18") return fail(EFFOCR_EUNSUPPORTED, "encoder_create: unsupported architecture '" + a + "'");
+  if (a == "resnet18") {
+    if (img_size < 32 || img_size % 32) return fail(EFFOCR_EINVAL, "resnet18: img_size must be a positive multiple of 32");
+    e->is_vit = false; e->D = 512;
+    e->prec = PREC_FP32;           // the conv path runs exact-fp32 MFMA in every mode
+    build_resnet18(e.get());
+  } else {
+    if (img_size < 16 || img_size % 16) return fail(EFFOCR_EINVAL, "vit: img_size must be a positive multiple of 16");
+    const int T = (img_size / 16) * (img_size / 16) + 1;
+    if (!(T <= 64 || (T > 192 && T <= 224)))
+      return fail(EFFOCR_EUNSUPPORTED, "vit: token count must be <= 64 or in (192, 224] (img_size 224)");
+    e->is_vit = true; e->D = e->vit.D;
+    build_vit(e.get());
+  }
+  *out = e.release();
+  return EFFOCR_OK;
+}
+
+void effocr_encoder_destroy(effocr_encoder_t* enc) { delete enc; }
+int effocr_encoder_embed_dim(const effocr_encoder_t* enc) { return enc ? enc->D : 0; }
+int effocr_encoder_num_params(const effocr_encoder_t* enc) { return enc ? (int)enc->params.size() : 0; }
+const char* effocr_encoder_param_name(const effocr_encoder_t* enc, int i) {
+  if (!enc || i < 0 || i >= (int)enc->params.size()) return nullptr;
+  return enc->params[i].name.c_str();
+}
+int64_t effocr_encoder_param_numel(const effocr_encoder_t* enc, int i) {
+  if (!enc || i < 0 || i >= (int)enc->params.size()) return -1;
+  return enc->params[i].numel;
+}
+
+int effocr_encoder_set_param(effocr_encoder_t* enc, const char* name, const float* host, int64_t numel) {
+  if (!enc || !name || !host) return fail(EFFOCR_EINVAL, "set_param: NULL argument");
+  auto it = enc->index.find(name);
+  if (it == enc->index.end()) return fail(EFFOCR_EINVAL, std::string("set_param: unknown parameter '") + name + "'");
+  Param& p = enc->params[it->second];
+  if (p.numel != numel)
+    return fail(EFFOCR_EINVAL, std::string("set_param: '") + name + "' expects " + std::to_string(p.numel) +
+                                   " elements, got " + std::to_string(numel));
+  p.data.assign(host, host + numel);
+  p.set = true;
+  return EFFOCR_OK;
+}
+
+size_t effocr_encoder_weights_bytes(const effocr_encoder_t* enc) { return enc ? enc->wbytes : 0; }
+
+int effocr_encoder_upload(effocr_encoder_t* enc, void* weights_dev, size_t bytes) {
+  if (!enc || !weights_dev) return fail(EFFOCR_EINVAL, "upload: NULL argument");
+  if (bytes < enc->wbytes) return fail(EFFOCR_EWORKSPACE, "upload: weight buffer too small");
+  for (const Param& p : enc->params)
+    if (!p.set) return fail(EFFOCR_ESTATE, "upload: parameter '" + p.name + "' was never set");
+  std::vector<char> blob(enc->wbytes, 0);
+  if (enc->is_vit) pack_vit(enc, blob); else pack_resnet(enc, blob);
+  const hipError_t er = hipMemcpy(weights_dev, blob.data(), enc->wbytes, hipMemcpyHostToDevice);
+  if (er != hipSuccess) return fail(EFFOCR_EHIP, std::string("upload: hipMemcpy: ") + hipGetErrorString(er));
+  enc->wdev = static_cast<const char*>(weights_dev);
+  return EFFOCR_OK;
+}
+
+size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch) {
+  if (!enc || batch <= 0) return 0;
+  return enc->is_vit ? vit_ws(enc, batch).total : resnet_ws(enc, batch).total;
+}
+
+int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev, int l2_normalize,
+                           void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!enc) return fail(EFFOCR_EINVAL, "forward: NULL encoder");
+  if (batch < 0) return fail(EFFOCR_EINVAL, "forward: negative batch");
+  if (batch == 0) return EFFOCR_OK;
+  if (!x_dev || !emb_dev || !workspace_dev) return fail(EFFOCR_EINVAL, "forward: NULL device pointer");
+  if (!enc->wdev) return fail(EFFOCR_ESTATE, "forward: weights were not uploaded");
+  if (workspace_bytes < effocr_encoder_workspace_bytes(enc, batch)) return fail(EFFOCR_EWORKSPACE, "forward: workspace too small");
+  if ((int64_t)batch * (enc->is_vit ? enc->T : enc->img * enc->img) >= (int64_t)1 << 30)
+    return fail(EFFOCR_EUNSUPPORTED, "forward: batch too large for 32-bit row indices");
+  char* ws = static_cast<char*>(workspace_dev);
+  return enc->is_vit ? vit_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream))
+                     : resnet_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream));
+}
+
+size_t effocr_knn_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k) { return knn_workspace_bytes(nq, ntotal, d, k); }
+
+int effocr_knn_ip_topk(const float* q_dev, int64_t nq, const float* xb_dev, int64_t ntotal, int d, int k,
+                       float* dist_dev, int64_t* idx_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (nq > 0 && (!q_dev || !dist_dev || !idx_dev)) return fail(EFFOCR_EINVAL, "knn: NULL device pointer");
+  if (nq > 0 && ntotal > 0 && !xb_dev) return fail(EFFOCR_EINVAL, "knn: NULL index pointer");
+  return knn_ip_topk(q_dev, nq, xb_dev, ntotal, d, k, dist_dev, idx_dev, workspace_dev, workspace_bytes, S(stream));
+}
+
+int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void* stream) {
+  if (n > 0 && (!x_dev || !y_dev)) return fail(EFFOCR_EINVAL, "l2_normalize: NULL device pointer");
+  return l2_normalize_rows(x_dev, n, d, y_dev, S(stream));
+}
+
+int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64_t n_keep, int d, float* dst_dev, void* stream) {
+  if (n_keep > 0 && (!src_dev || !keep_rows_dev || !dst_dev)) return fail(EFFOCR_EINVAL, "gather_rows: NULL device pointer");
+  return gather_rows(src_dev, keep_rows_dev, n_keep, d, dst_dev, S(stream));
+}
+
+int effocr_op_linear(int precision, int epilogue, const void* x_dev, const void* w_dev, const float* bias_dev,
+                     const float* resid_dev, void* out_dev, int m, int n, int k, void* stream) {
+  if (epilogue < 0 || epilogue > 2) return fail(EFFOCR_EINVAL, "op_linear: unknown epilogue");
+  GemmArgs g{};
+  g.X = x_dev; g.ldx = k; g.W = w_dev; g.ldw = k; g.bias = bias_dev; g.out = out_dev; g.ldo = n;
+  g.resid = resid_dev; g.ldr = n; g.M = m; g.N = n; g.K = k;
+  return gemm_nt(precision, epilogue, g, S(stream));
+}
+
+int effocr_op_layernorm(int out_precision, const float* x_dev, int64_t rows, int d, const float* gamma_dev,
+                        const float* beta_dev, float eps, void* out_dev, void* stream) {
+  return layernorm_rows(out_precision, x_dev, rows, d, gamma_dev, beta_dev, eps, out_dev, S(stream));
+}
+
+int effocr_op_attention(int precision, const void* qkv_dev, void* out_dev, int batch, int tokens, int heads, void* stream) {
+  return attention(precision, qkv_dev, out_dev, batch, tokens, heads, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the EffOCR recognizer path.
+// wave = 64 lanes everywhere; no portability layer — this code targets gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/effocr_hip.h"
+
+namespace effocr {
+
+// ---------------------------------------------------------------- vector types / MFMA fragments
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t u32x4;
+typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t u32x2;
+
+struct bf16_t { typedef __bf16 T; typedef bf16x8 V8; };
+struct f16_t  { typedef _Float16 T; typedef f16x8 V8; };
+
+// 16-bit operand traits (bf16 / f16): storage type, 8-wide fragment, MFMA 32x32x16.
+template <typename E> struct Op16;
+template <> struct Op16<__bf16> {
+  typedef bf16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Op16<_Float16> {
+  typedef f16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// MFMA 32x32 C/D fragment map (dtype independent on gfx950): lane l, register r in [0,16):
+//   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// wave id as a provably wave-uniform scalar
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): consecutive *logical* ids
+// land on the same XCD so that neighbouring tiles share that XCD's L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, in = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + in;
+}
+
+// erf-based GELU (torch.nn.GELU default, what timm's Mlp uses)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+
+// pack 4 floats into 4 x 16-bit (8 bytes) / 2 floats
+template <typename E> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+  typedef __attribute__((__vector_size__(4 * sizeof(E)))) E V4;
+  V4 v = {(E)a, (E)b, (E)c, (E)d};
+  return __builtin_bit_cast(u32x2, v);
+}
+
+// ---------------------------------------------------------------- host side error plumbing
+// status codes: enum effocr_status in include/effocr_hip.h
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int check_launch(const char* what);
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace effocr

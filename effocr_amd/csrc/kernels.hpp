@@ -1,0 +1,57 @@
+// Internal launcher interface between the C-ABI layer (api.hip) and the kernel files.
+#pragma once
+#include "common.hpp"
+
+namespace effocr {
+
+enum { PREC_BF16 = 0, PREC_FP16 = 1, PREC_FP32 = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_PATCH = 3 };
+
+static inline int prec_esize(int prec) { return prec == PREC_FP32 ? 4 : 2; }
+
+struct GemmArgs {
+  const void* X; int64_t ldx;       // activations [M,K] (elements of the operand type)
+  const void* W; int64_t ldw;       // weights     [N,K]
+  const float* bias;                // [N]
+  void* out; int64_t ldo;           // [M,N] (operand type, or fp32 for RESID / PATCH)
+  const float* resid; int64_t ldr;  // EPI_BIAS_RESID: fp32 residual (may alias out)
+  const float* pos;                 // EPI_PATCH: pos_embed rows [1+P, N] fp32
+  int M, N, K;
+  int P;                            // EPI_PATCH: patches per image
+};
+
+// gemm.hip
+int gemm_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
+
+// vit_ops.hip
+int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
+                   float eps, void* out, hipStream_t s);
+int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s);
+int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, hipStream_t s);
+int attention(int prec, const void* qkv, void* out, int B, int T, int heads, hipStream_t s);
+int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, const float* beta, float eps,
+                   int l2norm, float* emb, hipStream_t s);
+
+// knn.hip
+size_t knn_workspace_bytes(int64_t B, int64_t N, int D, int k);
+int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, int k, float* dist, int64_t* idx,
+                void* ws, size_t ws_bytes, hipStream_t s);
+int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s);
+int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);
+
+// resnet.hip
+struct ConvArgs {
+  const float* in;      // NHWC fp32 [B,H,W,Cin]
+  const float* w;       // [Cout][KH*KW*Cin] fp32, BN folded
+  const float* bias;    // [Cout] folded BN shift
+  const float* resid;   // optional NHWC [B,OH,OW,Cout]
+  float* out;           // NHWC [B,OH,OW,Cout]
+  int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu;
+};
+int conv2d_nhwc(const ConvArgs& a, hipStream_t s);
+// conv1 7x7/2 pad 3 im2col straight from the NCHW input: rows [B*OH*OW][160] (147 taps (ky,kx,c) + zero pad)
+int im2col_conv1(const float* x, float* col, int B, int H, int W, int OH, int OW, hipStream_t s);
+int maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
+int global_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, int l2norm, hipStream_t s);
+
+}  // namespace effocr

@@ -1,0 +1,357 @@
+// Exact inner-product k-NN against the reference-glyph index: the faiss.IndexFlatIP.search role.
+//
+// Reference call sites: infer_effocr.py:184-187,317 (FaissKNN(index_init_fn=faiss.IndexFlatIP),
+// knn_func(emb, k=10)); infer_effocr_onnx_multi.py:372 (k=1); train_effocr_recognizer.py:47-52
+// (index rows = L2-normalised embeddings).  Semantics: S = Q.X^T in fp32, per query the k largest
+// scores in descending order with their row ids; k > ntotal pads (score -FLT_MAX, id -1).
+//
+// Design for gfx950:
+//   * S is never materialised.  A workgroup owns 128 queries x a contiguous chunk of index rows and
+//     walks the chunk in 128-row tiles with the shared fp32 MFMA tile pipeline (tile128.hpp):
+//     v_mfma_f32_32x32x2_f32, exact fp32, k ascending — so every score is bit-for-bit the
+//     ascending-k fmaf chain the C oracle (oracle/flat_ip.c) computes, and ids match exactly even
+//     at near-ties.  No split-K (it would break the chain).
+//   * the MFMA is issued swapped (rows = index entries, cols = queries): a lane's 16 accumulators
+//     of a 32x32 tile all belong to ONE query, index id ascending with the register number, so the
+//     running top-k is a lane-local sorted list in registers (one threshold compare per score in
+//     the common case; ties keep the earlier = lower id).
+//   * per workgroup the 4 partial lists of a query (2 index-half waves x 2 half-waves) are merged
+//     through LDS; per-chunk partial results go to the workspace and a second tiny kernel merges
+//     the chunks (skipped when there is a single chunk).
+// Tie rule (defined by this implementation, faiss leaves it unspecified): equal scores rank by
+// ascending row id.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "tile128.hpp"
+#include <float.h>
+#include <limits.h>
+
+namespace effocr {
+namespace {
+
+using namespace tile128;
+
+constexpr int ID_NONE = INT_MAX;          // internal sentinel id (ranks after every real id)
+constexpr int MAX_CHUNKS = 256;
+
+__device__ __forceinline__ bool before(float s1, int i1, float s2, int i2) {
+  return (s1 > s2) || (s1 == s2 && i1 < i2);
+}
+
+// sorted-list insert, statically indexed (register resident).  Candidates arrive in ascending id
+// order per lane, so a strict score compare keeps the lower id ahead on ties.
+template <int KMAX>
+__device__ __forceinline__ void topk_insert(float (&ls)[KMAX], int (&li)[KMAX], float s, int id) {
+#pragma unroll
+  for (int t = KMAX - 1; t >= 1; --t) {
+    const bool gp = s > ls[t - 1];
+    const bool g = s > ls[t];
+    ls[t] = gp ? ls[t - 1] : (g ? s : ls[t]);
+    li[t] = gp ? li[t - 1] : (g ? id : li[t]);
+  }
+  const bool g0 = s > ls[0];
+  li[0] = g0 ? id : li[0];
+  ls[0] = g0 ? s : ls[0];
+}
+
+struct KnnArgs {
+  const float* q; int B;
+  const float* xb; int N; int D;
+  int k;
+  int nqt;                // query tiles
+  int tiles_per_chunk;    // 128-row index tiles per chunk
+  int nchunks;
+  float* pdist; int* pidx;          // partial lists [nchunks][B][KMAX]   (nchunks > 1)
+  float* dist; int64_t* idx;        // final [B][k]                        (nchunks == 1)
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
+  constexpr int MERGEB = 128 * 4 * KMAX * 8;
+  constexpr int LDSB = GEMM_LDS > MERGEB ? GEMM_LDS : MERGEB;
+  __shared__ __attribute__((aligned(16))) char smem[LDSB];
+  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  const int w = wave_id(), wn = w >> 1, wm = w & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = bid % a.nqt, chunk = bid / a.nqt;
+  const int q0 = qt * 128;
+  const int ntiles = (a.N + 127) / 128;
+  const int t0 = chunk * a.tiles_per_chunk;
+  const int t1 = min(t0 + a.tiles_per_chunk, ntiles);
+  const int nks = a.D / 32;
+  const int nstage = (t1 - t0) * nks;
+
+  float ls[2][KMAX];
+  int li[2][KMAX];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { ls[j][t] = -FLT_MAX; li[j][t] = ID_NONE; }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 rx[4], rq[4];
+  if (nstage > 0) {
+    stage_load<float>(rx, a.xb, a.D, t0 * 128, a.N, 0, tid);
+    stage_load<float>(rq, a.q, a.D, q0, a.B, 0, tid);
+    stage_store<float>(rx, smem, tid);
+    stage_store<float>(rq, smem + TILEB, tid);
+  }
+  __syncthreads();
+
+  int tile = t0, ks = 0;
+  for (int s = 0; s < nstage; ++s) {
+    char* cur = smem + (s & 1) * STAGEB;
+    char* nxt = smem + ((s & 1) ^ 1) * STAGEB;
+    const bool more = (s + 1) < nstage;
+    int ntile = tile, nksn = ks + 1;
+    if (nksn == nks) { nksn = 0; ntile = tile + 1; }
+    if (more) {
+      stage_load<float>(rx, a.xb, a.D, ntile * 128, a.N, nksn * ROWB, tid);
+      stage_load<float>(rq, a.q, a.D, q0, a.B, nksn * ROWB, tid);
+    }
+    stage_mma<float>(acc, cur, cur + TILEB, wn, wm, lane);
+    if (ks == nks - 1) {
+      // scores of index tile `tile` are complete: feed the per-lane top-k lists, reset.
+      // Per query column j a lane holds 32 candidates (i, r) with ascending index id; a bitmask of
+      // those beating the current k-th score is drained lowest-bit-first through ONE insertion site
+      // (keeps everything statically indexed / register resident and the code small).
+      const int nbase = tile * 128 + wn * 64 + 4 * half;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        uint32_t hits = 0;
+        const float thr = ls[j][KMAX - 1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
+            hits |= (n < a.N && acc[i][j][r] > thr) ? (1u << (i * 16 + r)) : 0u;
+          }
+        if (__any(hits != 0)) {
+          // wave-uniform walk over the 32 candidate slots (uniform index -> register-relative
+          // addressing); lanes whose bit is set insert, ascending id order is preserved
+          float cand[32];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { cand[r] = acc[0][j][r]; cand[16 + r] = acc[1][j][r]; }
+#pragma unroll 1
+          for (int bsel = 0; bsel < 32; ++bsel) {
+            const bool mine = (hits >> bsel) & 1u;
+            if (__any(mine)) {
+              const int r = bsel & 15;
+              const int n = nbase + (bsel >> 4) * 32 + (r & 3) + 8 * (r >> 2);
+              const float sc = cand[bsel];
+              if (mine) topk_insert<KMAX>(ls[j], li[j], sc, n);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    }
+    if (more) {
+      stage_store<float>(rx, nxt, tid);
+      stage_store<float>(rq, nxt + TILEB, tid);
+    }
+    __syncthreads();
+    tile = ntile; ks = nksn;
+  }
+
+  // ---- merge the 4 partial lists of every query through LDS (staging buffers are dead now)
+  float* mS = reinterpret_cast<float*>(smem);                       // [128][4][KMAX]
+  int* mI = reinterpret_cast<int*>(smem + 128 * 4 * KMAX * 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ql = wm * 64 + j * 32 + r31;
+    const int src = wn * 2 + half;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      mS[(ql * 4 + src) * KMAX + t] = ls[j][t];
+      mI[(ql * 4 + src) * KMAX + t] = li[j][t];
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int qg = q0 + tid;
+    if (qg < a.B) {
+      const float* s0 = mS + tid * 4 * KMAX;
+      const int* i0 = mI + tid * 4 * KMAX;
+      int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+      const int nout = (a.nchunks == 1) ? a.k : KMAX;
+      for (int o = 0; o < nout; ++o) {
+        float bs = -FLT_MAX; int bi = ID_NONE; int bsrc = -1;
+        if (o < KMAX) {
+          if (p0 < KMAX) { bs = s0[p0]; bi = i0[p0]; bsrc = 0; }
+          if (p1 < KMAX && (bsrc < 0 || before(s0[KMAX + p1], i0[KMAX + p1], bs, bi))) { bs = s0[KMAX + p1]; bi = i0[KMAX + p1]; bsrc = 1; }
+          if (p2 < KMAX && (bsrc < 0 || before(s0[2 * KMAX + p2], i0[2 * KMAX + p2], bs, bi))) { bs = s0[2 * KMAX + p2]; bi = i0[2 * KMAX + p2]; bsrc = 2; }
+          if (p3 < KMAX && (bsrc < 0 || before(s0[3 * KMAX + p3], i0[3 * KMAX + p3], bs, bi))) { bs = s0[3 * KMAX + p3]; bi = i0[3 * KMAX + p3]; bsrc = 3; }
+          p0 += (bsrc == 0); p1 += (bsrc == 1); p2 += (bsrc == 2); p3 += (bsrc == 3);
+        }
+        if (a.nchunks == 1) {
+          a.dist[(int64_t)qg * a.k + o] = bs;
+          a.idx[(int64_t)qg * a.k + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
+        } else {
+          const int64_t off = ((int64_t)chunk * a.B + qg) * KMAX + o;
+          a.pdist[off] = bs;
+          a.pidx[off] = bi;
+        }
+      }
+    }
+  }
+}
+
+// merge the per-chunk sorted lists of one query: one wave per query, lane L owns chunks L, L+64, ...
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
+                                                        int B, int nchunks, int k, float* __restrict__ dist,
+                                                        int64_t* __restrict__ idx) {
+  constexpr int LPL = MAX_CHUNKS / 64;
+  const int lane = threadIdx.x & 63;
+  const int qg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qg >= B) return;                                   // whole wave exits together
+  int ptr[LPL];
+#pragma unroll
+  for (int c = 0; c < LPL; ++c) ptr[c] = 0;
+  for (int o = 0; o < k; ++o) {
+    float bs = -FLT_MAX; int bi = ID_NONE; int bc = -1;
+    if (o < KMAX) {
+#pragma unroll
+      for (int c = 0; c < LPL; ++c) {
+        const int chunk = lane + 64 * c;
+        if (chunk < nchunks && ptr[c] < KMAX) {
+          const int64_t off = ((int64_t)chunk * B + qg) * KMAX + ptr[c];
+          const float s = pdist[off]; const int i = pidx[off];
+          if (bc < 0 || before(s, i, bs, bi)) { bs = s; bi = i; bc = c; }
+        }
+      }
+    }
+    // wave argmax with the compound order; real ids are unique, so the owner is identifiable
+    float ws = bs; int wi = bi;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(ws, off, 64);
+      const int oi = __shfl_xor(wi, off, 64);
+      if (before(os, oi, ws, wi)) { ws = os; wi = oi; }
+    }
+    if (wi != ID_NONE && bc >= 0 && bi == wi) {
+#pragma unroll
+      for (int c = 0; c < LPL; ++c) ptr[c] += (c == bc);
+    }
+    if (lane == 0) {
+      dist[(int64_t)qg * k + o] = ws;
+      idx[(int64_t)qg * k + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
+    }
+  }
+}
+
+// y = x / max(||x||_2, 1e-12) row-wise (F.normalize, infer_effocr.py:316); one wave per row
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int64_t B, int D, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* xr = x + row * D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss += xr[d] * xr[d];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  for (int d = lane; d < D; d += 64) y[row * D + d] = xr[d] / nrm;
+}
+
+// dst[i] = src[rows[i]]  (IndexFlat.remove_ids compaction: gather of the kept rows)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ rows,
+                                                          int64_t n, int D, float* __restrict__ dst) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = n * D;
+  if (id >= total) return;
+  const int64_t i = id / D;
+  const int d = (int)(id - i * D);
+  dst[id] = src[rows[i] * D + d];
+}
+
+int pick_kmax(int k) { return k <= 1 ? 1 : (k <= 16 ? 16 : (k <= 32 ? 32 : 0)); }
+
+struct Plan { int nqt, ntiles, tpc, nchunks, kmax; };
+
+Plan make_plan(int64_t B, int64_t N, int k) {
+  Plan p;
+  p.kmax = pick_kmax(k);
+  p.nqt = (int)((B + 127) / 128);
+  p.ntiles = (int)((N + 127) / 128);
+  if (p.ntiles < 1) p.ntiles = 1;
+  // aim for ~2 resident workgroups per CU (512) without making chunks shorter than one tile
+  int want = 512 / (p.nqt > 0 ? p.nqt : 1);
+  if (want < 1) want = 1;
+  if (want > MAX_CHUNKS) want = MAX_CHUNKS;
+  if (want > p.ntiles) want = p.ntiles;
+  p.tpc = (p.ntiles + want - 1) / want;
+  p.nchunks = (p.ntiles + p.tpc - 1) / p.tpc;
+  return p;
+}
+
+template <int KMAX>
+int launch_knn(const KnnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((knn_partial_kernel<KMAX>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a);
+  int rc = check_launch("knn_partial");
+  if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
+  hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
+                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx);
+  return check_launch("knn_merge");
+}
+
+}  // namespace
+
+size_t knn_workspace_bytes(int64_t B, int64_t N, int D, int k) {
+  (void)D;
+  if (B <= 0 || k <= 0) return 0;
+  const Plan p = make_plan(B, N, k);
+  if (p.kmax == 0 || p.nchunks <= 1) return 256;
+  return align_up((size_t)p.nchunks * (size_t)B * p.kmax * 8, 256) + 256;
+}
+
+int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, int k, float* dist, int64_t* idx,
+                void* ws, size_t ws_bytes, hipStream_t s) {
+  if (B < 0 || N < 0 || D <= 0 || k <= 0) return fail(EFFOCR_EINVAL, "knn: bad sizes");
+  if (B == 0) return EFFOCR_OK;
+  if (D % 32 != 0) return fail(EFFOCR_EUNSUPPORTED, "knn: embedding dim must be a multiple of 32");
+  if (N >= (int64_t)INT_MAX - 256 || B >= (int64_t)INT_MAX - 256) return fail(EFFOCR_EUNSUPPORTED, "knn: index or batch too large");
+  const Plan p = make_plan(B, N, k);
+  if (p.kmax == 0) return fail(EFFOCR_EUNSUPPORTED, "knn: k > 32 is not supported by the fused top-k kernel");
+  if (ws_bytes < knn_workspace_bytes(B, N, D, k)) return fail(EFFOCR_EWORKSPACE, "knn: workspace too small");
+  KnnArgs a;
+  a.q = q; a.B = (int)B; a.xb = (N > 0) ? xb : q; a.N = (int)N; a.D = D; a.k = k;
+  a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
+  a.pdist = static_cast<float*>(ws);
+  a.pidx = reinterpret_cast<int*>(static_cast<char*>(ws) + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
+  a.dist = dist; a.idx = idx;
+  if (N == 0) { a.tiles_per_chunk = 0; a.nchunks = 1; }
+  switch (p.kmax) {
+    case 1: return launch_knn<1>(a, s);
+    case 16: return launch_knn<16>(a, s);
+    case 32: return launch_knn<32>(a, s);
+  }
+  return fail(EFFOCR_EINVAL, "knn: internal");
+}
+
+int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s) {
+  if (B <= 0) return EFFOCR_OK;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, B, D, y);
+  return check_launch("l2_normalize");
+}
+
+int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s) {
+  if (n <= 0) return EFFOCR_OK;
+  const int64_t total = n * D;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, rows, n, D, dst);
+  return check_launch("gather_rows");
+}
+
+}  // namespace effocr

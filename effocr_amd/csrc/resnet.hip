@@ -1,0 +1,231 @@
+// resnet18 recognizer encoder (timm resnet18, num_classes=0 -> global-average-pooled 512-d feature;
+// models/encoders.py:58, called at infer_effocr.py:314) — BASELINE.json config 1.
+//
+// Convolutions run as implicit GEMM on the shared fp32 MFMA tile pipeline (tile128.hpp,
+// v_mfma_f32_32x32x2_f32): rows = output pixels (b,oy,ox), columns = output channels,
+// K = (ky,kx,ci) with ci fastest, activations NHWC so that one 128-byte K-stage of a row is 32
+// contiguous input channels of one tap -> the im2col gather is fused into the stage loader
+// (zero-filled taps outside the image).  BatchNorm is folded into the weights/bias on the host
+// (api.hip pack_resnet); bias, the residual add and ReLU are fused into the epilogue.
+// conv1 (3 input channels, 7x7) has no 32-channel runs: a small im2col kernel builds its rows
+// [B*OH*OW][160] straight from the NCHW input and the same kernel then runs as a 1x1 conv.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "tile128.hpp"
+
+namespace effocr {
+namespace {
+
+using namespace tile128;
+
+struct RowCoord { int b, iy0, ix0; };
+
+__device__ __forceinline__ void conv_stage_load(u32x4 (&r)[4], const ConvArgs& a, const RowCoord (&rc)[4], int ks, int tid) {
+  const int c = tid & 7;
+  const int kk = ks * 32;
+  const int tap = kk / a.Cin, ci0 = kk - tap * a.Cin;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int iy = rc[i].iy0 + ky, ix = rc[i].ix0 + kx;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+      const float* p = a.in + (((int64_t)rc[i].b * a.H + iy) * a.W + ix) * a.Cin + ci0 + c * 4;
+      v = *reinterpret_cast<const u32x4*>(p);
+    }
+    r[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = wave_id(), wn = w >> 1, wm = w & 1;
+  const int M = a.B * a.OH * a.OW;
+  const int K = a.KH * a.KW * a.Cin;
+  const int ntn = (a.Cout + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int nks = K / 32;
+
+  RowCoord rc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + (tid >> 3) + 32 * i;
+    m = m < M ? m : M - 1;
+    const int ox = m % a.OW, t = m / a.OW;
+    const int oy = t % a.OH;
+    rc[i].b = t / a.OH;
+    rc[i].iy0 = oy * a.stride - a.pad;
+    rc[i].ix0 = ox * a.stride - a.pad;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 rw[4], rx[4];
+  stage_load<float>(rw, a.w, K, n0, a.Cout, 0, tid);
+  conv_stage_load(rx, a, rc, 0, tid);
+  stage_store<float>(rw, smem, tid);
+  stage_store<float>(rx, smem + TILEB, tid);
+  __syncthreads();
+  for (int ks = 0; ks < nks; ++ks) {
+    char* cur = smem + (ks & 1) * STAGEB;
+    char* nxt = smem + ((ks & 1) ^ 1) * STAGEB;
+    const bool more = (ks + 1) < nks;
+    if (more) {
+      stage_load<float>(rw, a.w, K, n0, a.Cout, (ks + 1) * ROWB, tid);
+      conv_stage_load(rx, a, rc, ks + 1, tid);
+    }
+    stage_mma<float>(acc, cur, cur + TILEB, wn, wm, lane);
+    if (more) {
+      stage_store<float>(rw, nxt, tid);
+      stage_store<float>(rx, nxt + TILEB, tid);
+    }
+    __syncthreads();
+  }
+
+  const int half = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+        if (n >= a.Cout) continue;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+        f32x4 v = {acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1], acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]};
+        if (a.resid) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)m * a.Cout + n);
+          v += rv;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(a.out + (int64_t)m * a.Cout + n) = v;
+      }
+    }
+  }
+}
+
+// conv1 im2col: col[(b,oy,ox)][(ky*7+kx)*3 + c] = x[b][c][2oy-3+ky][2ox-3+kx] (0 outside), cols 147..159 = 0
+__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ x, float* __restrict__ col,
+                                                           int B, int H, int W, int OH, int OW) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * OH * OW * 160;
+  if (id >= total) return;
+  const int k = (int)(id % 160);
+  const int64_t m = id / 160;
+  float v = 0.f;
+  if (k < 147) {
+    const int c = k % 3, tap = k / 3, kx = tap % 7, ky = tap / 7;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH);
+    const int64_t b = m / ((int64_t)OW * OH);
+    const int iy = oy * 2 - 3 + ky, ix = ox * 2 - 3 + kx;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * 3 + c) * H + iy) * (int64_t)W + ix];
+  }
+  col[id] = v;
+}
+
+// max_pool2d(kernel 3, stride 2, padding 1) on NHWC (padding never wins: -inf)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                      int B, int H, int W, int C, int OH, int OW) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)B * OH * OW * C4;
+  if (id >= total) return;
+  const int c4 = (int)(id % C4);
+  const int64_t p = id / C4;
+  const int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
+  const int64_t b = p / ((int64_t)OW * OH);
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((b * H + iy) * W + ix) * C + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+  *reinterpret_cast<f32x4*>(out + p * C + c4 * 4) = m;
+}
+
+// global average pool over HW (+ optional L2 normalisation): one workgroup per image, C = 512
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                      int HW, int C, int l2norm) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float v[2];
+  float ss = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int c = tid + 256 * t;
+    float s = 0.f;
+    if (c < C) {
+      for (int p = 0; p < HW; ++p) s += in[((int64_t)b * HW + p) * C + c];
+      s = s / (float)HW;
+    }
+    v[t] = s;
+    ss += s * s;
+  }
+  if (l2norm) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    v[0] = v[0] / nrm; v[1] = v[1] / nrm;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int c = tid + 256 * t;
+    if (c < C) out[(int64_t)b * C + c] = v[t];
+  }
+}
+
+}  // namespace
+
+int conv2d_nhwc(const ConvArgs& a, hipStream_t s) {
+  const int64_t M = (int64_t)a.B * a.OH * a.OW;
+  if (M <= 0) return EFFOCR_OK;
+  if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
+  if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
+  const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+  return check_launch("conv2d_nhwc");
+}
+
+int im2col_conv1(const float* x, float* col, int B, int H, int W, int OH, int OW, hipStream_t s) {
+  const int64_t total = (int64_t)B * OH * OW * 160;
+  if (total <= 0) return EFFOCR_OK;
+  hipLaunchKernelGGL(im2col_conv1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, col, B, H, W, OH, OW);
+  return check_launch("im2col_conv1");
+}
+
+int maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t s) {
+  const int64_t total = (int64_t)B * OH * OW * (C / 4);
+  if (total <= 0) return EFFOCR_OK;
+  hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, H, W, C, OH, OW);
+  return check_launch("maxpool");
+}
+
+int global_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, int l2norm, hipStream_t s) {
+  if (B <= 0) return EFFOCR_OK;
+  if (C > 512) return fail(EFFOCR_EUNSUPPORTED, "avgpool: more than 512 channels");
+  hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)B), dim3(256), 0, s, in, out, HW, C, l2norm);
+  return check_launch("avgpool");
+}
+
+}  // namespace effocr

@@ -1,0 +1,431 @@
+// Non-GEMM kernels of the ViT recognizer encoder (timm VisionTransformer, called through
+// models/encoders.py:58-64 at infer_effocr.py:314): LayerNorm, patch im2col, CLS row set-up,
+// multi-head self-attention, and the final LayerNorm + CLS pooling (+ the F.normalize of
+// infer_effocr.py:316 fused in).
+#include "common.hpp"
+#include "kernels.hpp"
+#include <math.h>
+
+namespace effocr {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over rows of D fp32 values.  A row is owned by G lanes, V float4 per lane
+// (D = 4*G*V), so a wave64 handles 64/G rows with 16-byte coalesced loads; statistics in fp32,
+// two-pass (mean, then centred variance) like torch's CPU kernel.
+// ------------------------------------------------------------------------------------------
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int G, int V>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, int sub, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float eps, f32x4 (&y)[V]) {
+  constexpr int D = 4 * G * V;
+  f32x4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + (sub + G * i) * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = group_sum<G>(s) * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+  }
+  const float var = group_sum<G>(ss) * (1.0f / D);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + (sub + G * i) * 4);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + (sub + G * i) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[i][e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+  }
+}
+
+template <int G, int V, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        TO* __restrict__ out) {
+  constexpr int D = 4 * G * V;
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63, sub = lane % G;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+  const int64_t rc = row < rows ? row : rows - 1;
+  f32x4 y[V];
+  ln_row<G, V>(x + rc * D, sub, gamma, beta, eps, y);
+  if (row < rows) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      TO* p = out + row * D + (sub + G * i) * 4;
+      if constexpr (sizeof(TO) == 4) *reinterpret_cast<f32x4*>(p) = y[i];
+      else *reinterpret_cast<u32x2*>(p) = pack4<TO>(y[i][0], y[i][1], y[i][2], y[i][3]);
+    }
+  }
+}
+
+// final LayerNorm on the CLS row of every image (+ optional L2 normalisation) -> emb [B,D] fp32
+template <int G, int V>
+__global__ __launch_bounds__(256) void cls_norm_kernel(const float* __restrict__ x, int B, int T,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int l2norm,
+                                                       float* __restrict__ emb) {
+  constexpr int D = 4 * G * V;
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63, sub = lane % G;
+  const int img = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+  const int ic = img < B ? img : B - 1;
+  f32x4 y[V];
+  ln_row<G, V>(x + (int64_t)ic * T * D, sub, gamma, beta, eps, y);
+  if (l2norm) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss += y[i][e] * y[i][e];
+    const float nrm = fmaxf(sqrtf(group_sum<G>(ss)), 1e-12f);    // F.normalize: x / max(||x||, eps)
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[i][e] = y[i][e] / nrm;
+  }
+  if (img < B) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) *reinterpret_cast<f32x4*>(emb + (int64_t)img * D + (sub + G * i) * 4) = y[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// im2col for the 16x16/stride-16 patch-embedding conv: x [B,3,H,W] fp32 NCHW ->
+// rows [(img,py,px)][k = c*256 + ky*16 + kx] in the GEMM operand type (k order = the conv weight's
+// own [D,3,16,16] flattening, so the weight needs no permutation).
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__ x, int B, int H, int W,
+                                                       TO* __restrict__ out) {
+  const int PH = H / 16, PW = W / 16;
+  const int64_t total = (int64_t)B * PH * PW * 96;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int k8 = (int)(id % 96);
+  const int64_t m = id / 96;
+  const int px = (int)(m % PW), py = (int)((m / PW) % PH);
+  const int64_t img = m / ((int64_t)PW * PH);
+  const int c = k8 >> 5, ky = (k8 & 31) >> 1, kx0 = (k8 & 1) * 8;
+  const float* src = x + ((img * 3 + c) * H + (py * 16 + ky)) * (int64_t)W + px * 16 + kx0;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+  TO* dst = out + m * 768 + k8 * 8;
+  if constexpr (sizeof(TO) == 4) {
+    *reinterpret_cast<f32x4*>(dst) = a;
+    *reinterpret_cast<f32x4*>(dst + 4) = b;
+  } else {
+    const u32x2 lo = pack4<TO>(a[0], a[1], a[2], a[3]);
+    const u32x2 hi = pack4<TO>(b[0], b[1], b[2], b[3]);
+    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    *reinterpret_cast<u32x4*>(dst) = v;
+  }
+}
+
+// token 0 of every image = cls_token + pos_embed[0] (pre-added on the host at weight upload)
+__global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)B * D) return;
+  const int d = (int)(id % D);
+  const int64_t img = id / D;
+  x[img * T * D + d] = cls_pos0[d];
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-head self-attention, head_dim 64, whole sequence (T <= 32*NKT keys) in one workgroup.
+//   qkv [B*T, 3*D] (q | k | v, feature = which*D + h*64 + d, timm's reshape(B,N,3,H,hd)),
+//   out [B*T, D]   (feature = h*64 + d)  ==  (softmax(q k^T / 8) v).transpose(1,2).reshape(B,N,D)
+// One workgroup (4 waves) per (image, head).  K (row-major, 144-B padded rows) and V^T
+// (keys contiguous, packed key pairs) are staged once in LDS; each wave then owns 32-query
+// blocks.  Scores are computed SWAPPED, S^T = K Q^T with v_mfma_f32_32x32x16, so that a lane
+// holds one query column and all of its keys in registers: the softmax max / sum are lane-local
+// plus ONE cross-half exchange, no online rescaling (the whole row is resident, <= 112
+// accumulator registers).  The un-normalised P fragment that falls out of the S^T C-layout is
+// already a valid B-operand for O^T = V^T P^T provided V^T is read with the matching key
+// permutation (keys {0-3,8-11 | 4-7,12-15} + 16m per half-wave), so no permute instructions.
+// ------------------------------------------------------------------------------------------
+template <typename E, int NKT>
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__ qkv, E* __restrict__ out,
+                                                           int B, int T, int heads) {
+  typedef typename Op16<E>::V8 V8;
+  constexpr int TP = 32 * NKT;
+  constexpr int KROW = 144;                 // bytes per K row: 64 elements + 16 B pad
+  constexpr int VS = TP / 2 + 6;            // dwords per V^T row (even, VS/2 odd -> conflict-free b64 reads)
+  __shared__ __attribute__((aligned(16))) char smem[TP * KROW + 64 * VS * 4];
+  char* sK = smem;
+  uint32_t* sV = reinterpret_cast<uint32_t*>(smem + TP * KROW);
+
+  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  const int w = wave_id();
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const E* base = qkv + (int64_t)b * T * ld + h * 64;
+
+  // ---- stage K rows (zero rows beyond T)
+  for (int id = tid; id < TP * 8; id += 256) {
+    const int t = id >> 3, c = id & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t < T) v = *reinterpret_cast<const u32x4*>(base + (int64_t)t * ld + D + c * 8);
+    *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = v;
+  }
+  // ---- stage V transposed: dword (d, tp) = {V[2tp][d], V[2tp+1][d]}
+  for (int id = tid; id < (TP / 2) * 8; id += 256) {
+    const int tp = id >> 3, c = id & 7;
+    const int t0 = 2 * tp;
+    u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+    if (t0 < T) v0 = *reinterpret_cast<const u32x4*>(base + (int64_t)t0 * ld + 2 * D + c * 8);
+    if (t0 + 1 < T) v1 = *reinterpret_cast<const u32x4*>(base + (int64_t)(t0 + 1) * ld + 2 * D + c * 8);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const uint32_t a = v0[jj], bq = v1[jj];
+      sV[(c * 8 + 2 * jj) * VS + tp] = (a & 0xffffu) | (bq << 16);
+      sV[(c * 8 + 2 * jj + 1) * VS + tp] = (a >> 16) | (bq & 0xffff0000u);
+    }
+  }
+  __syncthreads();
+
+  const float cexp = 0.125f * 1.44269504088896340736f;     // head_dim^-0.5 * log2(e)
+  for (int qb = w; qb * 32 < T; qb += 4) {
+    int tq = qb * 32 + r31;
+    const bool qvalid = tq < T;
+    tq = qvalid ? tq : T - 1;
+    V8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = *reinterpret_cast<const V8*>(base + (int64_t)tq * ld + ks * 16 + half * 8);
+
+    // S^T tiles: rows = keys, cols = queries
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *reinterpret_cast<const V8*>(sK + (kt * 32 + r31) * KROW + (2 * ks + half) * 16);
+        s[kt] = Op16<E>::mfma(kf, qf[ks], s[kt]);
+      }
+    }
+    // mask the padded keys of the last tile, row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt == NKT - 1) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= T) s[kt][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // P = exp2((S - max) * c) tile by tile, fed straight into O^T = V^T P^T (rows = head dims,
+    // cols = queries) so that each score tile's registers die as soon as it is consumed
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float l = 0.f;
+    const float mxc = mx * cexp;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        V8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * m + j], cexp, -mxc));
+          l += p;
+          pf[j] = (E)p;
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const uint32_t* vp = sV + (db * 32 + r31) * VS + (kt * 16 + 8 * m + 2 * half);
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 4);
+          const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+          o[db] = Op16<E>::mfma(__builtin_bit_cast(V8, vv), pf, o[db]);
+        }
+      }
+      // keep the scheduler from hoisting every tile's exp / V^T reads to the top (424 live registers)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qvalid) {
+      const float inv = 1.0f / l;
+      E* orow = out + ((int64_t)b * T + tq) * D + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int d = db * 32 + 8 * q4 + 4 * half;
+          *reinterpret_cast<u32x2*>(orow + d) =
+              pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+        }
+    }
+  }
+}
+
+// fp32 parity mode: straightforward one-thread-per-query attention with K, V in LDS (broadcast
+// reads), online softmax in fp32.  Correctness reference path, not a throughput kernel.
+constexpr int ATT32_TMAX = 224;
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       int B, int T, int heads) {
+  __shared__ __attribute__((aligned(16))) float sK[ATT32_TMAX * 64];
+  __shared__ __attribute__((aligned(16))) float sV[ATT32_TMAX * 64];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const float* base = qkv + (int64_t)b * T * ld + h * 64;
+  for (int id = tid; id < T * 16; id += 256) {
+    const int t = id >> 4, c = id & 15;
+    *reinterpret_cast<f32x4*>(sK + t * 64 + c * 4) = *reinterpret_cast<const f32x4*>(base + (int64_t)t * ld + D + c * 4);
+    *reinterpret_cast<f32x4*>(sV + t * 64 + c * 4) = *reinterpret_cast<const f32x4*>(base + (int64_t)t * ld + 2 * D + c * 4);
+  }
+  __syncthreads();
+  for (int tq = tid; tq < T; tq += 256) {
+    float q[64], o[64];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)tq * ld + c * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { q[c * 4 + e] = v[e] * 0.125f; o[c * 4 + e] = 0.f; }
+    }
+    float mx = -INFINITY, l = 0.f;
+    for (int key = 0; key < T; ++key) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) sc = fmaf(q[d], sK[key * 64 + d], sc);
+      const float mn = fmaxf(mx, sc);
+      const float alpha = expf(mx - mn);
+      const float p = expf(sc - mn);
+      l = l * alpha + p;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) o[d] = fmaf(p, sV[key * 64 + d], o[d] * alpha);
+      mx = mn;
+    }
+    const float inv = 1.0f / l;
+    float* orow = out + ((int64_t)b * T + tq) * D + h * 64;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      f32x4 v = {o[c * 4] * inv, o[c * 4 + 1] * inv, o[c * 4 + 2] * inv, o[c * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(orow + c * 4) = v;
+    }
+  }
+}
+
+template <typename TO>
+int launch_ln(const float* x, int64_t rows, int D, const float* gamma, const float* beta, float eps, TO* out,
+              hipStream_t s) {
+  if (rows <= 0) return EFFOCR_OK;
+  if (D == 384) {
+    const int64_t rpb = 4 * 2;
+    hipLaunchKernelGGL((layernorm_kernel<32, 3, TO>), dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  } else if (D == 768) {
+    const int64_t rpb = 4;
+    hipLaunchKernelGGL((layernorm_kernel<64, 3, TO>), dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  } else if (D == 128) {
+    const int64_t rpb = 4 * 2;
+    hipLaunchKernelGGL((layernorm_kernel<32, 1, TO>), dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  } else {
+    return fail(EFFOCR_EUNSUPPORTED, "layernorm: embed dim must be 128, 384 or 768");
+  }
+  return check_launch("layernorm");
+}
+
+template <typename TO>
+int launch_im2col(const float* x, int B, int H, int W, TO* out, hipStream_t s) {
+  const int64_t total = (int64_t)B * (H / 16) * (W / 16) * 96;
+  if (total <= 0) return EFFOCR_OK;
+  hipLaunchKernelGGL((im2col16_kernel<TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, B, H, W, out);
+  return check_launch("im2col16");
+}
+
+template <typename E>
+int launch_attn_mfma(const E* qkv, E* out, int B, int T, int heads, hipStream_t s) {
+  const int nkt = (T + 31) / 32;
+  const dim3 grid((unsigned)(B * heads)), blk(256);
+  switch (nkt) {
+    case 1: hipLaunchKernelGGL((attn_mfma_kernel<E, 1>), grid, blk, 0, s, qkv, out, B, T, heads); break;
+    case 2: hipLaunchKernelGGL((attn_mfma_kernel<E, 2>), grid, blk, 0, s, qkv, out, B, T, heads); break;
+    case 7: hipLaunchKernelGGL((attn_mfma_kernel<E, 7>), grid, blk, 0, s, qkv, out, B, T, heads); break;
+    default: return fail(EFFOCR_EUNSUPPORTED, "attention: token count must be <=64 or in (192,224]");
+  }
+  return check_launch("attention");
+}
+
+}  // namespace
+
+int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
+                   float eps, void* out, hipStream_t s) {
+  switch (prec_out) {
+    case PREC_BF16: return launch_ln<__bf16>(x, rows, D, gamma, beta, eps, static_cast<__bf16*>(out), s);
+    case PREC_FP16: return launch_ln<_Float16>(x, rows, D, gamma, beta, eps, static_cast<_Float16*>(out), s);
+    case PREC_FP32: return launch_ln<float>(x, rows, D, gamma, beta, eps, static_cast<float*>(out), s);
+  }
+  return fail(EFFOCR_EINVAL, "layernorm: unknown precision");
+}
+
+int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s) {
+  if (H % 16 || W % 16) return fail(EFFOCR_EINVAL, "im2col: image size must be a multiple of 16");
+  switch (prec_out) {
+    case PREC_BF16: return launch_im2col<__bf16>(x, B, H, W, static_cast<__bf16*>(out), s);
+    case PREC_FP16: return launch_im2col<_Float16>(x, B, H, W, static_cast<_Float16*>(out), s);
+    case PREC_FP32: return launch_im2col<float>(x, B, H, W, static_cast<float*>(out), s);
+  }
+  return fail(EFFOCR_EINVAL, "im2col: unknown precision");
+}
+
+int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, hipStream_t s) {
+  const int64_t total = (int64_t)B * D;
+  if (total <= 0) return EFFOCR_OK;
+  hipLaunchKernelGGL(set_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls_pos0, x, B, T, D);
+  return check_launch("set_cls_rows");
+}
+
+int attention(int prec, const void* qkv, void* out, int B, int T, int heads, hipStream_t s) {
+  if (B <= 0) return EFFOCR_OK;
+  switch (prec) {
+    case PREC_BF16: return launch_attn_mfma<__bf16>(static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), B, T, heads, s);
+    case PREC_FP16: return launch_attn_mfma<_Float16>(static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), B, T, heads, s);
+    case PREC_FP32:
+      if (T > ATT32_TMAX) return fail(EFFOCR_EUNSUPPORTED, "attention(fp32): more than 224 tokens");
+      hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, s,
+                         static_cast<const float*>(qkv), static_cast<float*>(out), B, T, heads);
+      return check_launch("attention_f32");
+  }
+  return fail(EFFOCR_EINVAL, "attention: unknown precision");
+}
+
+int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, const float* beta, float eps,
+                   int l2norm, float* emb, hipStream_t s) {
+  if (B <= 0) return EFFOCR_OK;
+  if (D == 384) {
+    hipLaunchKernelGGL((cls_norm_kernel<32, 3>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, emb);
+  } else if (D == 768) {
+    hipLaunchKernelGGL((cls_norm_kernel<64, 3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, emb);
+  } else if (D == 128) {
+    hipLaunchKernelGGL((cls_norm_kernel<32, 1>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, emb);
+  } else {
+    return fail(EFFOCR_EUNSUPPORTED, "final norm: embed dim must be 128, 384 or 768");
+  }
+  return check_launch("final_cls_norm");
+}
+
+}  // namespace effocr

@@ -1,0 +1,165 @@
+"""Recognizer encoder engine on MI355X, behind the reference's two call conventions.
+
+* ``AutoEncoderFactory(backend, modelpath)`` mirrors models/encoders.py:50-97: it returns a class
+  whose instances behave like the reference's ``AutoEncoder`` ``nn.Module`` at its call sites —
+  ``encoder.load(ckpt)`` (infer_effocr.py:177), ``.to(device)`` / ``.eval()`` (:178-179),
+  ``encoder(x[B,3,H,W]) -> [B,D]`` (:314), ``.named_parameters()`` (:538-540).
+* ``EffRecognizer`` (effocr_amd/recognizer_engine.py) keeps onnx_engines/recognizer_engine.py:6-27.
+
+Both sit on ``HipEncoder``, a thin owner of the C-ABI encoder handle (include/effocr_hip.h):
+weights are packed by the library and live in a device blob allocated by torch; the forward pass is
+a fixed sequence of hand-written gfx950 kernels launched on torch's current HIP stream.
+"""
+import ctypes
+import threading
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+
+class HipEncoder:
+    """Device-resident encoder: C-ABI handle + weight blob + grow-only workspace."""
+
+    def __init__(self, arch, state_dict, img_size=224, precision="bf16", device="cuda:0"):
+        if precision not in _lib.PREC:
+            raise ValueError(f"precision must be one of {sorted(_lib.PREC)}, got {precision!r}")
+        self.device = _lib.require_gpu(device)
+        self.arch, self.img_size, self.precision = arch, int(img_size), precision
+        self._L = _lib.lib()
+        self._lock = threading.Lock()
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.effocr_encoder_create(arch.encode(), self.img_size, _lib.PREC[precision],
+                                                 ctypes.byref(self._h)), "effocr_encoder_create")
+        self.embed_dim = int(self._L.effocr_encoder_embed_dim(self._h))
+        sd = W.strip_prefix(state_dict)
+        W.check_state_dict(arch, sd, self.img_size)
+        for i in range(self._L.effocr_encoder_num_params(self._h)):
+            name = self._L.effocr_encoder_param_name(self._h, i).decode()
+            t = sd[name].detach().to("cpu", torch.float32).contiguous()
+            _lib.check(self._L.effocr_encoder_set_param(self._h, name.encode(), _lib.ptr(t), t.numel()),
+                       f"effocr_encoder_set_param({name})")
+        nbytes = int(self._L.effocr_encoder_weights_bytes(self._h))
+        with torch.cuda.device(self.device):
+            self._wblob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self._L.effocr_encoder_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_encoder_upload")
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._L.effocr_encoder_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def workspace_bytes(self, batch):
+        return int(self._L.effocr_encoder_workspace_bytes(self._h, int(batch)))
+
+    def forward(self, x, normalize=False):
+        """x: [B,3,H,W] float32 CUDA tensor -> [B,D] float32 CUDA tensor (async on the current stream)."""
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("HipEncoder.forward expects a torch.Tensor")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
+            raise ValueError(f"expected input [B,3,{self.img_size},{self.img_size}], got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise ValueError(f"expected float32 input, got {x.dtype}")
+        if x.device != self.device:
+            raise ValueError(f"input is on {x.device}, encoder on {self.device}")
+        x = x.contiguous()
+        B = x.shape[0]
+        emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return emb
+        need = self.workspace_bytes(B)
+        with self._lock, torch.cuda.device(self.device):
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(self._L.effocr_encoder_forward(self._h, _lib.ptr(x), B, _lib.ptr(emb), 1 if normalize else 0,
+                                                      _lib.ptr(self._ws), self._ws.numel(),
+                                                      _lib.current_stream(self.device)), "effocr_encoder_forward")
+        return emb
+
+    __call__ = forward
+
+
+def AutoEncoderFactory(backend, modelpath, precision="bf16", img_size=224):
+    """Drop-in for models/encoders.py:50 ``AutoEncoderFactory(backend, modelpath)``.
+
+    Only the ``"timm"`` backend with the architectures BASELINE.json names is implemented (the "hf"
+    branch and XcitDinoEncoder are out of scope); anything else raises
+    NotImplementedError exactly like the reference's ``else`` branch (encoders.py:93-95).
+    ``precision`` / ``img_size`` are extensions with reference-compatible defaults.
+    """
+    if backend != "timm":
+        raise NotImplementedError
+    W.embed_dim(modelpath)          # raises NotImplementedError for unknown architectures
+
+    class AutoEncoder:
+        arch = modelpath
+
+        def __init__(self, model=modelpath, device="cuda", seed=0):
+            # the reference downloads ImageNet weights here (pretrained=True, encoders.py:58); with
+            # no network the instance starts from a seeded random init until load_state_dict().
+            self.model_name = model
+            self._sd = W.init_state_dict(model, seed=seed, img_size=img_size)
+            self._device = torch.device("cuda:0" if str(device) == "cuda" else device)
+            self._engine = None
+            self.training = False
+
+        # -- checkpoint I/O (encoders.py:66-70) ------------------------------------------------
+        @classmethod
+        def load(cls, checkpoint):
+            ptnet = cls()
+            ptnet.load_state_dict(W.load_checkpoint(checkpoint))
+            return ptnet
+
+        def load_state_dict(self, sd, strict=True):
+            sd = W.strip_prefix(sd)
+            W.check_state_dict(self.model_name, sd, img_size)
+            self._sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in sd.items()}
+            self._engine = None
+
+        def state_dict(self):
+            return {"net." + k: v for k, v in self._sd.items()}
+
+        # -- nn.Module look-alikes used by infer_effocr.py:178-179,538-540 ---------------------
+        def to(self, device):
+            device = torch.device("cuda:0" if str(device) == "cuda" else device)
+            if device != self._device:
+                self._device, self._engine = device, None
+            return self
+
+        def eval(self):
+            self.training = False
+            return self
+
+        def named_parameters(self):
+            shapes = W.param_shapes(self.model_name, img_size)
+            for k, v in self._sd.items():
+                if k in shapes and not k.endswith(("running_mean", "running_var")):
+                    p = torch.nn.Parameter(v, requires_grad=True)
+                    yield "net." + k, p
+
+        def parameters(self):
+            for _, p in self.named_parameters():
+                yield p
+
+        @property
+        def engine(self):
+            if self._engine is None:
+                self._engine = HipEncoder(self.model_name, self._sd, img_size=img_size, precision=precision,
+                                          device=self._device)
+            return self._engine
+
+        def forward(self, x):
+            return self.engine.forward(x, normalize=False)
+
+        __call__ = forward
+
+    AutoEncoder.__name__ = "AutoEncoder"
+    return AutoEncoder

@@ -1,0 +1,272 @@
+"""k-NN engine: the ``faiss.IndexFlatIP`` + ``pytorch_metric_learning`` ``FaissKNN`` /
+``InferenceModel`` call conventions of the reference, backed by the gfx950 inner-product top-k
+kernel (effocr_amd/csrc/knn.hip) with the index resident in HBM.
+
+Reference call sites kept working unchanged:
+  infer_effocr.py:184-188   FaissKNN(index_init_fn=faiss.IndexFlatIP, reset_before=False, reset_after=False)
+                            InferenceModel(recognizer_encoder, knn_func=knn_func)
+  infer_effocr.py:201,207   recognizer.train_knn(render_dataset) / recognizer.load_knn_func(ref.index)
+  infer_effocr.py:211       recognizer.knn_func.index.remove_ids(blacklist_ids)
+  infer_effocr.py:317       _, indices = self.recognizer.knn_func(emb, k=self.knn)
+  infer_effocr_onnx_multi.py:496-500,509,372   knn_func.load(...); knn_func.index.remove_ids(...); knn_func(emb, k=1)
+  train_effocr_recognizer.py:27-29,35,49-52    load_knn_func / get_nearest_neighbors / train_knn / save_knn_func
+
+Semantics: scores = fp32 inner products, k best per query in descending order,
+int64 row ids; k > ntotal pads with id -1 / score -FLT_MAX; ``remove_ids`` deletes rows and
+compacts.  Defined here because faiss leaves them open: the dot product is the ascending-k fmaf
+chain and equal scores rank by ascending id.
+"""
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NEG_SCORE = -3.4028234663852886e+38
+
+
+class IndexFlatIP:
+    """HBM-resident exact inner-product index (faiss.IndexFlatIP role)."""
+
+    metric_type = 0          # faiss.METRIC_INNER_PRODUCT
+    is_trained = True
+
+    def __init__(self, d, device="cuda:0"):
+        self.d = int(d)
+        self.device = _lib.require_gpu(device)
+        self._L = _lib.lib()
+        self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+        self._ws = None
+
+    @property
+    def ntotal(self):
+        return int(self._xb.shape[0])
+
+    def _as_dev(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("expected a numpy array or torch tensor")
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise ValueError(f"expected shape [n,{self.d}], got {tuple(x.shape)}")
+        return x.to(self.device, torch.float32).contiguous()
+
+    def add(self, x):
+        x = self._as_dev(x)
+        self._xb = x.clone() if self.ntotal == 0 else torch.cat([self._xb, x], dim=0)
+
+    def reset(self):
+        self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+
+    def reconstruct_n(self, i0=0, n=None):
+        n = self.ntotal - i0 if n is None else n
+        return self._xb[i0:i0 + n].cpu().numpy()
+
+    def remove_ids(self, ids):
+        """Delete the given rows and compact (later rows shift down); returns the number removed."""
+        ids = np.unique(np.asarray(ids, dtype=np.int64).reshape(-1))
+        ids = ids[(ids >= 0) & (ids < self.ntotal)]
+        if ids.size == 0:
+            return 0
+        keep = np.ones(self.ntotal, dtype=bool)
+        keep[ids] = False
+        rows = torch.from_numpy(np.nonzero(keep)[0].astype(np.int64)).to(self.device)
+        dst = torch.empty((rows.numel(), self.d), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.effocr_gather_rows(_lib.ptr(self._xb), _lib.ptr(rows), rows.numel(), self.d,
+                                                  _lib.ptr(dst), _lib.current_stream(self.device)), "effocr_gather_rows")
+        self._xb = dst
+        return int(ids.size)
+
+    def search_device(self, q, k):
+        """q: [n,d] float32 CUDA tensor -> (D [n,k] float32, I [n,k] int64) CUDA tensors, async."""
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        q = self._as_dev(q)
+        n = q.shape[0]
+        D = torch.empty((n, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((n, k), dtype=torch.int64, device=self.device)
+        if n == 0:
+            return D, I
+        need = int(self._L.effocr_knn_workspace_bytes(n, self.ntotal, self.d, k))
+        with torch.cuda.device(self.device):
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            _lib.check(self._L.effocr_knn_ip_topk(_lib.ptr(q), n, _lib.ptr(self._xb), self.ntotal, self.d, k,
+                                                  _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(),
+                                                  _lib.current_stream(self.device)), "effocr_knn_ip_topk")
+        return D, I
+
+    def search(self, x, k):
+        """faiss signature: numpy in, numpy (D, I) out."""
+        D, I = self.search_device(x, k)
+        return D.cpu().numpy(), I.cpu().numpy()
+
+
+# --------------------------------------------------------------------------- ref.index file format
+# faiss ``write_index`` layout for IndexFlatIP, restated from faiss's index_write.cpp (faiss is not
+# installable here, so this is UNVERIFIED against a file written by faiss itself):
+#   fourcc "IxFI" u32 | d i32 | ntotal i64 | dummy i64 (1<<20) | dummy i64 (1<<20) | is_trained u8 |
+#   metric_type i32 (0 = inner product) | n_floats u64 | ntotal*d float32 row-major
+_FOURCC_IP = b"IxFI"
+
+
+def write_index(index, path):
+    xb = index._xb.cpu().numpy().astype("<f4", copy=False)
+    with open(path, "wb") as f:
+        f.write(_FOURCC_IP)
+        f.write(struct.pack("<iqqqBi", index.d, index.ntotal, 1 << 20, 1 << 20, 1, 0))
+        f.write(struct.pack("<Q", xb.size))
+        f.write(xb.tobytes(order="C"))
+
+
+def read_index(path, device="cuda:0"):
+    with open(path, "rb") as f:
+        buf = f.read()
+    if buf[:4] != _FOURCC_IP:
+        raise ValueError(f"{path}: not a faiss IndexFlatIP file (fourcc {buf[:4]!r}); only 'IxFI' is supported")
+    d, ntotal, _, _, _, metric = struct.unpack_from("<iqqqBi", buf, 4)
+    off = 4 + struct.calcsize("<iqqqBi")
+    (nfl,) = struct.unpack_from("<Q", buf, off)
+    off += 8
+    if metric != 0 or nfl != ntotal * d or len(buf) < off + 4 * nfl:
+        raise ValueError(f"{path}: inconsistent IndexFlatIP header (d={d}, ntotal={ntotal}, metric={metric}, n={nfl})")
+    idx = IndexFlatIP(d, device=device)
+    if ntotal:
+        idx.add(np.frombuffer(buf, dtype="<f4", count=nfl, offset=off).reshape(ntotal, d).copy())
+    return idx
+
+
+# --------------------------------------------------------------------------- PML look-alikes
+class FaissKNN:
+    """pytorch_metric_learning.utils.inference.FaissKNN call convention on the HIP index."""
+
+    def __init__(self, reset_before=True, reset_after=True, index_init_fn=None, gpus=None, device="cuda:0"):
+        self.reset_before = reset_before
+        self.reset_after = reset_after
+        # the reference passes faiss.IndexFlatIP; any callable taking d works, default = ours
+        self.index_init_fn = IndexFlatIP if index_init_fn is None else index_init_fn
+        self.gpus = gpus
+        self.device = device
+        self.index = None
+
+    def _new_index(self, d):
+        try:
+            return self.index_init_fn(d, device=self.device)
+        except TypeError:
+            return self.index_init_fn(d)
+
+    def __call__(self, query, k, reference=None, ref_includes_query=False):
+        if ref_includes_query:
+            k = k + 1
+        device = query.device if isinstance(query, torch.Tensor) else torch.device("cpu")
+        d = query.shape[1]
+        if self.reset_before:
+            self.index = self._new_index(d)
+        if self.index is None:
+            raise ValueError("self.index is None. It needs to be initialized before being used.")
+        if reference is not None:
+            self.index.add(reference)
+        if isinstance(query, torch.Tensor):
+            query = query.detach()
+        distances, indices = self.index.search_device(query, k)
+        distances, indices = distances.to(device), indices.to(device)
+        if self.reset_after:
+            self.reset()
+        if ref_includes_query:
+            distances, indices = distances[:, 1:], indices[:, 1:]
+        return distances, indices
+
+    def train(self, embeddings):
+        self.index = self._new_index(embeddings.shape[1])
+        self.add(embeddings)
+
+    def add(self, embeddings):
+        if isinstance(embeddings, torch.Tensor):
+            embeddings = embeddings.detach()
+        self.index.add(embeddings)
+
+    def save(self, filename):
+        write_index(self.index, filename)
+
+    def load(self, filename):
+        self.index = read_index(filename, device=self.device)
+
+    def reset(self):
+        if self.index is not None:
+            self.index.reset()
+
+
+class InferenceModel:
+    """pytorch_metric_learning.utils.inference.InferenceModel subset used by the reference
+    (infer_effocr.py:188,201,207,317; train_effocr_recognizer.py:27-35,49-52)."""
+
+    def __init__(self, trunk, embedder=None, match_finder=None, normalize_embeddings=True, knn_func=None,
+                 data_device=None, dtype=None):
+        self.trunk = trunk
+        self.embedder = embedder
+        self.match_finder = match_finder
+        self.normalize_embeddings = normalize_embeddings
+        self.knn_func = FaissKNN(reset_before=False, reset_after=False) if knn_func is None else knn_func
+        self.data_device = torch.device("cuda:0") if data_device is None else torch.device(data_device)
+        self.dtype = dtype
+
+    def get_embeddings(self, x):
+        if isinstance(x, torch.Tensor):
+            x = x.to(self.data_device, torch.float32)
+        if hasattr(self.trunk, "eval"):
+            self.trunk.eval()
+        with torch.no_grad():
+            eng = getattr(self.trunk, "engine", None)
+            if eng is not None and self.embedder is None:
+                return eng.forward(x, normalize=bool(self.normalize_embeddings))   # fused F.normalize
+            emb = self.trunk(x)
+            if self.embedder is not None:
+                emb = self.embedder(emb)
+        if self.normalize_embeddings:
+            emb = l2_normalize(emb)
+        return emb
+
+    def _embed_all(self, inputs, batch_size):
+        if isinstance(inputs, (list, tuple)):
+            inputs = torch.stack(list(inputs))
+        if isinstance(inputs, torch.Tensor):
+            chunks = [self.get_embeddings(inputs[i:i + batch_size]) for i in range(0, len(inputs), batch_size)]
+        else:   # a torch Dataset yielding (image, label) like FontImageFolder
+            chunks, batch = [], []
+            for i in range(len(inputs)):
+                item = inputs[i]
+                batch.append(item[0] if isinstance(item, (tuple, list)) else item)
+                if len(batch) == batch_size or i == len(inputs) - 1:
+                    chunks.append(self.get_embeddings(torch.stack(batch)))
+                    batch = []
+        return torch.cat(chunks, dim=0)
+
+    def train_knn(self, inputs, batch_size=64):
+        self.knn_func.train(self._embed_all(inputs, batch_size))
+
+    def add_to_knn(self, inputs, batch_size=64):
+        self.knn_func.add(self._embed_all(inputs, batch_size))
+
+    def get_nearest_neighbors(self, query, k):
+        return self.knn_func(self.get_embeddings(query), k)
+
+    def save_knn_func(self, filename):
+        self.knn_func.save(filename)
+
+    def load_knn_func(self, filename):
+        self.knn_func.load(filename)
+
+
+def l2_normalize(x):
+    """torch.nn.functional.normalize(x, p=2, dim=1) on device (infer_effocr.py:316)."""
+    dev = _lib.require_gpu(x.device)
+    x = x.to(torch.float32).contiguous()
+    y = torch.empty_like(x)
+    if x.shape[0]:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().effocr_l2_normalize(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(y),
+                                                      _lib.current_stream(dev)), "effocr_l2_normalize")
+    return y

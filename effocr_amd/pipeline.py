@@ -1,0 +1,110 @@
+"""Host-side glue of the recognizer hot path: batching, id -> character mapping and the
+encode -> normalise -> k-NN -> characters sequence, with the reference's exact conventions.
+
+Restated reference logic (file:line into the reference tree):
+  create_batches / iteration      infer_effocr_onnx_multi.py:143-163
+  candidate chars / blacklist     infer_effocr.py:203-205,209-212 ; infer_effocr_onnx_multi.py:502-510
+  kNN branch of EffOCR.infer      infer_effocr.py:310-319,337-338
+  ONNX-driver recognizer phase    infer_effocr_onnx_multi.py:350-375
+"""
+import numpy as np
+import torch
+
+from .knn import FaissKNN, InferenceModel
+
+
+def create_batches(data, batch_size=64):
+    """infer_effocr_onnx_multi.py:143-158.  ``None`` crops become zero images; full chunks of
+    ``batch_size``; the last chunk is zero-padded to the literal 64 of the reference (:157) —
+    so, like there, ``batch_size`` is effectively fixed at 64."""
+    batches, batch = [], []
+    for i, d in enumerate(data):
+        batch.append(d if d is not None else torch.zeros((3, 224, 224)))
+        if (i + 1) % batch_size == 0:
+            batches.append(torch.stack(batch))
+            batch = []
+    if len(batch) > 0:
+        batches.append(torch.nn.functional.pad(torch.stack(batch), (0, 0, 0, 0, 0, 0, 0, 64 - len(batch))))
+    return [b.detach().numpy() for b in batches]
+
+
+def iteration(model, input):
+    """infer_effocr_onnx_multi.py:161-163: returns ``(output, output)``; consumers read [0][0]."""
+    output = model.run(input)
+    return output, output
+
+
+def read_candidate_chars(path):
+    """``ref.txt`` -> list of glyph strings (whitespace split, infer_effocr.py:203-205)."""
+    with open(path) as f:
+        return f.read().split()
+
+
+def write_candidate_chars(chars, path):
+    """train_effocr_recognizer.py:61-62: one glyph per line."""
+    with open(path, "w") as f:
+        f.write("\n".join(chars))
+
+
+def apply_blacklist(knn_func, candidate_chars, blacklist):
+    """infer_effocr.py:209-212: iterate the CHARACTERS of ``blacklist``, drop their rows from the
+    index (compaction) and filter the char list in the same order.  Raises KeyError for a
+    blacklisted char that is not in the list, like the reference's dict lookup."""
+    if blacklist is None:
+        return candidate_chars
+    candidate_chars_dict = {c: idx for idx, c in enumerate(candidate_chars)}
+    blacklist_ids = np.array([candidate_chars_dict[blc] for blc in blacklist], dtype=np.int64)
+    knn_func.index.remove_ids(blacklist_ids)
+    return [c for c in candidate_chars if c not in blacklist]
+
+
+def indices_to_chars(indices, candidate_chars):
+    """infer_effocr.py:318-319,337-338 for an index tensor [B,k] (k >= 2 in the reference):
+    -> (nearest_chars list[B] of list[k], output_nns list[B] of str, output str)."""
+    if indices.dim() == 2 and indices.shape[1] == 1:
+        # the reference's ``squeeze(-1)`` turns k=1 into a 1-D list and then fails (SURVEY a-1); here
+        # k=1 simply yields one neighbour per crop
+        index_list = [[i] for i in indices[:, 0].cpu().tolist()]
+    else:
+        index_list = indices.squeeze(-1).cpu().tolist()
+    nearest_chars = [[candidate_chars[nn] for nn in nns] for nns in index_list]
+    output_nns = ["".join(chars).strip() for chars in nearest_chars]
+    output = "".join(x[0] for x in nearest_chars).strip()
+    return nearest_chars, output_nns, output
+
+
+class Recognizer:
+    """The kNN branch of ``EffOCR.infer`` (infer_effocr.py:310-319) as one object:
+    crops -> encoder -> L2 normalise (fused) -> IP top-k -> characters, everything on one GPU."""
+
+    def __init__(self, encoder, knn_func, candidate_chars, knn=10):
+        self.recongizer_encoder = encoder          # sic — attribute name of infer_effocr.py:224
+        self.recognizer = InferenceModel(encoder, knn_func=knn_func)
+        self.candidate_chars = candidate_chars
+        self.knn = knn
+
+    def neighbors(self, crops):
+        """crops: [B,3,H,W] float32 tensor (or list of [3,H,W]) -> (distances, indices) on device."""
+        if isinstance(crops, (list, tuple)):
+            crops = torch.stack(list(crops))
+        emb = self.recognizer.get_embeddings(crops)                 # encode + F.normalize
+        return self.recognizer.knn_func(emb, k=self.knn)
+
+    def __call__(self, crops):
+        _, indices = self.neighbors(crops)
+        return indices_to_chars(indices, self.candidate_chars)
+
+
+def run_recognizer_batches(char_crops, recognizer_engine, knn_func, candidate_chars, normalize=None):
+    """Recognizer phase of ``run_effocr`` (infer_effocr_onnx_multi.py:347-375) without the thread
+    pool: batches of 64 -> engine -> normalise -> knn(k=1) -> flat list of characters (the padded
+    tail included, exactly like the reference, whose consumers never read it)."""
+    from .knn import l2_normalize
+    batches = create_batches(char_crops)
+    embeddings = [iteration(recognizer_engine, b) for b in batches]
+    dev = knn_func.index.device
+    embs = [l2_normalize(torch.from_numpy(e[0][0]).to(dev)) for e in embeddings]
+    indices = [knn_func(e, k=1)[1] for e in embs]
+    index_list = [ix.squeeze(-1).tolist() for ix in indices]
+    flat = [item for sub in index_list for item in sub]
+    return [candidate_chars[i] for i in flat], flat

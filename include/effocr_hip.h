@@ -1,0 +1,120 @@
+/* effocr_hip.h — C ABI of libeffocr_hip.so: the MI355X (gfx950) implementation of EffOCR's
+ * recognizer hot path (encoder forward -> L2 normalise -> exact inner-product top-k).
+ *
+ * The reference (dell-research-harvard/effocr) is pure Python and has no FFI of its own; its
+ * "operator API" for this path is three Python call conventions.  Each entry point below names the
+ * reference interface it sits underneath (file:line into the reference tree); the Python classes
+ * that keep those conventions bit-for-bit live in effocr_amd/ and call ONLY this header's
+ * functions through ctypes.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - plain C types only; every *_dev pointer is caller-owned DEVICE memory (hipMalloc / torch
+ *     allocator).  The library allocates no device memory, ever; host memory only inside the
+ *     encoder handle (parameter staging).
+ *   - every call that takes a `stream` is asynchronous on that hipStream_t (passed as void*; NULL =
+ *     the default stream) and performs no device synchronisation.
+ *   - return value: 0 on success, a negative EFFOCR_E* code on failure; the message is available
+ *     from effocr_last_error() (thread-local).
+ */
+#ifndef EFFOCR_HIP_H
+#define EFFOCR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFFOCR_ABI_VERSION 1
+
+enum effocr_status {
+  EFFOCR_OK = 0,
+  EFFOCR_EINVAL = -1,        /* bad argument (shape, NULL pointer, unknown name)            */
+  EFFOCR_EUNSUPPORTED = -2,  /* valid request outside what the kernels implement            */
+  EFFOCR_EWORKSPACE = -3,    /* caller-provided workspace / blob too small                  */
+  EFFOCR_EHIP = -4,          /* HIP runtime error (launch failure, memcpy failure)          */
+  EFFOCR_ESTATE = -5         /* call order violated (e.g. forward before upload)            */
+};
+
+/* arithmetic type of the encoder's MFMA operands (accumulation, LayerNorm, softmax, the residual
+ * stream and the embedding are always fp32) */
+enum effocr_precision {
+  EFFOCR_PREC_BF16 = 0,      /* v_mfma_f32_32x32x16_bf16 — the BASELINE.json configuration   */
+  EFFOCR_PREC_FP16 = 1,      /* v_mfma_f32_32x32x16_f16                                      */
+  EFFOCR_PREC_FP32 = 2       /* v_mfma_f32_32x32x2_f32, exact fp32 — the parity mode         */
+};
+
+int effocr_abi_version(void);
+const char* effocr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder engine.  Replaces: onnx_engines/recognizer_engine.py:6-27 (EffRecognizer: ORT session
+ * over enc_best.onnx, run(imgs[B,3,H,W] f32) -> [embs[B,D] f32]) and the torch twin
+ * models/encoders.py:50-70 (AutoEncoderFactory("timm", name) -> timm.create_model(name,
+ * num_classes=0); forward(x) = pooled features; load(ckpt) = state dict with "net." keys),
+ * called at infer_effocr.py:177-179,314 and infer_effocr_onnx_multi.py:161-163,491-494.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct effocr_encoder effocr_encoder_t;
+
+/* arch: "resnet18" | "vit_small_patch16_224" | "vit_base_patch16_224" ("vit_tiny_test" for tests).
+ * img_size: input H = W (224 for the ViTs' pos_embed; any multiple of 32 for resnet18). */
+int effocr_encoder_create(const char* arch, int img_size, int precision, effocr_encoder_t** out);
+void effocr_encoder_destroy(effocr_encoder_t* enc);
+int effocr_encoder_embed_dim(const effocr_encoder_t* enc);
+
+/* Parameter table = the timm state-dict keys WITHOUT the "net." prefix (models/encoders.py:60). */
+int effocr_encoder_num_params(const effocr_encoder_t* enc);
+const char* effocr_encoder_param_name(const effocr_encoder_t* enc, int i);
+int64_t effocr_encoder_param_numel(const effocr_encoder_t* enc, int i);
+/* copy one fp32 HOST tensor (C-contiguous, torch layout) into the handle's staging area */
+int effocr_encoder_set_param(effocr_encoder_t* enc, const char* name, const float* host, int64_t numel);
+
+/* Packed device image of the weights: LayerNorm/bias/pos_embed in fp32, GEMM operands in the
+ * handle's precision, BatchNorm folded into the conv weights (resnet18). */
+size_t effocr_encoder_weights_bytes(const effocr_encoder_t* enc);
+/* pack all staged parameters and copy them into weights_dev (synchronous; not on the hot path) */
+int effocr_encoder_upload(effocr_encoder_t* enc, void* weights_dev, size_t bytes);
+
+size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch);
+/* x_dev  : [B,3,img,img] fp32 NCHW, C-contiguous (the tensor infer_effocr.py:313 stacks)
+ * emb_dev: [B,D] fp32.  l2_normalize != 0 fuses F.normalize(p=2,dim=1) (infer_effocr.py:316). */
+int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev,
+                           int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * k-NN engine.  Replaces faiss.IndexFlatIP as driven by pytorch_metric_learning's FaissKNN:
+ * infer_effocr.py:184-187,207,211,317; infer_effocr_onnx_multi.py:496-500,509,372;
+ * train_effocr_recognizer.py:47-52.
+ * ------------------------------------------------------------------------------------------ */
+size_t effocr_knn_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k);
+/* IndexFlatIP.search: q_dev [nq,d] fp32, xb_dev [ntotal,d] fp32 row-major ->
+ * dist_dev [nq,k] fp32 descending, idx_dev [nq,k] int64; k > ntotal pads (-FLT_MAX, -1).
+ * Scores are the ascending-k fp32 fmaf chain; equal scores rank by ascending id.  k <= 32. */
+int effocr_knn_ip_topk(const float* q_dev, int64_t nq, const float* xb_dev, int64_t ntotal, int d, int k,
+                       float* dist_dev, int64_t* idx_dev, void* workspace_dev, size_t workspace_bytes,
+                       void* stream);
+/* torch.nn.functional.normalize(x, p=2, dim=1) (infer_effocr.py:316; PML InferenceModel default) */
+int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void* stream);
+/* IndexFlat.remove_ids compaction (infer_effocr.py:211): dst[i] = src[keep_rows[i]] */
+int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64_t n_keep, int d,
+                       float* dst_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Individual encoder operators (exported so that each kernel is parity-tested on its own).
+ * Operand buffers are in `precision`'s element type unless stated fp32.
+ * ------------------------------------------------------------------------------------------ */
+enum effocr_epilogue { EFFOCR_EPI_BIAS = 0, EFFOCR_EPI_BIAS_GELU = 1, EFFOCR_EPI_BIAS_RESID = 2 };
+/* out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]); RESID: out (fp32) = resid (fp32) + ... */
+int effocr_op_linear(int precision, int epilogue, const void* x_dev, const void* w_dev, const float* bias_dev,
+                     const float* resid_dev, void* out_dev, int m, int n, int k, void* stream);
+int effocr_op_layernorm(int out_precision, const float* x_dev, int64_t rows, int d, const float* gamma_dev,
+                        const float* beta_dev, float eps, void* out_dev, void* stream);
+/* qkv_dev [B*T, 3*heads*64] -> out_dev [B*T, heads*64], head_dim fixed at 64 */
+int effocr_op_attention(int precision, const void* qkv_dev, void* out_dev, int batch, int tokens, int heads,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFOCR_HIP_H */

@@ -1,0 +1,111 @@
+"""-m gpu: every HIP operator of the encoder against a CPU fp64/fp32 restatement, called through the
+C ABI (effocr_op_* entry points of include/effocr_hip.h)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from effocr_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+TDT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+
+def _stream(dev):
+    return _lib.current_stream(dev)
+
+
+def op_linear(L, dev, prec, epi, x, w, bias, resid=None):
+    M, K = x.shape
+    N = w.shape[0]
+    xd, wd, bd = x.to(dev).contiguous(), w.to(dev).contiguous(), bias.to(dev).contiguous()
+    if epi == "bias_resid":
+        out = resid.to(dev).clone().contiguous()
+        rd = out
+    else:
+        out = torch.empty((M, N), dtype=TDT[prec], device=dev)
+        rd = None
+    _lib.check(L.effocr_op_linear(_lib.PREC[prec], _lib.EPI[epi], _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd),
+                                  _lib.ptr(rd), _lib.ptr(out), M, N, K, _stream(dev)), "op_linear")
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("epi", ["bias", "bias_gelu", "bias_resid"])
+@pytest.mark.parametrize("shape", [(197 * 3, 384, 384), (100, 128, 1536), (256, 1152, 384), (1, 128, 128)])
+def test_linear(hip_lib, dev, prec, epi, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g).to(TDT[prec])
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(TDT[prec])
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    got = op_linear(hip_lib, dev, prec, epi, x, w, bias, resid)
+    ref = x.double() @ w.double().T + bias.double()
+    if epi == "bias_gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if epi == "bias_resid":
+        ref = ref + resid.double()
+    # operands are exactly representable, so only the fp32 accumulation order and (for 16-bit
+    # outputs) the final rounding differ
+    tol = {"bf16": 8e-3, "fp16": 1e-3, "fp32": 2e-5}[prec] if epi != "bias_resid" else 2e-5
+    err = (got.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * scale, f"{prec} {epi} {shape}: err {err:.3e} scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("D,rows", [(384, 1000), (768, 33), (128, 17), (384, 1)])
+def test_layernorm(hip_lib, dev, prec, D, rows):
+    g = torch.Generator().manual_seed(D + rows)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    out = torch.empty((rows, D), dtype=TDT[prec], device=dev)
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    _lib.check(hip_lib.effocr_op_layernorm(_lib.PREC[prec], _lib.ptr(xd), rows, D, _lib.ptr(gd), _lib.ptr(bd),
+                                           1e-6, _lib.ptr(out), _stream(dev)), "op_layernorm")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6)
+    tol = {"bf16": 8e-3, "fp16": 1e-3, "fp32": 1e-5}[prec]
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= tol * ref.abs().max().item()
+
+
+def attention_ref(qkv, B, T, heads):
+    D = heads * 64
+    q, k, v = qkv.double().reshape(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1)
+    return (att @ v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("B,T,heads", [(3, 197, 6), (2, 17, 2), (1, 197, 12), (5, 50, 2), (2, 224, 2), (1, 1, 2)])
+def test_attention(hip_lib, dev, prec, B, T, heads):
+    D = heads * 64
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(TDT[prec])
+    qd = qkv.to(dev)
+    out = torch.full((B * T, D), float("nan"), dtype=TDT[prec], device=dev)
+    _lib.check(hip_lib.effocr_op_attention(_lib.PREC[prec], _lib.ptr(qd), _lib.ptr(out), B, T, heads, _stream(dev)),
+               "op_attention")
+    torch.cuda.synchronize()
+    ref = attention_ref(qkv, B, T, heads)
+    got = out.float().cpu().double()
+    assert torch.isfinite(got).all()
+    tol = {"bf16": 1.5e-2, "fp16": 2e-3, "fp32": 1e-5}[prec]      # P is rounded to the operand type
+    err = (got - ref).abs().max().item()
+    assert err <= tol * ref.abs().max().item(), f"err {err:.3e} vs scale {ref.abs().max().item():.3e}"
+
+
+def test_unsupported_shapes_fail_loudly(hip_lib, dev):
+    x = torch.zeros(4, 100, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(128, 100, device=dev, dtype=torch.bfloat16)
+    b = torch.zeros(128, device=dev)
+    o = torch.zeros(4, 128, device=dev, dtype=torch.bfloat16)
+    rc = hip_lib.effocr_op_linear(0, 0, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(o), 4, 128, 100, None)
+    assert rc == -2 and b"multiple" in hip_lib.effocr_last_error()
+    rc = hip_lib.effocr_op_attention(0, _lib.ptr(x), _lib.ptr(o), 1, 100, 2, None)
+    assert rc == -2

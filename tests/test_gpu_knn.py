@@ -1,0 +1,125 @@
+"""-m gpu: the inner-product top-k kernel against the C oracle (oracle/flat_ip.c) — BIT-EXACT scores
+and identical ids (ascending-k fmaf chain, ties -> lower id) — plus FaissKNN / IndexFlatIP semantics."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def unit(a):
+    return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+
+
+def make(B, N, D, seed):
+    rng = np.random.default_rng(seed)
+    X = unit(rng.standard_normal((N, D)))
+    if N:
+        Q = unit(X[rng.integers(0, N, B)] + 0.1 * rng.standard_normal((B, D)).astype(np.float32))
+    else:
+        Q = unit(rng.standard_normal((B, D)))
+    return Q, X
+
+
+@pytest.mark.parametrize("B,N,D,k", [
+    (64, 96, 512, 10),          # BASELINE config 1
+    (1024, 10000, 384, 10),     # BASELINE config 2
+    (64, 10000, 384, 1),        # ONNX driver call (k=1, batches of 64)
+    (7, 1000, 384, 10), (130, 257, 768, 16), (33, 129, 128, 32), (1, 1, 32, 1),
+    (5, 5, 64, 10),             # k > ntotal -> (-FLT_MAX, -1) padding
+    (300, 70000, 384, 10),      # multi-tile chunks + chunk merge
+])
+def test_knn_bit_exact(dev, B, N, D, k):
+    from effocr_amd.knn import IndexFlatIP
+    Q, X = make(B, N, D, seed=B + N + D + k)
+    idx = IndexFlatIP(D, device=dev)
+    idx.add(X)
+    assert idx.ntotal == N
+    Dg, Ig = idx.search(Q, k)
+    Dr, Ir = knn_ref.flat_ip_search(Q, X, k)
+    assert Ig.dtype == np.int64 and Dg.dtype == np.float32
+    np.testing.assert_array_equal(Ig, Ir)
+    np.testing.assert_array_equal(Dg.view(np.uint32), Dr.view(np.uint32))     # bit-exact scores
+
+
+def test_knn_exact_ties_lowest_id(dev):
+    from effocr_amd.knn import IndexFlatIP
+    rng = np.random.default_rng(5)
+    base = unit(rng.standard_normal((40, 384)))
+    X = np.concatenate([base, base[:20], base[5:9], base])          # many exact duplicates
+    Q = base[:33].copy()
+    idx = IndexFlatIP(384, device=dev)
+    idx.add(X)
+    Dg, Ig = idx.search(Q, 10)
+    Dr, Ir = knn_ref.flat_ip_search(Q, X, 10)
+    np.testing.assert_array_equal(Ig, Ir)
+    np.testing.assert_array_equal(Dg.view(np.uint32), Dr.view(np.uint32))
+    for b in range(33):                                             # duplicates appear in id order
+        same = Ig[b][Dg[b] == Dg[b][0]]
+        assert list(same) == sorted(same)
+
+
+def test_empty_index_and_empty_query(dev):
+    from effocr_amd.knn import IndexFlatIP
+    idx = IndexFlatIP(64, device=dev)
+    D, I = idx.search(np.ones((3, 64), np.float32), 4)
+    assert (I == -1).all() and (D == np.float32(knn_ref.NEG)).all()
+    idx.add(np.eye(64, dtype=np.float32))
+    D, I = idx.search(np.zeros((0, 64), np.float32), 4)
+    assert D.shape == (0, 4) and I.shape == (0, 4)
+
+
+def test_remove_ids_compacts_like_faiss(dev):
+    from effocr_amd.knn import IndexFlatIP
+    Q, X = make(50, 300, 384, seed=3)
+    idx = IndexFlatIP(384, device=dev)
+    idx.add(X)
+    rm = np.array([0, 17, 299, 150, 17], dtype=np.int64)
+    assert idx.remove_ids(rm) == 4 and idx.ntotal == 296
+    Xc = knn_ref.remove_ids(X, rm)
+    np.testing.assert_array_equal(idx.reconstruct_n(), Xc)
+    Dg, Ig = idx.search(Q, 10)
+    Dr, Ir = knn_ref.flat_ip_search(Q, Xc, 10)
+    np.testing.assert_array_equal(Ig, Ir)
+
+
+def test_faissknn_and_index_file_roundtrip(dev, tmp_path):
+    from effocr_amd.knn import FaissKNN, IndexFlatIP, read_index
+    Q, X = make(40, 500, 384, seed=11)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
+    knn.train(torch.from_numpy(X))
+    q = torch.from_numpy(Q).to(dev)
+    d, i = knn(q, k=10)
+    assert d.device == q.device and i.dtype == torch.int64 and tuple(i.shape) == (40, 10)
+    Dr, Ir = knn_ref.flat_ip_search(Q, X, 10)
+    np.testing.assert_array_equal(i.cpu().numpy(), Ir)
+    # CPU query tensor -> results come back on the CPU (FaissKNN returns on query.device)
+    d2, i2 = knn(torch.from_numpy(Q), k=10)
+    assert d2.device.type == "cpu" and torch.equal(i2, i.cpu())
+    # ref_includes_query drops the self match
+    d3, i3 = knn(torch.from_numpy(X[:8]), k=3, ref_includes_query=True)
+    _, Ir4 = knn_ref.flat_ip_search(X[:8], X, 4)
+    np.testing.assert_array_equal(i3.numpy(), Ir4[:, 1:])
+    p = tmp_path / "ref.index"
+    knn.save(str(p))
+    knn2 = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
+    knn2.load(str(p))
+    assert knn2.index.ntotal == 500 and knn2.index.d == 384
+    np.testing.assert_array_equal(knn2.index.reconstruct_n(), X)
+    _, i4 = knn2(q, k=10)
+    assert torch.equal(i4, i)
+    with pytest.raises(Exception):
+        knn2(q, k=33)                       # k > 32 is refused loudly, never silently wrong
+
+
+def test_l2_normalize_matches_oracle(dev):
+    from effocr_amd.knn import l2_normalize
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((77, 384)).astype(np.float32) * 5
+    x[3] = 0                                 # zero row: x / max(0, 1e-12) = 0
+    y = l2_normalize(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = knn_ref.l2_normalize(x)
+    np.testing.assert_allclose(y, ref, rtol=2e-6, atol=1e-7)
+    assert (y[3] == 0).all()
