@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py — glyph-crops/s end-to-end (encode + L2-normalise + inner-product top-k) on MI355X.
+
+Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON
+line on rank 0.  A *step* is one pass of the hot path over one batch of synthetic crops:
+BASELINE.json configs[1] — ViT-S/16 encoder, bf16 MFMA operands, 1024 x 3x224x224 fp32 crops per GPU
+already resident in HBM, 10,000-row fp32 glyph index, k=10.  For N>1 every rank (one process per
+GPU, launched by torch.distributed.run) processes its own 1024 crops (weak scaling; encoder weights
+and index replicated) and one RCCL all_gather assembles the [N*1024, 10] ids on every rank.
+
+Extra objects on the line:
+  roofline      the dominant kernel class, timed live with HIP events recorded on the launch stream
+                INSIDE the timed region by the library's own profiler (effocr_encoder_profile_*):
+                achieved = algorithmic FLOPs per launch / mean launch duration, vs the dense bf16
+                MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline  rank 0, N=1 only: the CPU restatement of the reference path (oracle/: plain-torch
+                fp32 ViT-S + F.normalize + Q@X^T/top-k, i.e. PyTorch-CPU + IndexFlatIP semantics; timm
+                and faiss cannot be installed offline) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}      # dense, MI355X_MICROARCH.md
+FLOP_PER_CROP = {"vit_small_patch16_224": 9.197e9, "vit_base_patch16_224": 35.13e9}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="vit_small_patch16_224")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--batch", type=int, default=1024, help="crops per GPU per step")
+    ap.add_argument("--index-rows", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel-class table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(arch, sd, index_cpu, k, target_s):
+    """PyTorch-CPU fp32 restatement of the reference path on a bounded sample; returns dict."""
+    from oracle.encoders_ref import encoder_forward, l2_normalize
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1234)
+
+    def run(n):
+        x = torch.randn(n, 3, 224, 224, generator=g)
+        t0 = time.perf_counter()
+        emb = l2_normalize(encoder_forward(arch, sd, x))
+        s = emb @ index_cpu.T
+        torch.topk(s, k, dim=1)
+        return time.perf_counter() - t0
+
+    run(8)                                   # warm the thread pool / allocator
+    t = run(32)
+    rate = 32 / t
+    n = int(max(32, min(1024, rate * target_s)))
+    n = (n // 32) * 32
+    t = run(n)
+    return {"value": round(n / t, 2), "unit": "glyph-crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} of the 1024 crops of one step (same shapes, fp32, torch {torch.__version__} CPU, "
+                      f"oracle/encoders_ref.py + normalize + Q@X^T top-{k} over the full {index_cpu.shape[0]}-row index), {t:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import FaissKNN, IndexFlatIP
+    from effocr_amd.weights import init_state_dict
+    from effocr_amd.dist import all_gather_rows
+
+    # ---- synthetic workload (seeded; identical weights/index on every rank, per-rank crops)
+    sd = init_state_dict(a.arch, seed=0, img_size=224)
+    enc = HipEncoder(a.arch, sd, img_size=224, precision=a.precision, device=dev)
+    D = enc.embed_dim
+    gi = torch.Generator().manual_seed(0)
+    index_cpu = torch.nn.functional.normalize(torch.randn(a.index_rows, D, generator=gi), dim=1)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.train(index_cpu)
+    gx = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(a.batch, 3, 224, 224, generator=gx, device=dev)          # resident in HBM
+    n_total = a.batch * world
+
+    def step():
+        emb = enc.forward(x, normalize=True)
+        d, i = knn(emb, k=a.k)
+        if world > 1:
+            i = all_gather_rows(i, n_total)
+        return i
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    # pick the dominant kernel class with one fully-profiled step (untimed)
+    enc.profile_begin()
+    step()
+    table = enc.profile_collect()
+    dom = max(table, key=lambda n: table[n]["ms"]) if table else None
+    if a.breakdown and rank == 0:
+        tot = sum(v["ms"] for v in table.values())
+        for n, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            print(f"  {n:18s} {v['ms']:8.3f} ms {100 * v['ms'] / tot:5.1f}%  x{v['launches']:3d}  {tf:8.1f} TFLOP/s", file=sys.stderr)
+        print(f"  {'sum of kernels':18s} {tot:8.3f} ms", file=sys.stderr)
+
+    # ---- timed region: exactly K steps between barrier+synchronize fences; only the dominant class
+    # carries event pairs (2 events per launch of that class), everything else runs untouched
+    if dom:
+        enc.profile_begin(only=dom)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = enc.profile_collect() if dom else {}
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert tuple(out.shape) == (n_total, a.k)
+
+    if rank == 0:
+        value = n_total * a.steps / dt
+        line = {
+            "metric": "glyph-crops/sec end-to-end (encode+kNN), 224x224 bs=1024",
+            "value": round(value, 1), "unit": "glyph-crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {a.arch} encoder ({a.precision} MFMA operands, fp32 accumulate/"
+                                   f"residual/LN/softmax), {a.batch}x3x224x224 fp32 crops per GPU resident in HBM, "
+                                   f"{a.index_rows}-row fp32 IndexFlatIP, k={a.k}; seeded random-init weights",
+                       "crops_per_gpu": a.batch, "global_batch": n_total, "index_rows": a.index_rows, "k": a.k,
+                       "parallelism": f"crops sharded over {world} GPU(s), weights+index replicated"
+                                      + (", all_gather(ids) over RCCL" if world > 1 else "")},
+        }
+        if dom and dom in prof and prof[dom]["launches"]:
+            p = prof[dom]
+            sec = p["ms"] * 1e-3 / p["launches"]
+            fl = p["flops"] / p["launches"]
+            peak = MFMA_PEAK[a.precision]
+            line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(fl / sec / 1e12, 2),
+                                "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(fl / sec / peak, 4),
+                                "flops_per_launch": fl, "avg_launch_us": round(sec * 1e6, 2), "launches": p["launches"],
+                                "traffic": None}
+        if a.arch in FLOP_PER_CROP:
+            line["encoder_mfma_frac_end_to_end"] = round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.arch, sd, index_cpu, a.k, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,10 @@ def _declare(lib):
         "effocr_encoder_upload": (i32, [vp, vp, sz]),
         "effocr_encoder_workspace_bytes": (sz, [vp, i32]),
         "effocr_encoder_forward": (i32, [vp, f32p, i32, f32p, i32, vp, sz, vp]),
+        "effocr_encoder_profile_begin": (i32, [vp, i32, c.c_char_p]),
+        "effocr_encoder_profile_collect": (i32, [vp]),
+        "effocr_encoder_profile_get": (i32, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double), c.POINTER(i32),
+                                             c.POINTER(c.c_double)]),
         "effocr_knn_workspace_bytes": (sz, [i64, i64, i32, i32]),
         "effocr_knn_ip_topk": (i32, [f32p, i64, f32p, i64, i32, i32, f32p, i64p, vp, sz, vp]),
         "effocr_l2_normalize": (i32, [f32p, i64, i32, f32p, vp]),

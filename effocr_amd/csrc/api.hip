@@ -52,6 +52,17 @@ struct effocr_encoder {
   std::vector<ConvSpec> convs;      // conv1, then per block conv1, conv2, (downsample)
   size_t wbytes = 0;
   const char* wdev = nullptr;       // device blob after upload
+  // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
+  // selected kernel classes, recorded on the forward's own stream
+  int prof_mode = 0;                // 0 off, 1 every class, 2 only prof_only
+  std::string prof_only;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  std::vector<std::pair<int, int>> prof_rec;      // (class id, pool slot)
+  std::vector<std::string> prof_names;
+  size_t prof_used = 0;
+  std::vector<float> prof_ms;                     // filled by profile_collect
+  std::vector<int> prof_cnt;
+  std::vector<double> prof_work;                  // algorithmic flops (or bytes) per class, summed
 };
 
 namespace effocr {
@@ -234,6 +245,34 @@ void pack_resnet(const effocr_encoder* e, std::vector<char>& blob) {
   }
 }
 
+int prof_class(effocr_encoder* e, const char* name) {
+  for (size_t i = 0; i < e->prof_names.size(); ++i) if (e->prof_names[i] == name) return (int)i;
+  e->prof_names.push_back(name);
+  e->prof_work.push_back(0.0);
+  return (int)e->prof_names.size() - 1;
+}
+
+// Runs `launch` (which enqueues exactly one kernel class on stream s), bracketed by an event pair
+// when the profiler is armed for that class.  `work` = algorithmic flops of the launch.
+template <typename F>
+int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F launch) {
+  const bool on = e->prof_mode == 1 || (e->prof_mode == 2 && e->prof_only == name);
+  if (!on) return launch();
+  if (e->prof_used == e->prof_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(EFFOCR_EHIP, "profile: hipEventCreate failed");
+    e->prof_pool.push_back({a, b});
+  }
+  const int cls = prof_class(e, name);
+  const size_t slot = e->prof_used++;
+  hipEventRecord(e->prof_pool[slot].first, s);
+  const int rc = launch();
+  hipEventRecord(e->prof_pool[slot].second, s);
+  e->prof_rec.push_back({cls, (int)slot});
+  e->prof_work[cls] += work;
+  return rc;
+}
+
 struct VitWs { size_t x, xn, qkv, att, h, total; };
 VitWs vit_ws(const effocr_encoder* e, int B) {
   const size_t M = (size_t)B * e->T, D = e->vit.D, es = prec_esize(e->prec);
@@ -256,35 +295,36 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   void* xn = ws + w.xn; void* qkv = ws + w.qkv; void* att = ws + w.att; void* hb = ws + w.h;
   auto F = [&](size_t off) { return reinterpret_cast<const float*>(wb + off); };
   int rc;
-  if ((rc = im2col_patch16(prec, x, B, e->img, e->img, hb, s))) return rc;
+  const double Md = (double)M, Dd = (double)D, Hd = (double)e->vit.mlp;
+  if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, s))) return rc;
   GemmArgs g{};
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
   g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn;
-  if ((rc = gemm_nt(prec, EPI_PATCH, g, s))) return rc;
+  if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
-    if ((rc = layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s))) return rc;
+    if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
     g = GemmArgs{};
     g.X = xn; g.ldx = D; g.W = wb + L.qkvw; g.ldw = D; g.bias = F(L.qkvb); g.out = qkv; g.ldo = 3 * D;
     g.M = M; g.N = 3 * D; g.K = D;
-    if ((rc = gemm_nt(prec, EPI_BIAS, g, s))) return rc;
-    if ((rc = attention(prec, qkv, att, B, T, e->vit.heads, s))) return rc;
+    if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS, g, s); }))) return rc;
+    if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
     g = GemmArgs{};
     g.X = att; g.ldx = D; g.W = wb + L.projw; g.ldw = D; g.bias = F(L.projb); g.out = xs; g.ldo = D;
     g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = D;
-    if ((rc = gemm_nt(prec, EPI_BIAS_RESID, g, s))) return rc;
-    if ((rc = layernorm_rows(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s))) return rc;
+    if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
+    if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
     g = GemmArgs{};
     g.X = xn; g.ldx = D; g.W = wb + L.fc1w; g.ldw = D; g.bias = F(L.fc1b); g.out = hb; g.ldo = e->vit.mlp;
     g.M = M; g.N = e->vit.mlp; g.K = D;
-    if ((rc = gemm_nt(prec, EPI_BIAS_GELU, g, s))) return rc;
+    if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS_GELU, g, s); }))) return rc;
     g = GemmArgs{};
     g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
     g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp;
-    if ((rc = gemm_nt(prec, EPI_BIAS_RESID, g, s))) return rc;
+    if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] { return gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }
-  return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, emb, s);
+  return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, emb, s); });
 }
 
 struct ResWs { size_t col, a, b, c, total; };
@@ -394,7 +434,11 @@ int effocr_encoder_create(const char* arch, int img_size, int precision, effocr_
   return EFFOCR_OK;
 }
 
-void effocr_encoder_destroy(effocr_encoder_t* enc) { delete enc; }
+void effocr_encoder_destroy(effocr_encoder_t* enc) {
+  if (!enc) return;
+  for (auto& ev : enc->prof_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  delete enc;
+}
 int effocr_encoder_embed_dim(const effocr_encoder_t* enc) { return enc ? enc->D : 0; }
 int effocr_encoder_num_params(const effocr_encoder_t* enc) { return enc ? (int)enc->params.size() : 0; }
 const char* effocr_encoder_param_name(const effocr_encoder_t* enc, int i) {
@@ -452,6 +496,43 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
   char* ws = static_cast<char*>(workspace_dev);
   return enc->is_vit ? vit_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream))
                      : resnet_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream));
+}
+
+int effocr_encoder_profile_begin(effocr_encoder_t* enc, int mode, const char* only_class) {
+  if (!enc || mode < 0 || mode > 2) return fail(EFFOCR_EINVAL, "profile_begin: bad argument");
+  if (mode == 2 && !only_class) return fail(EFFOCR_EINVAL, "profile_begin: mode 2 needs a class name");
+  enc->prof_mode = mode;
+  enc->prof_only = only_class ? only_class : "";
+  enc->prof_rec.clear(); enc->prof_used = 0;
+  enc->prof_names.clear(); enc->prof_work.clear(); enc->prof_ms.clear(); enc->prof_cnt.clear();
+  return EFFOCR_OK;
+}
+
+int effocr_encoder_profile_collect(effocr_encoder_t* enc) {
+  if (!enc) return fail(EFFOCR_EINVAL, "profile_collect: NULL encoder");
+  enc->prof_mode = 0;
+  enc->prof_ms.assign(enc->prof_names.size(), 0.f);
+  enc->prof_cnt.assign(enc->prof_names.size(), 0);
+  for (const auto& r : enc->prof_rec) {
+    const auto& ev = enc->prof_pool[r.second];
+    if (hipEventSynchronize(ev.second) != hipSuccess) return fail(EFFOCR_EHIP, "profile_collect: hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess) return fail(EFFOCR_EHIP, "profile_collect: hipEventElapsedTime failed");
+    enc->prof_ms[r.first] += ms;
+    enc->prof_cnt[r.first] += 1;
+  }
+  enc->prof_rec.clear(); enc->prof_used = 0;
+  return (int)enc->prof_names.size();
+}
+
+int effocr_encoder_profile_get(const effocr_encoder_t* enc, int i, const char** name, double* total_ms, int* launches,
+                               double* total_work) {
+  if (!enc || i < 0 || i >= (int)enc->prof_ms.size()) return fail(EFFOCR_EINVAL, "profile_get: bad index");
+  if (name) *name = enc->prof_names[i].c_str();
+  if (total_ms) *total_ms = enc->prof_ms[i];
+  if (launches) *launches = enc->prof_cnt[i];
+  if (total_work) *total_work = enc->prof_work[i];
+  return EFFOCR_OK;
 }
 
 size_t effocr_knn_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k) { return knn_workspace_bytes(nq, ntotal, d, k); }

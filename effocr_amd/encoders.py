@@ -86,6 +86,25 @@ class HipEncoder:
 
     __call__ = forward
 
+    # -- HIP-event profiler (bench.py roofline) --------------------------------------------------
+    def profile_begin(self, only=None):
+        """Arm the in-library profiler: every kernel class, or only the class named ``only``."""
+        _lib.check(self._L.effocr_encoder_profile_begin(self._h, 2 if only else 1, only.encode() if only else None),
+                   "effocr_encoder_profile_begin")
+
+    def profile_collect(self):
+        """-> {class: {"ms": total, "launches": n, "flops": total algorithmic FLOPs}} (synchronises)."""
+        n = self._L.effocr_encoder_profile_collect(self._h)
+        if n < 0:
+            _lib.check(n, "effocr_encoder_profile_collect")
+        out = {}
+        for i in range(n):
+            name, ms, cnt, work = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+            _lib.check(self._L.effocr_encoder_profile_get(self._h, i, ctypes.byref(name), ctypes.byref(ms),
+                                                          ctypes.byref(cnt), ctypes.byref(work)), "profile_get")
+            out[name.value.decode()] = {"ms": ms.value, "launches": cnt.value, "flops": work.value}
+        return out
+
 
 def AutoEncoderFactory(backend, modelpath, precision="bf16", img_size=224):
     """Drop-in for models/encoders.py:50 ``AutoEncoderFactory(backend, modelpath)``.

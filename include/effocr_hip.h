@@ -82,6 +82,16 @@ size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch);
 int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev,
                            int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* HIP-event profiler for bench.py's roofline object: while armed, every launch of the selected
+ * kernel classes inside effocr_encoder_forward is bracketed by an event pair on the forward's own
+ * stream.  mode 0 = off, 1 = every class, 2 = only `only_class` (e.g. "gemm_fc1_gelu").
+ * profile_collect synchronises the recorded events, disarms, and returns the number of classes;
+ * profile_get reads class i: summed duration (ms), launch count and summed algorithmic FLOPs. */
+int effocr_encoder_profile_begin(effocr_encoder_t* enc, int mode, const char* only_class);
+int effocr_encoder_profile_collect(effocr_encoder_t* enc);
+int effocr_encoder_profile_get(const effocr_encoder_t* enc, int i, const char** name, double* total_ms,
+                               int* launches, double* total_work);
+
 /* ------------------------------------------------------------------------------------------
  * k-NN engine.  Replaces faiss.IndexFlatIP as driven by pytorch_metric_learning's FaissKNN:
  * infer_effocr.py:184-187,207,211,317; infer_effocr_onnx_multi.py:496-500,509,372;
