@@ -54,6 +54,9 @@ def _declare(lib):
         "effocr_encoder_upload": (i32, [vp, vp, sz]),
         "effocr_encoder_workspace_bytes": (sz, [vp, i32]),
         "effocr_encoder_forward": (i32, [vp, f32p, i32, f32p, i32, vp, sz, vp]),
+        "effocr_encoder_set_chunk": (i32, [vp, i32]),
+        "effocr_encoder_set_option": (i32, [vp, c.c_char_p, i32]),
+        "effocr_op_ln_linear": (i32, [i32, i32, f32p, f32p, f32p, c.c_float, vp, f32p, f32p, vp, i32, i32, i32, vp]),
         "effocr_encoder_profile_begin": (i32, [vp, i32, c.c_char_p]),
         "effocr_encoder_profile_collect": (i32, [vp]),
         "effocr_encoder_profile_get": (i32, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double), c.POINTER(i32),

@@ -54,6 +54,8 @@ struct effocr_encoder {
   const char* wdev = nullptr;       // device blob after upload
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
+  int use_panel = 1;                // 0: force the K-streaming GEMM + standalone LayerNorm path (A/B switch)
+  int chunk = 0;                    // crops per internal sub-batch of the ViT forward (0 = whole batch)
   int prof_mode = 0;                // 0 off, 1 every class, 2 only prof_only
   std::string prof_only;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -265,9 +267,9 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
   }
   const int cls = prof_class(e, name);
   const size_t slot = e->prof_used++;
-  hipEventRecord(e->prof_pool[slot].first, s);
+  (void)hipEventRecord(e->prof_pool[slot].first, s);
   const int rc = launch();
-  hipEventRecord(e->prof_pool[slot].second, s);
+  (void)hipEventRecord(e->prof_pool[slot].second, s);
   e->prof_rec.push_back({cls, (int)slot});
   e->prof_work[cls] += work;
   return rc;
@@ -302,23 +304,41 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
   g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn;
   if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
+  const bool panel = e->use_panel && panel_gemm_supported(prec, 3 * D, D) && panel_gemm_supported(prec, e->vit.mlp, D);
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
-    if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
-    g = GemmArgs{};
-    g.X = xn; g.ldx = D; g.W = wb + L.qkvw; g.ldw = D; g.bias = F(L.qkvb); g.out = qkv; g.ldo = 3 * D;
-    g.M = M; g.N = 3 * D; g.K = D;
-    if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS, g, s); }))) return rc;
-    if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
-    g = GemmArgs{};
-    g.X = att; g.ldx = D; g.W = wb + L.projw; g.ldw = D; g.bias = F(L.projb); g.out = xs; g.ldo = D;
-    g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = D;
-    if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
-    if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
-    g = GemmArgs{};
-    g.X = xn; g.ldx = D; g.W = wb + L.fc1w; g.ldw = D; g.bias = F(L.fc1b); g.out = hb; g.ldo = e->vit.mlp;
-    g.M = M; g.N = e->vit.mlp; g.K = D;
-    if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS_GELU, g, s); }))) return rc;
+    if (panel) {
+      // row-panel kernels: LayerNorm fused into the A-panel load, no xn buffer, no LayerNorm launches
+      PanelArgs p{};
+      p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
+      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D;
+      if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
+      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
+      p = PanelArgs{};
+      p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
+      p.M = M; p.N = D; p.K = D;
+      if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
+      p = PanelArgs{};
+      p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
+      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D;
+      if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
+    } else {
+      if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
+      g = GemmArgs{};
+      g.X = xn; g.ldx = D; g.W = wb + L.qkvw; g.ldw = D; g.bias = F(L.qkvb); g.out = qkv; g.ldo = 3 * D;
+      g.M = M; g.N = 3 * D; g.K = D;
+      if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS, g, s); }))) return rc;
+      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
+      g = GemmArgs{};
+      g.X = att; g.ldx = D; g.W = wb + L.projw; g.ldw = D; g.bias = F(L.projb); g.out = xs; g.ldo = D;
+      g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = D;
+      if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
+      if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
+      g = GemmArgs{};
+      g.X = xn; g.ldx = D; g.W = wb + L.fc1w; g.ldw = D; g.bias = F(L.fc1b); g.out = hb; g.ldo = e->vit.mlp;
+      g.M = M; g.N = e->vit.mlp; g.K = D;
+      if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS_GELU, g, s); }))) return rc;
+    }
     g = GemmArgs{};
     g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
     g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp;
@@ -436,7 +456,7 @@ int effocr_encoder_create(const char* arch, int img_size, int precision, effocr_
 
 void effocr_encoder_destroy(effocr_encoder_t* enc) {
   if (!enc) return;
-  for (auto& ev : enc->prof_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  for (auto& ev : enc->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   delete enc;
 }
 int effocr_encoder_embed_dim(const effocr_encoder_t* enc) { return enc ? enc->D : 0; }
@@ -480,7 +500,22 @@ int effocr_encoder_upload(effocr_encoder_t* enc, void* weights_dev, size_t bytes
 
 size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch) {
   if (!enc || batch <= 0) return 0;
-  return enc->is_vit ? vit_ws(enc, batch).total : resnet_ws(enc, batch).total;
+  if (!enc->is_vit) return resnet_ws(enc, batch).total;
+  return vit_ws(enc, (enc->chunk > 0 && enc->chunk < batch) ? enc->chunk : batch).total;
+}
+
+int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value) {
+  if (!enc || !name) return fail(EFFOCR_EINVAL, "set_option: NULL argument");
+  const std::string n = name;
+  if (n == "use_panel") { enc->use_panel = value; return EFFOCR_OK; }
+  if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
+  return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");
+}
+
+int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk) {
+  if (!enc || crops_per_chunk < 0) return fail(EFFOCR_EINVAL, "set_chunk: bad argument");
+  enc->chunk = crops_per_chunk;
+  return EFFOCR_OK;
 }
 
 int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev, int l2_normalize,
@@ -494,8 +529,17 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
   if ((int64_t)batch * (enc->is_vit ? enc->T : enc->img * enc->img) >= (int64_t)1 << 30)
     return fail(EFFOCR_EUNSUPPORTED, "forward: batch too large for 32-bit row indices");
   char* ws = static_cast<char*>(workspace_dev);
-  return enc->is_vit ? vit_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream))
-                     : resnet_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream));
+  if (!enc->is_vit) return resnet_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream));
+  // sub-batches: all activations of `chunk` crops (~1.6 MB per ViT-S crop) stay resident in the
+  // 256 MiB Infinity Cache between consecutive kernels instead of round-tripping through HBM
+  const int chunk = enc->chunk > 0 ? enc->chunk : batch;
+  const size_t img_elems = (size_t)3 * enc->img * enc->img;
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int cb = (batch - b0 < chunk) ? batch - b0 : chunk;
+    const int rc = vit_forward(enc, x_dev + (size_t)b0 * img_elems, cb, emb_dev + (size_t)b0 * enc->D, l2_normalize, ws, S(stream));
+    if (rc) return rc;
+  }
+  return EFFOCR_OK;
 }
 
 int effocr_encoder_profile_begin(effocr_encoder_t* enc, int mode, const char* only_class) {
@@ -557,10 +601,26 @@ int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64
 int effocr_op_linear(int precision, int epilogue, const void* x_dev, const void* w_dev, const float* bias_dev,
                      const float* resid_dev, void* out_dev, int m, int n, int k, void* stream) {
   if (epilogue < 0 || epilogue > 2) return fail(EFFOCR_EINVAL, "op_linear: unknown epilogue");
+  if (panel_gemm_supported(precision, n, k)) {          // same dispatch rule as the encoder forward
+    PanelArgs p{};
+    p.A = x_dev; p.lda = k; p.W = w_dev; p.bias = bias_dev; p.out = out_dev; p.ldo = n; p.resid = resid_dev; p.ldr = n;
+    p.M = m; p.N = n; p.K = k;
+    return panel_gemm(precision, PRO_COPY, epilogue, p, S(stream));
+  }
   GemmArgs g{};
   g.X = x_dev; g.ldx = k; g.W = w_dev; g.ldw = k; g.bias = bias_dev; g.out = out_dev; g.ldo = n;
   g.resid = resid_dev; g.ldr = n; g.M = m; g.N = n; g.K = k;
   return gemm_nt(precision, epilogue, g, S(stream));
+}
+
+int effocr_op_ln_linear(int precision, int epilogue, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                        float eps, const void* w_dev, const float* bias_dev, const float* resid_dev, void* out_dev,
+                        int m, int n, int k, void* stream) {
+  if (epilogue < 0 || epilogue > 2) return fail(EFFOCR_EINVAL, "op_ln_linear: unknown epilogue");
+  PanelArgs p{};
+  p.A = x_dev; p.lda = k; p.gamma = gamma_dev; p.beta = beta_dev; p.eps = eps; p.W = w_dev; p.bias = bias_dev;
+  p.out = out_dev; p.ldo = n; p.resid = resid_dev; p.ldr = n; p.M = m; p.N = n; p.K = k;
+  return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
 
 int effocr_op_layernorm(int out_precision, const float* x_dev, int64_t rows, int d, const float* gamma_dev,

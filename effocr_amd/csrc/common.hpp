@@ -52,8 +52,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + in;
 }
 
-// erf-based GELU (torch.nn.GELU default, what timm's Mlp uses)
+// erf-based GELU (torch.nn.GELU default, what timm's Mlp uses): 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Same function with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free: one
+// v_rcp, one v_exp, 5 FMAs) — used when the result is rounded to bf16/f16 anyway (2^-9 / 2^-12
+// relative), where libm's two-branch erff is wasted work in the GEMM epilogue.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erfz = 1.0f - p * e;                       // erf(|x|/sqrt2) in [0,1)
+  const float h = 0.5f * x;
+  return fmaf(copysignf(erfz, x), h, h);                 // 0.5x + 0.5x*erf(x/sqrt2)
+}
 
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

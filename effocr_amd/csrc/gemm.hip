@@ -82,42 +82,72 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, per (i,j,q), 4 consecutive features of one token
+  // ---- epilogue: lane holds, per (i,j,q), 4 consecutive features of one token.  All loads (bias,
+  // residual, pos_embed) are issued before the first store: out may alias resid (in-place residual
+  // stream), which would otherwise force load -> wait -> store serialisation.
   const int half = lane >> 5;
   TO* out = static_cast<TO*>(g.out);
+  f32x4 bv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * half);
+  bool mok[2];
+  int64_t orow[2];
+  const float* posrow[2] = {nullptr, nullptr};
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + (lane & 31);
-    if (m >= g.M) continue;
-    int64_t orow = m;
-    const float* posrow = nullptr;
+    int m = m0 + wm * 64 + j * 32 + (lane & 31);
+    mok[j] = m < g.M;
+    m = mok[j] ? m : g.M - 1;
+    orow[j] = m;
     if constexpr (EPI == EPI_PATCH) {
       const int img = m / g.P, p = m - img * g.P;
-      orow = (int64_t)img * (g.P + 1) + 1 + p;
-      posrow = g.pos + (int64_t)(1 + p) * g.N;
+      orow[j] = (int64_t)img * (g.P + 1) + 1 + p;
+      posrow[j] = g.pos + (int64_t)(1 + p) * g.N;
     }
+  }
+  if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_PATCH) {
+    f32x4 rv[2][2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+          if constexpr (EPI == EPI_BIAS_RESID) rv[i][j][q] = *reinterpret_cast<const f32x4*>(g.resid + orow[j] * g.ldr + n);
+          else rv[i][j][q] = *reinterpret_cast<const f32x4*>(posrow[j] + n);
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[i][j][q][e];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (!mok[j]) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-        float v0 = acc[i][j][4 * q + 0] + bv[0];
-        float v1 = acc[i][j][4 * q + 1] + bv[1];
-        float v2 = acc[i][j][4 * q + 2] + bv[2];
-        float v3 = acc[i][j][4 * q + 3] + bv[3];
+        float v0 = acc[i][j][4 * q + 0] + bv[i][q][0];
+        float v1 = acc[i][j][4 * q + 1] + bv[i][q][1];
+        float v2 = acc[i][j][4 * q + 2] + bv[i][q][2];
+        float v3 = acc[i][j][4 * q + 3] + bv[i][q][3];
         if constexpr (EPI == EPI_BIAS_GELU) {
-          v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+          if constexpr (sizeof(TO) == 4) {
+            v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+          } else {
+            v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
+          }
         }
-        if constexpr (EPI == EPI_BIAS_RESID) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(g.resid + orow * g.ldr + n);
-          v0 += rv[0]; v1 += rv[1]; v2 += rv[2]; v3 += rv[3];
-        }
-        if constexpr (EPI == EPI_PATCH) {
-          const f32x4 pv = *reinterpret_cast<const f32x4*>(posrow + n);
-          v0 += pv[0]; v1 += pv[1]; v2 += pv[2]; v3 += pv[3];
-        }
-        store4<TO>(out + orow * g.ldo + n, v0, v1, v2, v3);
+        store4<TO>(out + orow[j] * g.ldo + n, v0, v1, v2, v3);
       }
     }
   }

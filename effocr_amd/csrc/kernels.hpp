@@ -23,6 +23,20 @@ struct GemmArgs {
 // gemm.hip
 int gemm_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 
+// panel.hip — row-panel GEMM with optional fused LayerNorm prologue (K = embed dim)
+enum { PRO_COPY = 0, PRO_LN = 1 };
+struct PanelArgs {
+  const void* A; int64_t lda;       // PRO_COPY: operand-type [M,K]; PRO_LN: fp32 residual stream [M,K] (dense rows)
+  const float* gamma; const float* beta; float eps;   // PRO_LN
+  const void* W;                    // [N,K] operand type, dense rows
+  const float* bias;                // [N]
+  void* out; int64_t ldo;
+  const float* resid; int64_t ldr;  // EPI_BIAS_RESID (may alias out)
+  int M, N, K;
+};
+bool panel_gemm_supported(int prec, int N, int K);
+int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
+
 // vit_ops.hip
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                    float eps, void* out, hipStream_t s);

@@ -56,6 +56,15 @@ class HipEncoder:
         except Exception:
             pass
 
+    def set_chunk(self, crops_per_chunk):
+        """Internal sub-batch size of the ViT forward (0 = whole batch); see effocr_encoder_set_chunk."""
+        _lib.check(self._L.effocr_encoder_set_chunk(self._h, int(crops_per_chunk)), "effocr_encoder_set_chunk")
+        self._ws = None
+
+    def set_option(self, name, value):
+        _lib.check(self._L.effocr_encoder_set_option(self._h, name.encode(), int(value)), "effocr_encoder_set_option")
+        self._ws = None
+
     def workspace_bytes(self, batch):
         return int(self._L.effocr_encoder_workspace_bytes(self._h, int(batch)))
 

@@ -82,6 +82,14 @@ size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch);
 int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev,
                            int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ViT only: run the forward in internal sub-batches of `crops_per_chunk` crops (0 = whole batch) so
+ * that the activations between consecutive kernels stay in the 256 MiB Infinity Cache.  Results
+ * are identical for every setting; it only changes the workspace size and the launch count. */
+int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
+/* tuning / A-B switches: "use_panel" (1 = row-panel GEMMs with fused LayerNorm [default], 0 = K-streaming
+ * GEMM + standalone LayerNorm), "chunk" (= set_chunk).  Results agree to fp32 rounding of the LN. */
+int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value);
+
 /* HIP-event profiler for bench.py's roofline object: while armed, every launch of the selected
  * kernel classes inside effocr_encoder_forward is bracketed by an event pair on the forward's own
  * stream.  mode 0 = off, 1 = every class, 2 = only `only_class` (e.g. "gemm_fc1_gelu").
@@ -118,6 +126,11 @@ enum effocr_epilogue { EFFOCR_EPI_BIAS = 0, EFFOCR_EPI_BIAS_GELU = 1, EFFOCR_EPI
 /* out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]); RESID: out (fp32) = resid (fp32) + ... */
 int effocr_op_linear(int precision, int epilogue, const void* x_dev, const void* w_dev, const float* bias_dev,
                      const float* resid_dev, void* out_dev, int m, int n, int k, void* stream);
+/* out = epi(LayerNorm(x)[m,:] . w[n,:] + bias[n]) with the LayerNorm fused into the operand load
+ * (row-panel kernel; bf16/fp16, k in {128,384}, n % 128 == 0, n <= 4k); x_dev is fp32 [m,k]. */
+int effocr_op_ln_linear(int precision, int epilogue, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                        float eps, const void* w_dev, const float* bias_dev, const float* resid_dev, void* out_dev,
+                        int m, int n, int k, void* stream);
 int effocr_op_layernorm(int out_precision, const float* x_dev, int64_t rows, int d, const float* gamma_dev,
                         const float* beta_dev, float eps, void* out_dev, void* stream);
 /* qkv_dev [B*T, 3*heads*64] -> out_dev [B*T, heads*64], head_dim fixed at 64 */

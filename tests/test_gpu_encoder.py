@@ -90,6 +90,22 @@ def test_batch_invariance_and_determinism(dev):
         assert torch.equal(enc.forward(x[lo:hi].contiguous()), full[lo:hi])
 
 
+def test_panel_and_streaming_paths_agree(dev):
+    """The row-panel (fused LayerNorm) path and the K-streaming + LayerNorm-kernel path are two
+    implementations of the same arithmetic; both must sit within the bf16 bound of the oracle and
+    within operand-rounding noise of each other."""
+    from effocr_amd.encoders import HipEncoder
+    sd = init_state_dict("vit_small_patch16_224", seed=4, img_size=224)
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    ref = encoder_forward("vit_small_patch16_224", sd, x)
+    enc = HipEncoder("vit_small_patch16_224", sd, precision="bf16", device=dev)
+    a = enc.forward(x.to(dev)).cpu()
+    enc.set_option("use_panel", 0)
+    b = enc.forward(x.to(dev)).cpu()
+    assert rel_err(a, ref) <= REL["bf16"] and rel_err(b, ref) <= REL["bf16"]
+    assert rel_err(a, b) <= REL["bf16"]
+
+
 def test_input_validation(dev):
     from effocr_amd.encoders import HipEncoder
     sd = init_state_dict("vit_tiny_test", seed=2, img_size=64)

@@ -74,6 +74,44 @@ def test_layernorm(hip_lib, dev, prec, D, rows):
     assert err <= tol * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("epi", ["bias", "bias_gelu", "bias_resid"])
+@pytest.mark.parametrize("shape", [(197 * 5, 1152, 384), (300, 384, 384), (129, 1536, 384), (77, 384, 128), (128, 512, 128)])
+def test_ln_linear_fused(hip_lib, dev, prec, epi, shape):
+    """Row-panel kernel with the LayerNorm fused into the operand load vs LN -> round -> linear."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(TDT[prec])
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    xd, gd, bd, wd, bsd = x.to(dev), gamma.to(dev), beta.to(dev), w.to(dev), bias.to(dev)
+    if epi == "bias_resid":
+        out = resid.to(dev).clone()
+        rd = out
+    else:
+        out = torch.full((M, N), float("nan"), dtype=TDT[prec], device=dev)
+        rd = None
+    _lib.check(hip_lib.effocr_op_ln_linear(_lib.PREC[prec], _lib.EPI[epi], _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6,
+                                           _lib.ptr(wd), _lib.ptr(bsd), _lib.ptr(rd), _lib.ptr(out), M, N, K, _stream(dev)),
+               "op_ln_linear")
+    torch.cuda.synchronize()
+    xn = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-6).to(TDT[prec]).double()
+    ref = xn @ w.double().T + bias.double()
+    if epi == "bias_gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if epi == "bias_resid":
+        ref = ref + resid.double()
+    got = out.float().cpu().double()
+    assert torch.isfinite(got).all()
+    # the fused LN rounds its fp32 result to the operand type exactly like the reference expression,
+    # but fp32-vs-fp64 LN arithmetic can flip a rounding: allow a few operand ulps
+    tol = {"bf16": 1.2e-2, "fp16": 1.5e-3}[prec]
+    err = (got - ref).abs().max().item()
+    assert err <= tol * ref.abs().max().item(), f"{prec} {epi} {shape}: err {err:.3e} scale {ref.abs().max().item():.3e}"
+
+
 def attention_ref(qkv, B, T, heads):
     D = heads * 64
     q, k, v = qkv.double().reshape(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
