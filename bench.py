@@ -115,6 +115,8 @@ def main():
     D = enc.embed_dim
     if a.chunk:
         enc.set_chunk(a.chunk)
+    if os.environ.get("EFFOCR_DEBUG"):
+        enc.set_option("debug", int(os.environ["EFFOCR_DEBUG"]))
     if a.no_panel:
         enc.set_option("use_panel", 0)
     gi = torch.Generator().manual_seed(0)

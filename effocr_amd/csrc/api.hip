@@ -54,6 +54,7 @@ struct effocr_encoder {
   const char* wdev = nullptr;       // device blob after upload
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
+  int debug = 0;
   int use_panel = 1;                // 0: force the K-streaming GEMM + standalone LayerNorm path (A/B switch)
   int chunk = 0;                    // crops per internal sub-batch of the ViT forward (0 = whole batch)
   int prof_mode = 0;                // 0 off, 1 every class, 2 only prof_only
@@ -277,7 +278,8 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
 
 struct VitWs { size_t x, xn, qkv, att, h, total; };
 VitWs vit_ws(const effocr_encoder* e, int B) {
-  const size_t M = (size_t)B * e->T, D = e->vit.D, es = prec_esize(e->prec);
+  // rows padded to the panel height (128) so that the row-panel kernels store without bounds checks
+  const size_t M = align_up((size_t)B * e->T, 128), D = e->vit.D, es = prec_esize(e->prec);
   Alloc a; VitWs w;
   w.x = a.take(M * D * 4);
   w.xn = a.take(M * D * es);
@@ -311,16 +313,16 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       // row-panel kernels: LayerNorm fused into the A-panel load, no xn buffer, no LayerNorm launches
       PanelArgs p{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
-      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D;
+      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug;
       if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
-      p.M = M; p.N = D; p.K = D;
+      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug;
       if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
       p = PanelArgs{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
-      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D;
+      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug;
       if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
     } else {
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
@@ -508,6 +510,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (!enc || !name) return fail(EFFOCR_EINVAL, "set_option: NULL argument");
   const std::string n = name;
   if (n == "use_panel") { enc->use_panel = value; return EFFOCR_OK; }
+  if (n == "debug") { enc->debug = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");
 }
@@ -620,6 +623,16 @@ int effocr_op_ln_linear(int precision, int epilogue, const float* x_dev, const f
   PanelArgs p{};
   p.A = x_dev; p.lda = k; p.gamma = gamma_dev; p.beta = beta_dev; p.eps = eps; p.W = w_dev; p.bias = bias_dev;
   p.out = out_dev; p.ldo = n; p.resid = resid_dev; p.ldr = n; p.M = m; p.N = n; p.K = k;
+  return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
+}
+
+// experiment hook: LN-fused linear with an in-kernel timeline buffer (2 x 512 x 4 u64, device)
+int effocr_dbg_ln_linear(int precision, int epilogue, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                         const void* w_dev, const float* bias_dev, void* out_dev, int m, int n, int k, int debug,
+                         unsigned long long* dbg_dev, void* stream) {
+  PanelArgs p{};
+  p.A = x_dev; p.lda = k; p.gamma = gamma_dev; p.beta = beta_dev; p.eps = 1e-6f; p.W = w_dev; p.bias = bias_dev;
+  p.out = out_dev; p.ldo = n; p.M = m; p.N = n; p.K = k; p.debug = debug; p.dbg = dbg_dev;
   return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
 

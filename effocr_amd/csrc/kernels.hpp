@@ -33,6 +33,9 @@ struct PanelArgs {
   void* out; int64_t ldo;
   const float* resid; int64_t ldr;  // EPI_BIAS_RESID (may alias out)
   int M, N, K;
+  unsigned long long* dbg;          // optional timeline buffer (experiments)
+  int debug;                        // experiment switches (bit0: skip epilogue stores)
+  int rows_padded;                  // out / resid buffers are addressable up to the next multiple of 128 rows
 };
 bool panel_gemm_supported(int prec, int N, int K);
 int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);

@@ -10,24 +10,39 @@
 //     (norm1 before attn.qkv, norm2 before mlp.fc1) is fused into that load: fp32 residual stream in,
 //     fp32 statistics, normalised 16-bit operands straight into LDS — the LayerNorm kernel, its
 //     output buffer and one launch per linear disappear;
-//   * W (L2-resident, <= 1.2 MB) streams through a 3-deep LDS ring of [256 n x 32 k] stages filled by
-//     global_load_lds (16 B/lane, no VGPR round trip) issued TWO stages ahead; waits are counted
-//     (s_waitcnt vmcnt(2)) and the workgroup barrier is the raw s_barrier so that the DMA stays in
-//     flight across it.  The ring image is lane-linear, so the bank-conflict swizzle
-//     (16-B chunk ^= (row>>2)&3) is applied to the per-lane SOURCE address and again on the read;
-//   * 8 waves = 2 (token halves) x 4 (64-feature slices) sweep the output in 256-column steps; the
-//     MFMA is issued swapped (A-operand = W rows) like gemm.hip, so the epilogue code is shared.
-// LDS: 128 x (2K+16) + 3 x 16 KB = 146 KB at K = 384  ->  one workgroup (2 waves/SIMD) per CU.
+//   * W (L2-resident, <= 1.2 MB) streams through a 3-deep LDS ring of [128 n x 64 k] stages (full
+//     128-byte rows) filled by global_load_lds (16 B/lane, no VGPR round trip) issued two stages ahead;
+//     waits are counted (s_waitcnt vmcnt(N), N exact in the presence of the epilogue stores that
+//     share the in-order VM counter) and the workgroup barrier is the raw s_barrier so the DMA stays
+//     in flight across it.  The ring image is lane-linear, so the bank-conflict swizzle
+//     (16-B chunk ^= (row>>1)&7) is applied to the per-lane SOURCE address and again on the read;
+//   * 8 waves = 2 (token halves) x 4 (32-feature slices) sweep the output in 128-column steps (every
+//     layer width is a multiple of 128: no partial steps).  A wave tile is 64 tokens x 32 features:
+//     32 accumulator registers — small on purpose, rocprof/s_memtime showed the 64x64 variant living
+//     on the register cliff (spills share the VM counter with the W DMA and drain it every stage);
+//   * the MFMA is issued swapped (A-operand = W rows) like gemm.hip: a lane owns 4 consecutive
+//     features of one token;
+//   * the epilogue of sweep step t is DEFERRED into the stages of step t+1: at the step boundary the
+//     accumulators (+bias) are parked as packed 16-bit values, and every following stage stores — or,
+//     for mlp.fc1, unpacks/GELUs/packs/stores — two parked groups, hand-sliced between that stage's 8
+//     MFMAs so that the VALU work issues in the MFMA shadow (s_memtime timeline before: stage body
+//     1400-1700 cycles with the epilogue behind the MFMAs, 500-900 without).
+// LDS: 128 x (2K+16) + 3 x 16 KB + 4K x 4 (bias) = 152 KB at K = 384 -> one workgroup (2 waves/SIMD) per CU.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "ln.hpp"
+#include <type_traits>
+
+#ifndef EFFOCR_EXP
+#define EFFOCR_EXP 0     // compile-time ablation switches for timing experiments (0 = product)
+#endif
 
 namespace effocr {
 namespace {
 
 constexpr int PBM = 128;            // token rows per panel
-constexpr int PNT = 256;            // output columns per sweep step
-constexpr int WSTAGE = PNT * 64;    // bytes per ring stage: 256 rows x 32 elements x 2 B
+constexpr int PNT = 128;            // output columns per sweep step
+constexpr int WSTAGE = PNT * 128;   // bytes per ring stage: 128 rows x 64 elements x 2 B
 constexpr int RING = 3;
 
 template <typename TO> __device__ __forceinline__ void pstore4(TO* p, float a, float b, float c, float d) {
@@ -43,11 +58,21 @@ template <int KD> struct LnShape;                       // LayerNorm lane layout
 template <> struct LnShape<384> { static constexpr int G = 32, V = 3; };
 template <> struct LnShape<128> { static constexpr int G = 32, V = 1; };
 
-template <typename E, int KD, int PRO, int EPI, typename TO>
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// FULL: every output / residual row index of a panel is addressable (M % 128 == 0, or the buffers
+// carry padding rows up to the next multiple of 128) -> branch-free stores.
+template <typename E, int KD, int PRO, int EPI, typename TO, bool FULL>
 __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
   constexpr int APITCH = KD * 2 + 16;                    // bytes per A-panel row (+16: conflict-free b128 reads)
-  constexpr int NKS = KD / 32;                           // ring stages per 256-column sweep step
+  constexpr int NKS = KD / 64;                           // ring stages per 128-column sweep step
   constexpr int NMAX = 4 * KD;                           // widest layer on this path: mlp.fc1
+  constexpr int NG = 8;                                  // epilogue groups per wave per step (2 token tiles x 4)
   __shared__ __attribute__((aligned(16))) char smem[PBM * APITCH + RING * WSTAGE + NMAX * 4];
   char* sA = smem;
   char* sW = smem + PBM * APITCH;
@@ -58,30 +83,35 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int wv = wave_id(), wn = wv >> 1, wm = wv & 1;
   const int m0 = blockIdx.x * PBM;
-  const int niter = (a.N + PNT - 1) / PNT;
+  const int niter = a.N / PNT;
   const int S = niter * NKS;
   const char* Wb = static_cast<const char*>(a.W);
 
-  // ---- W ring fill: stage s = (sweep step it, k-stage ks); 2 x 1 KB DMA pieces per wave per stage
-  auto issue_w = [&](int s) {
+  // ---- W ring fill: stage s = (sweep step it, k-stage ks); 2 x 1 KB DMA pieces (8 rows) per wave
+  uint32_t wsrc[2];                                      // per-lane source offset inside a stage's W block
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = (wv * 2 + i) * 64 + lane;
+    const int row = p >> 3;
+    wsrc[i] = (uint32_t)(row * KD * 2 + (((p & 7) ^ ((row >> 1) & 7)) * 16));
+  }
+  auto issue_w = [&](int s, int slot) {
     if (s >= S) return;
     const int it = s / NKS, ks = s - it * NKS;
-    char* dst = sW + (s % RING) * WSTAGE;
+    const char* src = Wb + ((size_t)it * PNT * KD + ks * 64) * 2;
+    char* dst = sW + slot * WSTAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p0 = (wv * 2 + i) * 64;
-      const int p = p0 + lane;
-      const int row = p >> 2;
-      const int ch = (p & 3) ^ ((row >> 2) & 3);
-      int n = it * PNT + row;
-      n = n < a.N ? n : a.N - 1;
-      const char* g = Wb + ((size_t)n * KD + ks * 32) * 2 + ch * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(dst + p0 * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wsrc[i]),
+                                       (__attribute__((address_space(3))) void*)(dst + (wv * 2 + i) * 1024), 16, 0, 0);
   };
-  issue_w(0);
-  issue_w(1);
+#if EFFOCR_EXP == 9
+  const bool stamp = (a.dbg != nullptr) && (blockIdx.x == 300 || blockIdx.x == 1300) && lane == 0 && (wv == 0 || wv == 5);
+  unsigned long long* dbgw = a.dbg + ((blockIdx.x == 300 ? 0 : 2) + (wv == 0 ? 0 : 1)) * 2048;
+  if (stamp) dbgw[2040] = __builtin_amdgcn_s_memtime();
+#endif
+  issue_w(0, 0);
+  issue_w(1, 1);
   for (int n = tid; n < a.N; n += 512) sBias[n] = a.bias[n];
 
   // ---- A panel
@@ -127,123 +157,260 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
       *reinterpret_cast<u32x4*>(sA + row * APITCH + c * 16) = v[i];
     }
   }
+#if EFFOCR_EXP == 9
+  if (stamp) dbgw[2041] = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();                                       // panel visible; also drains stages 0,1 (prologue only)
+#if EFFOCR_EXP == 9
+  if (stamp) dbgw[2042] = __builtin_amdgcn_s_memtime();
+#endif
+  issue_w(2, 2);
 
-  f32x16 acc[2][2];
+  constexpr bool DEFER = (EPI != EPI_BIAS_RESID);        // residual loads would stall the W stream: see below
+  constexpr int EPG = (NG + NKS - 1) / NKS < 2 ? 2 : (NG + NKS - 1) / NKS;   // deferred groups per stage
+  static_assert(NKS * EPG >= NG && NKS % 2 == 0, "panel geometry");
+  f32x16 acc[2];                                         // [token tile]: 32 features x 32 tokens each
+  u32x2 donep[NG];                                       // parked step: bias added, packed to E (group = 4 values)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { donep[g][0] = 0u; donep[g][1] = 0u; }
+
+  const int sw = (r31 >> 1) & 7;
+  const char* pa = sA + (wm * 64 + r31) * APITCH + half * 16;
+  const int wrow = (wn * 32 + r31) * 128;
+  TO* out = static_cast<TO*>(a.out);
+  int mrow[2];
+  bool mok[2];
+  uint32_t prow[2];                                      // byte offset of this lane's two output rows at its first column
+#pragma unroll                                           // (uniform base + 32-bit offset: launcher guarantees < 4 GB)
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + r31;
+    mok[j] = FULL || m < a.M;
+    mrow[j] = mok[j] ? m : a.M - 1;
+    prow[j] = (uint32_t)(((int64_t)mrow[j] * a.ldo + wn * 32 + 4 * half) * (int64_t)sizeof(TO));
+  }
+
+  // MFMA operand fragments.  W rows are the A-operand, tokens the B-operand.  W fragments of a whole
+  // stage (4 k16 steps) are fetched one stage ahead (that frees the ring slot at the next barrier);
+  // the token fragments come from the resident panel and are pipelined one k16 step ahead.
+  struct WFrags { V8 w[4]; };
+  auto load_w = [&](WFrags& f, int slot) {
+    const char* pw = sW + slot * WSTAGE + wrow;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) f.w[c4] = *reinterpret_cast<const V8*>(pw + (((2 * c4 + half) ^ sw) * 16));
+  };
+  auto load_x = [&](V8 (&x)[2], int k16) {               // k16 = k16-step index within K
+#pragma unroll
+    for (int j = 0; j < 2; ++j) x[j] = *reinterpret_cast<const V8*>(pa + j * 32 * APITCH + k16 * 32);
+  };
+
+  // group g = (token tile j = g>>2, feature quad q = g&3): 4 consecutive features of one token
+  auto group_ptr = [&](int g, int n0) -> TO* {
+    const int j = g >> 2, q = g & 3;
+    return reinterpret_cast<TO*>(reinterpret_cast<char*>(out) + (prow[j] + (uint32_t)((n0 + 8 * q) * (int)sizeof(TO))));
+  };
+  auto store_group = [&](int g, int n0, u32x2 v) {
+    TO* p = group_ptr(g, n0);
+#if EFFOCR_EXP == 5
+    if (v[0] != 0x12345678u) return;
+#endif
+    if constexpr (FULL) *reinterpret_cast<u32x2*>(p) = v;
+    else if (mok[g >> 2]) *reinterpret_cast<u32x2*>(p) = v;
+  };
+  // immediate epilogue straight from the fp32 accumulators (residual path, and the last sweep step)
+  auto epi_now = [&](int n0) {
+    float v[NG * 4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int j = g >> 2, q = g & 3;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + n0 + wn * 32 + 8 * q + 4 * half);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g * 4 + e] = acc[j][4 * q + e] + bv[e];
+    }
+    if constexpr (EPI == EPI_BIAS_GELU) gelu_erf_fast_n<NG * 4>(v);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      TO* p = group_ptr(g, n0);
+      if constexpr (FULL) pstore4<TO>(p, v[g * 4], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]);
+      else if (mok[g >> 2]) pstore4<TO>(p, v[g * 4], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]);
+    }
+  };
+  // sweep-step boundary: acc + bias -> packed E (half the registers of an fp32 copy), acc = 0.
+  // (mlp.fc1: GELU therefore sees its argument rounded to the operand type first; its result is
+  // rounded to the same type anyway, so the extra error stays below one output ulp.)
+  auto park = [&](int n0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int j = g >> 2, q = g & 3;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + n0 + wn * 32 + 8 * q + 4 * half);
+      donep[g] = pack4<E>(acc[j][4 * q] + bv[0], acc[j][4 * q + 1] + bv[1], acc[j][4 * q + 2] + bv[2], acc[j][4 * q + 3] + bv[3]);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  };
 
-  const int sw = (r31 >> 2) & 3;
-  const char* pa = sA + (wm * 64 + r31) * APITCH + half * 16;
-  TO* out = static_cast<TO*>(a.out);
-  int it = 0, ks = 0;
-  for (int s = 0; s < S; ++s) {
-    // stage s has landed for this wave's own DMA pieces (one newer stage may stay in flight) ...
-    if (s + 1 < S) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ... and, past the barrier, for everybody's; all reads of ring slot (s+2)%3 (stage s-1) are done too
+  WFrags wa, wb;
+  V8 x0[2], x1[2];
+  load_w(wa, 0);
+  load_x(x0, 0);
+  int s = 0, slot = 0;                                   // ring slot of stage s
+  int pend_n0 = 0;
+
+  // deferred-epilogue stores issued at stage position k of a steady-state sweep step (FULL only)
+  auto stores_at = [](int k) constexpr { k = (k % NKS + NKS) % NKS; const int lo = k * EPG; return lo >= NG ? 0 : (lo + EPG > NG ? NG - lo : EPG); };
+
+  // One ring stage.  Top: stage s+1 has landed for this wave's own DMA pieces (stage s+2 may stay in
+  // flight — the VM counter is in order and also counts the deferred stores issued since, hence the
+  // exact per-position count); past the barrier for everybody's, and every wave has finished reading
+  // slot(s) (its W fragments were fetched a stage ago) so that slot takes stage s+3.
+  auto stage = [&](auto KS, auto WITH_EPI, bool steady) {
+    constexpr int ks = decltype(KS)::value;
+    constexpr bool with_epi = decltype(WITH_EPI)::value;
+    constexpr int extra = (FULL && DEFER && with_epi) ? stores_at(ks - 1) + stores_at(ks - 2) : 0;
+#if EFFOCR_EXP == 9
+    if (stamp) dbgw[s * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
+    if (s + 2 >= S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (extra > 0 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + extra) : "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#if EFFOCR_EXP == 9
+    if (stamp) dbgw[s * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
+#if EFFOCR_EXP != 3
     __builtin_amdgcn_s_barrier();
+#endif
+#if EFFOCR_EXP == 9
+    if (stamp) dbgw[s * 4 + 2] = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("" ::: "memory");
-    issue_w(s + 2);
-
-    const int n0 = it * PNT;
-    const bool active = (n0 + wn * 64) < a.N;            // wave-uniform: partial last sweep step
-    if (active) {
-      const char* pw = sW + (s % RING) * WSTAGE + (wn * 64 + r31) * 64;
+#if EFFOCR_EXP != 4
+    issue_w(s + 3, slot);
+#endif
+    const int nslot = (slot + 1 == RING) ? 0 : slot + 1;
+    WFrags& cur = (ks & 1) ? wb : wa;
+    WFrags& nxt = (ks & 1) ? wa : wb;
+#if EFFOCR_EXP != 1
+    load_w(nxt, nslot);                                  // stage s+1 (garbage after the last stage: never consumed)
+#endif
+    // MFMA n of the stage = (k16 step c4 = n>>1, token tile j = n&1); token fragments ping-pong between
+    // x0 (even steps) and x1 (odd steps), each fetched while the other one is being consumed
+    auto mma1 = [&](int n) {
+      const int c4 = n >> 1, j = n & 1;
+      if (j == 0) {
+        const int nk = (c4 == 3) ? ((ks + 1) % NKS) * 4 : ks * 4 + c4 + 1;     // next k16 step (wraps into next stage)
+#if EFFOCR_EXP != 1
+        if (c4 & 1) load_x(x0, nk); else load_x(x1, nk);
+#endif
+      }
+#if EFFOCR_EXP == 2
+      acc[j][n] += (float)cur.w[c4][0] * (float)((c4 & 1) ? x1[j] : x0[j])[0];
+#else
+      acc[j] = Op16<E>::mfma(cur.w[c4], (c4 & 1) ? x1[j] : x0[j], acc[j]);
+#endif
+    };
+    constexpr int g0 = ks * EPG;
+    constexpr int ng = (g0 >= NG) ? 0 : (g0 + EPG > NG ? NG - g0 : EPG);
+    if constexpr (DEFER && with_epi && ng > 0 && EPI == EPI_BIAS_GELU) {
+      // Deferred GELU of `ng` parked groups (NE elements), hand-sliced between the stage's 8 MFMAs:
+      // every slice is a handful of independent (packed) VALU ops that issue in the 32-cycle shadow
+      // of the MFMA in front of it.  sched_barrier(0) pins the interleave (no instruction is emitted).
+      constexpr int NE = ng * 4;
+      typedef __attribute__((__vector_size__(4 * sizeof(E)))) E E4;
+      constexpr float c[7] = {4.1060451e-05f, -0.00051103633f, 0.00423542528f, -0.0251028568f, 0.111079332f, -0.375314877f, 1.12826843f};
+      float x[NE], z[NE], t[NE], p[NE];
+      mma1(0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        V8 wf[2], xf[2];
+      for (int gg = 0; gg < ng; ++gg) {
+        const E4 h = __builtin_bit_cast(E4, donep[g0 + gg]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          wf[i] = *reinterpret_cast<const V8*>(pw + i * 32 * 64 + (((2 * s2 + half) ^ sw) * 16));
-          xf[i] = *reinterpret_cast<const V8*>(pa + i * 32 * APITCH + (ks * 2 + s2) * 32);
+        for (int e = 0; e < 4; ++e) x[gg * 4 + e] = (float)h[e];
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) z[e] = __builtin_amdgcn_fmed3f(x[e] * 0.70710678118654752440f, -3.0f, 3.0f);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) { t[e] = z[e] * z[e]; p[e] = fmaf(4.07419588e-08f, t[e], -1.94481757e-06f); }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) p[e] = fmaf(p[e], t[e], c[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 1; k < 7; ++k) {
+        mma1(1 + k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) p[e] = fmaf(p[e], t[e], c[k]);
+        if (k == 6) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) { const float h = 0.5f * x[e]; x[e] = fmaf(z[e] * p[e], h, h); }
+#pragma unroll
+          for (int gg = 0; gg < ng; ++gg) store_group(g0 + gg, pend_n0, pack4<E>(x[gg * 4], x[gg * 4 + 1], x[gg * 4 + 2], x[gg * 4 + 3]));
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int n = 0; n < 8; ++n) mma1(n);
+      if constexpr (DEFER && with_epi && ng > 0) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Op16<E>::mfma(wf[i], xf[j], acc[i][j]);
+        for (int gg = 0; gg < ng; ++gg) store_group(g0 + gg, pend_n0, donep[g0 + gg]);
       }
     }
+#if EFFOCR_EXP == 9
+    if (stamp) { asm volatile("s_nop 0" ::: "memory"); dbgw[s * 4 + 3] = __builtin_amdgcn_s_memtime(); }
+#endif
+    ++s;
+    slot = nslot;
+  };
 
-    if (ks == NKS - 1) {
-      if (active) {
-        // phase 1: every load (bias from LDS, residual rows from global) before the first store, so
-        // that possibly-aliasing stores (in-place residual) cannot serialise them
-        f32x4 bv[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            bv[i][q] = *reinterpret_cast<const f32x4*>(sBias + n0 + wn * 64 + i * 32 + 8 * q + 4 * half);
-        int mrow[2];
-        bool mok[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int m = m0 + wm * 64 + j * 32 + r31;
-          mok[j] = m < a.M;
-          mrow[j] = mok[j] ? m : a.M - 1;
-        }
-        if constexpr (EPI == EPI_BIAS_RESID) {
-          f32x4 rv[2][2][4];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                rv[i][j][q] = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)mrow[j] * a.ldr + n0 + wn * 64 + i * 32 + 8 * q + 4 * half);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[i][j][q][e];
-        }
-        // phase 2: bias (+GELU) and stores
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (mok[j]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
-                float v0 = acc[i][j][4 * q + 0] + bv[i][q][0];
-                float v1 = acc[i][j][4 * q + 1] + bv[i][q][1];
-                float v2 = acc[i][j][4 * q + 2] + bv[i][q][2];
-                float v3 = acc[i][j][4 * q + 3] + bv[i][q][3];
-                if constexpr (EPI == EPI_BIAS_GELU) {
-                  v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
-                }
-                pstore4<TO>(out + (int64_t)mrow[j] * a.ldo + n, v0, v1, v2, v3);
-              }
-            }
-          }
-        }
+  for (int it = 0; it < niter; ++it) {
+    const int n0 = it * PNT + wn * 32;                   // first column of this wave's 32-feature slice
+    if (it == 0) static_for<0, NKS>([&](auto KS) { stage(KS, std::false_type{}, false); });
+    else static_for<0, NKS>([&](auto KS) { stage(KS, std::true_type{}, it >= 2); });
+    if constexpr (DEFER) {
+      if (it == niter - 1) {
+        epi_now(it * PNT);
+      } else {
+        park(it * PNT);
+        pend_n0 = it * PNT;
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      ks = 0; ++it;
     } else {
-      ++ks;
+      // residual epilogue (proj): global loads inside the pipelined loop would share the in-order VM
+      // counter with the W DMA, so it stays a plain load-all / store-all block at the step boundary
+      f32x4 rv[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[j][q] = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)mrow[j] * a.ldr + n0 + 8 * q + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[j][4 * q + e] += rv[j][q][e];
+      epi_now(it * PNT);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     }
   }
+#if EFFOCR_EXP == 9
+  if (stamp) dbgw[2043] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
-template <typename E, int KD>
+template <typename E, int KD, bool FULL>
 int launch_panel(int pro, int epi, const PanelArgs& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.M + PBM - 1) / PBM)), blk(512);
-#define EFFOCR_PANEL(P, EP, TOUT) hipLaunchKernelGGL((panel_gemm_kernel<E, KD, P, EP, TOUT>), grid, blk, 0, s, a)
+#define EFFOCR_PANEL(P, EP, TOUT) hipLaunchKernelGGL((panel_gemm_kernel<E, KD, P, EP, TOUT, FULL>), grid, blk, 0, s, a)
   if (pro == PRO_LN) {
     switch (epi) {
       case EPI_BIAS: EFFOCR_PANEL(PRO_LN, EPI_BIAS, E); break;
@@ -263,6 +430,12 @@ int launch_panel(int pro, int epi, const PanelArgs& a, hipStream_t s) {
   return check_launch("panel_gemm");
 }
 
+template <typename E, int KD>
+int launch_panel_full(int pro, int epi, const PanelArgs& a, hipStream_t s) {
+  const bool full = (a.M % PBM == 0) || a.rows_padded;
+  return full ? launch_panel<E, KD, true>(pro, epi, a, s) : launch_panel<E, KD, false>(pro, epi, a, s);
+}
+
 }  // namespace
 
 bool panel_gemm_supported(int prec, int N, int K) {
@@ -273,8 +446,9 @@ int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s) {
   if (a.M <= 0) return EFFOCR_OK;
   if (!panel_gemm_supported(prec, a.N, a.K)) return fail(EFFOCR_EUNSUPPORTED, "panel_gemm: needs bf16/fp16, K in {128,384}, N % 128 == 0, N <= 4K");
   if (pro == PRO_COPY && (a.lda % 8) != 0) return fail(EFFOCR_EINVAL, "panel_gemm: A rows must be 16-byte aligned");
-  if (prec == PREC_BF16) return a.K == 384 ? launch_panel<__bf16, 384>(pro, epi, a, s) : launch_panel<__bf16, 128>(pro, epi, a, s);
-  return a.K == 384 ? launch_panel<_Float16, 384>(pro, epi, a, s) : launch_panel<_Float16, 128>(pro, epi, a, s);
+  if ((int64_t)(a.M + PBM) * a.ldo * 4 >= ((int64_t)1 << 32)) return fail(EFFOCR_EUNSUPPORTED, "panel_gemm: output larger than 4 GB");
+  if (prec == PREC_BF16) return a.K == 384 ? launch_panel_full<__bf16, 384>(pro, epi, a, s) : launch_panel_full<__bf16, 128>(pro, epi, a, s);
+  return a.K == 384 ? launch_panel_full<_Float16, 384>(pro, epi, a, s) : launch_panel_full<_Float16, 128>(pro, epi, a, s);
 }
 
 }  // namespace effocr
