@@ -1,0 +1,85 @@
+"""-m "not gpu": libeffocr_hip.so loads, exports every function include/effocr_hip.h declares, and
+its host-side logic (parameter tables, sizes, argument checking, error strings) works without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from effocr_amd import _lib
+from effocr_amd.weights import param_shapes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "effocr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(effocr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(hip_lib):
+    names = declared_functions()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(_lib.SO_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in effocr_hip.h but not exported"
+    assert set(_lib.EXPORTS) <= set(names) | {"effocr_dbg_ln_linear"}
+    assert hip_lib.effocr_abi_version() == 1
+
+
+@pytest.mark.parametrize("arch,img,D", [("vit_small_patch16_224", 224, 384), ("vit_base_patch16_224", 224, 768),
+                                        ("resnet18", 32, 512), ("vit_tiny_test", 64, 128)])
+def test_encoder_handle_param_table(hip_lib, arch, img, D):
+    L = hip_lib
+    h = ctypes.c_void_p()
+    assert L.effocr_encoder_create(arch.encode(), img, 0, ctypes.byref(h)) == 0
+    try:
+        assert L.effocr_encoder_embed_dim(h) == D
+        want = param_shapes(arch, img)
+        n = L.effocr_encoder_num_params(h)
+        got = {L.effocr_encoder_param_name(h, i).decode(): L.effocr_encoder_param_numel(h, i) for i in range(n)}
+        assert list(got) == list(want)                                   # same names, same order as the timm state dict
+        for k, shp in want.items():
+            numel = 1
+            for d in shp:
+                numel *= d
+            assert got[k] == numel
+        assert L.effocr_encoder_weights_bytes(h) > 0
+        w1, w8 = L.effocr_encoder_workspace_bytes(h, 1), L.effocr_encoder_workspace_bytes(h, 8)
+        assert 0 < w1 < w8
+        # call-order and argument errors are reported, not crashed on
+        assert L.effocr_encoder_set_param(h, b"no.such.param", None, 0) == -1
+        import numpy as np
+        buf = np.zeros(3, np.float32)
+        assert L.effocr_encoder_set_param(h, b"norm.weight" if "vit" in arch else b"bn1.weight",
+                                          buf.ctypes.data_as(ctypes.c_void_p), 3) == -1
+        assert b"expects" in L.effocr_last_error()
+        assert L.effocr_encoder_upload(h, ctypes.c_void_p(16), 1 << 40) == -5      # parameters never set
+        assert L.effocr_encoder_forward(h, ctypes.c_void_p(16), 1, ctypes.c_void_p(16), 0, ctypes.c_void_p(16), 1 << 40, None) == -5
+    finally:
+        L.effocr_encoder_destroy(h)
+
+
+def test_create_rejects_bad_requests(hip_lib):
+    h = ctypes.c_void_p()
+    assert hip_lib.effocr_encoder_create(b"xcit_small_12_p8_224", 224, 0, ctypes.byref(h)) == -2
+    assert b"unsupported architecture" in hip_lib.effocr_last_error()
+    assert hip_lib.effocr_encoder_create(b"vit_small_patch16_224", 100, 0, ctypes.byref(h)) == -1
+    assert hip_lib.effocr_encoder_create(b"vit_small_patch16_224", 160, 0, ctypes.byref(h)) == -2    # 101 tokens: no attention kernel
+    assert hip_lib.effocr_encoder_create(b"vit_small_patch16_224", 224, 7, ctypes.byref(h)) == -1
+    assert hip_lib.effocr_encoder_create(None, 224, 0, ctypes.byref(h)) == -1
+
+
+def test_knn_workspace_and_argument_checks(hip_lib):
+    L = hip_lib
+    assert L.effocr_knn_workspace_bytes(1024, 10000, 384, 10) >= 40 * 1024 * 16 * 8
+    assert L.effocr_knn_workspace_bytes(64, 96, 512, 10) <= 512                 # single chunk: no partial lists
+    assert L.effocr_knn_workspace_bytes(0, 100, 64, 1) == 0
+    p = ctypes.c_void_p(16)
+    assert L.effocr_knn_ip_topk(p, 4, p, 10, 384, 33, p, p, p, 1 << 30, None) == -2     # k > 32
+    assert L.effocr_knn_ip_topk(p, 4, p, 10, 100, 5, p, p, p, 1 << 30, None) == -2      # d % 32 != 0
+    assert L.effocr_knn_ip_topk(p, 4, p, 10, 384, 0, p, p, p, 1 << 30, None) == -1
+    assert L.effocr_knn_ip_topk(p, 1024, p, 10000, 384, 10, p, p, p, 16, None) == -3    # workspace too small
+    assert L.effocr_knn_ip_topk(None, 4, p, 10, 384, 5, p, p, p, 1 << 30, None) == -1
+    assert L.effocr_knn_ip_topk(p, 0, p, 10, 384, 5, p, p, p, 0, None) == 0            # empty query batch is a no-op

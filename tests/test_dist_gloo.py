@@ -1,0 +1,65 @@
+"""-m "not gpu": the N>1 path (crop sharding + all_gather of the per-rank ids) on 2 CPU processes
+with the gloo backend; the per-rank neighbour function is the CPU oracle here."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from effocr_amd.dist import ShardedRecognizer, shard_bounds
+        from oracle import knn_ref
+        rng = np.random.default_rng(0)
+        X = rng.standard_normal((300, 64)).astype(np.float32)
+        Q = rng.standard_normal((n, 64)).astype(np.float32)
+
+        def neighbors(local):                      # stands in for Recognizer.neighbors on this rank's GPU
+            d, i = knn_ref.flat_ip_search(local.numpy(), X, 5)
+            return torch.from_numpy(d), torch.from_numpy(i)
+
+        sharded = ShardedRecognizer(neighbors)
+        d, i = sharded(torch.from_numpy(Q))
+        lo, hi = shard_bounds(n, rank, world)
+        d2, i2 = sharded(torch.from_numpy(Q[lo:hi]), n_total=n, presharded=True)
+        assert torch.equal(i, i2) and torch.equal(d, d2)
+        np.save(os.path.join(out_dir, f"i{rank}.npy"), i.numpy())
+        np.save(os.path.join(out_dir, f"d{rank}.npy"), d.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 33, 1])
+def test_sharded_recognizer_world_size_2(tmp_path, n):
+    from oracle import knn_ref
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((300, 64)).astype(np.float32)
+    Q = rng.standard_normal((n, 64)).astype(np.float32)
+    d_ref, i_ref = knn_ref.flat_ip_search(Q, X, 5)
+    for r in range(world):                                   # every rank holds the full, correctly ordered result
+        assert np.array_equal(np.load(tmp_path / f"i{r}.npy"), i_ref)
+        assert np.array_equal(np.load(tmp_path / f"d{r}.npy"), d_ref)
+
+
+def test_single_process_passthrough():
+    from effocr_amd.dist import ShardedRecognizer, all_gather_rows
+    t = torch.arange(12).reshape(4, 3)
+    assert all_gather_rows(t, 4) is t
+    d, i = ShardedRecognizer(lambda x: (x.float(), x))(t)
+    assert torch.equal(i, t)
