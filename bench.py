@@ -32,6 +32,20 @@ MFMA_PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}      # dense, MI3
 FLOP_PER_CROP = {"vit_small_patch16_224": 9.197e9, "vit_base_patch16_224": 35.13e9}
 
 
+def measured_traffic(kernel_class):
+    """HBM bytes per launch of ``kernel_class`` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes) or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel_class)
+        return None if k is None else float(k["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,7 +206,7 @@ def main():
             line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(fl / sec / 1e12, 2),
                                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(fl / sec / peak, 4),
                                 "flops_per_launch": fl, "avg_launch_us": round(sec * 1e6, 2), "launches": p["launches"],
-                                "traffic": None}
+                                "traffic": measured_traffic(dom) if (a.arch == "vit_small_patch16_224" and a.batch == 1024) else None}
         if a.arch in FLOP_PER_CROP:
             line["encoder_mfma_frac_end_to_end"] = round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)
         if world == 1 and not a.no_cpu_baseline:

@@ -1,34 +1,85 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 rocpd databases (kernel stats + PMC counters per kernel) as text."""
-import re, sqlite3, sys
+"""Summarise rocprofv3 rocpd databases (gpurun_out/prof_<tag>/) into text files under profiles/.
 
-def short(n):
-    n = re.sub(r"effocr::\(anonymous namespace\)::", "", n)
-    n = re.sub(r"void ", "", n)
-    return n[:95]
+usage: python tools_rocpd.py <tag>        e.g. r01  -> profiles/r01_kernel_stats.txt, r01_pmc.txt, r01_traffic.json
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced read stream
+(MI355X_MICROARCH.md, HBM section), so reads = 2 * FETCH_SIZE * 1024 bytes.
+"""
+import json, os, re, sqlite3, sys
 
-def stats(db):
+CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
+    ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
+    ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm_nt_kernelIDF16bLi2", "gemm_fc2_resid"),
+    ("gemm_nt_kernelIDF16bLi3", "gemm_patch_embed"), ("attn_mfma_kernel", "attention"), ("knn_partial", "knn_partial"),
+    ("knn_merge", "knn_merge"), ("im2col16", "im2col_patch16"), ("cls_norm", "final_cls_norm"), ("layernorm_kernel", "layernorm"),
+]
+
+def cls(name):
+    for sub, c in CLASSES:
+        if sub in name:
+            return c
+    if "gemm_nt_kernel<" in name:
+        return "gemm_fc2_resid"       # the only demangled gemm_nt instantiation on the bf16 ViT-S path
+    return re.sub(r"_ZN6effocr12_GLOBAL__N_1\d*", "", name)[:48]
+
+def stats(db, out):
     c = sqlite3.connect(db)
     rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
     tot = sum(r[2] for r in rows)
-    print(f"{'kernel':95s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
+    out.write(f"{'class':20s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}  kernel symbol\n")
     for n, cnt, s, a, mn, mx in rows:
-        print(f"{short(n):95s} {cnt:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}")
+        out.write(f"{cls(n):20s} {cnt:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}  {n[:110]}\n")
 
-def pmc(db):
+def pmc_by_kernel(db):
     c = sqlite3.connect(db)
-    cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
-    namecol = "kernel_name" if "kernel_name" in cols else "name"
-    rows = c.execute(f"select {namecol}, counter_name, count(*), avg(value), sum(value) from counters_collection group by {namecol}, counter_name").fetchall()
+    rows = c.execute("select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection group by kernel_name, counter_name, dispatch_id").fetchall()
     by = {}
-    for n, cn, cnt, avg, sm in rows:
-        by.setdefault(n, {})[cn] = (cnt, avg)
-    ctrs = sorted({cn for v in by.values() for cn in v})
-    print("per-dispatch averages")
-    print(f"{'kernel':70s} " + " ".join(f"{c[:18]:>18s}" for c in ctrs))
-    for n, v in sorted(by.items(), key=lambda kv: -max(x[1] for x in kv[1].values())):
-        print(f"{short(n)[:70]:70s} " + " ".join(f"{v.get(c,(0,0))[1]:18.4g}" for c in ctrs))
+    for n, cn, did, v in rows:
+        by.setdefault(cls(n), {}).setdefault(cn, []).append(v)
+    return {k: {cn: sum(v) / len(v) for cn, v in d.items()} for k, d in by.items()}
+
+def main(tag):
+    src = f"gpurun_out/prof_{tag}"
+    os.makedirs("profiles", exist_ok=True)
+    with open(f"profiles/{tag}_kernel_stats.txt", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (1x MI355X, tag {tag})\n")
+        f.write("# durations from the rocpd 'kernels' view; 5 timed + 2 warm-up + 1 profiled step => 8 forwards x 12 blocks = 96 launches per block kernel\n")
+        stats(f"{src}/stats/stats_results.db", f)
+    allc = {}
+    for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
+        db = f"{src}/{p}/{p}_results.db"
+        if os.path.exists(db):
+            for k, d in pmc_by_kernel(db).items():
+                allc.setdefault(k, {}).update(d)
+    ctrs = sorted({c for d in allc.values() for c in d})
+    with open(f"profiles/{tag}_pmc.txt", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc <set> (one pass per set, no other trace domain), per-dispatch averages, tag {tag}\n")
+        f.write("# SQ_* cycle counters are quad-cycles summed over waves/SEs; SQ_VALU_MFMA_BUSY_CYCLES = 32 x N_mfma; FETCH/WRITE_SIZE in KB\n")
+        for k, d in sorted(allc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+            if not any(s in k for s in ("panel", "gemm", "attention", "knn_partial")):
+                continue
+            f.write(f"\n[{k}]\n")
+            for c in ctrs:
+                if c in d:
+                    f.write(f"  {c:28s} {d[c]:16.6g}\n")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_INSTS_MFMA" in d and d["SQ_INSTS_MFMA"]:
+                f.write(f"  {'valu_per_mfma':28s} {d.get('SQ_INSTS_VALU', 0) / d['SQ_INSTS_MFMA']:16.2f}\n")
+            if "SQ_WAIT_ANY" in d and d.get("SQ_WAVE_CYCLES"):
+                f.write(f"  {'wait_any_frac':28s} {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:16.3f}\n")
+                f.write(f"  {'wait_inst_any_frac':28s} {d['SQ_WAIT_INST_ANY'] / d['SQ_WAVE_CYCLES']:16.3f}\n")
+    traffic = {}
+    for k, d in allc.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            traffic[k] = {"read_bytes": 2 * d["FETCH_SIZE"] * 1024, "write_bytes": d["WRITE_SIZE"] * 1024,
+                          "hbm_bytes_per_launch": 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024}
+    with open(f"profiles/{tag}_traffic.json", "w") as f:
+        json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md)",
+                   "kernels": traffic}, f, indent=1)
+    for fn in ("bench.json", "bench_breakdown.txt"):
+        if os.path.exists(f"{src}/{fn}"):
+            txt = open(f"{src}/{fn}").read()
+            open(f"profiles/{tag}_{fn}", "w").write("\n".join(l for l in txt.splitlines() if "amdgpu.ids" not in l) + "\n")
+    print(open(f"profiles/{tag}_kernel_stats.txt").read())
 
 if __name__ == "__main__":
-    mode, db = sys.argv[1], sys.argv[2]
-    (stats if mode == "stats" else pmc)(db)
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
