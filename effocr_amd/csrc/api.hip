@@ -55,6 +55,9 @@ struct effocr_encoder {
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
+  int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
+  int panel_impl = 0;               // 0: LDS-panel panel.hip (default, faster), 1: token-stationary panelr.hip (experiment)
+  int panel_rows = 128;             // row-panel height: 128 (1 workgroup/CU) or 64 (2 workgroups/CU)
   int use_panel = 1;                // 0: force the K-streaming GEMM + standalone LayerNorm path (A/B switch)
   int chunk = 0;                    // crops per internal sub-batch of the ViT forward (0 = whole batch)
   int prof_mode = 0;                // 0 off, 1 every class, 2 only prof_only
@@ -305,7 +308,8 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   GemmArgs g{};
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
   g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn;
-  if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
+  const bool g2p = e->use_gemm2 && gemm2_supported(prec, D, 768);
+  if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return g2p ? gemm2_nt(prec, EPI_PATCH, g, s) : gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
   const bool panel = e->use_panel && panel_gemm_supported(prec, 3 * D, D) && panel_gemm_supported(prec, e->vit.mlp, D);
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
@@ -313,17 +317,17 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       // row-panel kernels: LayerNorm fused into the A-panel load, no xn buffer, no LayerNorm launches
       PanelArgs p{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
-      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug;
-      if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
+      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
-      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug;
-      if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
+      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s) : panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
       p = PanelArgs{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
-      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug;
-      if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
+      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
     } else {
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
       g = GemmArgs{};
@@ -344,7 +348,8 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     g = GemmArgs{};
     g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
     g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp;
-    if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] { return gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
+    const bool g2 = e->use_gemm2 && gemm2_supported(prec, D, e->vit.mlp);
+    if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] { return g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }
   return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, emb, s); });
 }
@@ -511,6 +516,9 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   const std::string n = name;
   if (n == "use_panel") { enc->use_panel = value; return EFFOCR_OK; }
   if (n == "debug") { enc->debug = value; return EFFOCR_OK; }
+  if (n == "panel_impl") { enc->panel_impl = value; return EFFOCR_OK; }
+  if (n == "use_gemm2") { enc->use_gemm2 = value; return EFFOCR_OK; }
+  if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");
 }
@@ -613,6 +621,7 @@ int effocr_op_linear(int precision, int epilogue, const void* x_dev, const void*
   GemmArgs g{};
   g.X = x_dev; g.ldx = k; g.W = w_dev; g.ldw = k; g.bias = bias_dev; g.out = out_dev; g.ldo = n;
   g.resid = resid_dev; g.ldr = n; g.M = m; g.N = n; g.K = k;
+  if (gemm2_supported(precision, n, k)) return gemm2_nt(precision, epilogue, g, S(stream));   // same rule as the forward
   return gemm_nt(precision, epilogue, g, S(stream));
 }
 
@@ -632,7 +641,7 @@ int effocr_dbg_ln_linear(int precision, int epilogue, const float* x_dev, const 
                          unsigned long long* dbg_dev, void* stream) {
   PanelArgs p{};
   p.A = x_dev; p.lda = k; p.gamma = gamma_dev; p.beta = beta_dev; p.eps = 1e-6f; p.W = w_dev; p.bias = bias_dev;
-  p.out = out_dev; p.ldo = n; p.M = m; p.N = n; p.K = k; p.debug = debug; p.dbg = dbg_dev;
+  p.out = out_dev; p.ldo = n; p.M = m; p.N = n; p.K = k; p.debug = debug & 0xff; p.panel_rows = (debug >> 8) & 0xff; p.dbg = dbg_dev;
   return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
 

@@ -23,6 +23,10 @@ struct GemmArgs {
 // gemm.hip
 int gemm_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 
+// gemm2.hip — K-streaming GEMM with a glds ring for both operands (long K: mlp.fc2, patch embedding)
+bool gemm2_supported(int prec, int N, int K);
+int gemm2_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
+
 // panel.hip — row-panel GEMM with optional fused LayerNorm prologue (K = embed dim)
 enum { PRO_COPY = 0, PRO_LN = 1 };
 struct PanelArgs {
@@ -35,10 +39,13 @@ struct PanelArgs {
   int M, N, K;
   unsigned long long* dbg;          // optional timeline buffer (experiments)
   int debug;                        // experiment switches (bit0: skip epilogue stores)
+  int panel_rows;                   // 128 (one workgroup per CU) or 64 (two); 0 = default
   int rows_padded;                  // out / resid buffers are addressable up to the next multiple of 128 rows
 };
 bool panel_gemm_supported(int prec, int N, int K);
 int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
+// panelr.hip — token-stationary variant (token fragments resident in registers, W ring only in LDS)
+int panelr_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
 
 // vit_ops.hip
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,

@@ -40,10 +40,24 @@
 namespace effocr {
 namespace {
 
-constexpr int PBM = 128;            // token rows per panel
 constexpr int PNT = 128;            // output columns per sweep step
-constexpr int WSTAGE = PNT * 128;   // bytes per ring stage: 128 rows x 64 elements x 2 B
 constexpr int RING = 3;
+
+// Two geometries, same code:
+//   BMT = 128: 8 waves (2 token halves x 4 feature slices), ring stage [128 n x 64 k] = 16 KB (8 MFMAs per
+//              wave per barrier), 152 KB LDS -> ONE workgroup per CU;
+//   BMT =  64: 4 waves (4 feature slices), ring stage [128 n x 32 k] = 8 KB (4 MFMAs per wave per barrier),
+//              79 KB LDS -> TWO independent workgroups per CU: one workgroup's panel load / LayerNorm /
+//              barrier and DMA waits overlap the other's MFMAs, at the price of streaming W twice.
+template <int BMT> struct Geo {
+  static constexpr int WAVES = BMT / 16;               // 16 panel rows per wave in the prologue
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int KSTEPS = (BMT == 128) ? 4 : 2;  // k16 steps per ring stage
+  static constexpr int ROWB = KSTEPS * 32;             // bytes per W row per stage
+  static constexpr int CHUNKS = ROWB / 16;
+  static constexpr int WSTAGE = PNT * ROWB;
+  static constexpr int LPR = CHUNKS;                   // lanes per W row in a DMA piece
+};
 
 template <typename TO> __device__ __forceinline__ void pstore4(TO* p, float a, float b, float c, float d) {
   if constexpr (sizeof(TO) == 4) {
@@ -67,10 +81,12 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 
 // FULL: every output / residual row index of a panel is addressable (M % 128 == 0, or the buffers
 // carry padding rows up to the next multiple of 128) -> branch-free stores.
-template <typename E, int KD, int PRO, int EPI, typename TO, bool FULL>
-__global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
+template <typename E, int KD, int PRO, int EPI, typename TO, bool FULL, int BMT>
+__global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelArgs a) {
+  typedef Geo<BMT> GEO;
+  constexpr int PBM = BMT, WSTAGE = GEO::WSTAGE, NT = GEO::THREADS, KSTEPS = GEO::KSTEPS, NM = 2 * KSTEPS;
   constexpr int APITCH = KD * 2 + 16;                    // bytes per A-panel row (+16: conflict-free b128 reads)
-  constexpr int NKS = KD / 64;                           // ring stages per 128-column sweep step
+  constexpr int NKS = KD / (16 * KSTEPS);                // ring stages per 128-column sweep step
   constexpr int NMAX = 4 * KD;                           // widest layer on this path: mlp.fc1
   constexpr int NG = 8;                                  // epilogue groups per wave per step (2 token tiles x 4)
   __shared__ __attribute__((aligned(16))) char smem[PBM * APITCH + RING * WSTAGE + NMAX * 4];
@@ -81,24 +97,28 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
   typedef typename Op16<E>::V8 V8;
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
-  const int wv = wave_id(), wn = wv >> 1, wm = wv & 1;
+  const int wv = wave_id();
+  const int wn = (BMT == 128) ? (wv >> 1) : wv, wm = (BMT == 128) ? (wv & 1) : 0;
   const int m0 = blockIdx.x * PBM;
   const int niter = a.N / PNT;
   const int S = niter * NKS;
   const char* Wb = static_cast<const char*>(a.W);
 
-  // ---- W ring fill: stage s = (sweep step it, k-stage ks); 2 x 1 KB DMA pieces (8 rows) per wave
+  // ---- W ring fill: stage s = (sweep step it, k-stage ks); 2 x 1 KB DMA pieces per wave.  Lane-linear
+  // LDS image -> the bank swizzle goes on the SOURCE address: 128-B rows: chunk ^= (row>>1)&7, 64-B rows:
+  // chunk ^= (row>>2)&3 (both make the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-B slots)
   uint32_t wsrc[2];                                      // per-lane source offset inside a stage's W block
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = (wv * 2 + i) * 64 + lane;
-    const int row = p >> 3;
-    wsrc[i] = (uint32_t)(row * KD * 2 + (((p & 7) ^ ((row >> 1) & 7)) * 16));
+    const int row = p / GEO::LPR, ch = p % GEO::LPR;
+    const int swz = (GEO::CHUNKS == 8) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+    wsrc[i] = (uint32_t)(row * KD * 2 + ((ch ^ swz) * 16));
   }
   auto issue_w = [&](int s, int slot) {
     if (s >= S) return;
     const int it = s / NKS, ks = s - it * NKS;
-    const char* src = Wb + ((size_t)it * PNT * KD + ks * 64) * 2;
+    const char* src = Wb + ((size_t)it * PNT * KD + ks * 16 * KSTEPS) * 2;
     char* dst = sW + slot * WSTAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -112,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
 #endif
   issue_w(0, 0);
   issue_w(1, 1);
-  for (int n = tid; n < a.N; n += 512) sBias[n] = a.bias[n];
+  for (int n = tid; n < a.N; n += NT) sBias[n] = a.bias[n];
 
   // ---- A panel
   if constexpr (PRO == PRO_LN) {
@@ -140,11 +160,11 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
   } else {
     const E* X = static_cast<const E*>(a.A);
     constexpr int CPR = KD / 8;                          // 16-B chunks per row
-    constexpr int NCH = PBM * CPR / 512;
+    constexpr int NCH = PBM * CPR / NT;
     u32x4 v[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int id = tid + 512 * i;
+      const int id = tid + NT * i;
       const int row = id / CPR, c = id - row * CPR;
       int m = m0 + row;
       m = m < a.M ? m : a.M - 1;
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int id = tid + 512 * i;
+      const int id = tid + NT * i;
       const int row = id / CPR, c = id - row * CPR;
       *reinterpret_cast<u32x4*>(sA + row * APITCH + c * 16) = v[i];
     }
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
   issue_w(2, 2);
 
   constexpr bool DEFER = (EPI != EPI_BIAS_RESID);        // residual loads would stall the W stream: see below
-  constexpr int EPG = (NG + NKS - 1) / NKS < 2 ? 2 : (NG + NKS - 1) / NKS;   // deferred groups per stage
+  constexpr int EPG = (NKS >= 2 * NG) ? 1 : ((NG + NKS - 1) / NKS < 2 ? 2 : (NG + NKS - 1) / NKS);   // deferred groups per stage
   static_assert(NKS * EPG >= NG && NKS % 2 == 0, "panel geometry");
   f32x16 acc[2];                                         // [token tile]: 32 features x 32 tokens each
   u32x2 donep[NG];                                       // parked step: bias added, packed to E (group = 4 values)
@@ -178,9 +198,9 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
 #pragma unroll
   for (int g = 0; g < NG; ++g) { donep[g][0] = 0u; donep[g][1] = 0u; }
 
-  const int sw = (r31 >> 1) & 7;
+  const int sw = (GEO::CHUNKS == 8) ? ((r31 >> 1) & 7) : ((r31 >> 2) & 3);
   const char* pa = sA + (wm * 64 + r31) * APITCH + half * 16;
-  const int wrow = (wn * 32 + r31) * 128;
+  const int wrow = (wn * 32 + r31) * GEO::ROWB;
   TO* out = static_cast<TO*>(a.out);
   int mrow[2];
   bool mok[2];
@@ -196,11 +216,11 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
   // MFMA operand fragments.  W rows are the A-operand, tokens the B-operand.  W fragments of a whole
   // stage (4 k16 steps) are fetched one stage ahead (that frees the ring slot at the next barrier);
   // the token fragments come from the resident panel and are pipelined one k16 step ahead.
-  struct WFrags { V8 w[4]; };
+  struct WFrags { V8 w[KSTEPS]; };
   auto load_w = [&](WFrags& f, int slot) {
     const char* pw = sW + slot * WSTAGE + wrow;
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) f.w[c4] = *reinterpret_cast<const V8*>(pw + (((2 * c4 + half) ^ sw) * 16));
+    for (int c4 = 0; c4 < KSTEPS; ++c4) f.w[c4] = *reinterpret_cast<const V8*>(pw + (((2 * c4 + half) ^ sw) * 16));
   };
   auto load_x = [&](V8 (&x)[2], int k16) {               // k16 = k16-step index within K
 #pragma unroll
@@ -302,70 +322,60 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
     auto mma1 = [&](int n) {
       const int c4 = n >> 1, j = n & 1;
       if (j == 0) {
-        const int nk = (c4 == 3) ? ((ks + 1) % NKS) * 4 : ks * 4 + c4 + 1;     // next k16 step (wraps into next stage)
-#if EFFOCR_EXP != 1
+        const int nk = (c4 == KSTEPS - 1) ? ((ks + 1) % NKS) * KSTEPS : ks * KSTEPS + c4 + 1;   // next k16 step
         if (c4 & 1) load_x(x0, nk); else load_x(x1, nk);
-#endif
       }
-#if EFFOCR_EXP == 2
-      acc[j][n] += (float)cur.w[c4][0] * (float)((c4 & 1) ? x1[j] : x0[j])[0];
-#else
       acc[j] = Op16<E>::mfma(cur.w[c4], (c4 & 1) ? x1[j] : x0[j], acc[j]);
-#endif
     };
     constexpr int g0 = ks * EPG;
     constexpr int ng = (g0 >= NG) ? 0 : (g0 + EPG > NG ? NG - g0 : EPG);
     if constexpr (DEFER && with_epi && ng > 0 && EPI == EPI_BIAS_GELU) {
-      // Deferred GELU of `ng` parked groups (NE elements), hand-sliced between the stage's 8 MFMAs:
-      // every slice is a handful of independent (packed) VALU ops that issue in the 32-cycle shadow
-      // of the MFMA in front of it.  sched_barrier(0) pins the interleave (no instruction is emitted).
+      // Deferred GELU of `ng` parked groups (NE elements), hand-sliced (10 slices) between the stage's NM
+      // MFMAs: every slice is a handful of independent (packed) VALU ops that issue in the 32-cycle
+      // shadow of the MFMA in front of it.  sched_barrier(0) pins the interleave (emits nothing).
       constexpr int NE = ng * 4;
       typedef __attribute__((__vector_size__(4 * sizeof(E)))) E E4;
       constexpr float c[7] = {4.1060451e-05f, -0.00051103633f, 0.00423542528f, -0.0251028568f, 0.111079332f, -0.375314877f, 1.12826843f};
       float x[NE], z[NE], t[NE], p[NE];
-      mma1(0);
-      __builtin_amdgcn_sched_barrier(0);
+      auto slice = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i == 0) {
 #pragma unroll
-      for (int gg = 0; gg < ng; ++gg) {
-        const E4 h = __builtin_bit_cast(E4, donep[g0 + gg]);
+          for (int gg = 0; gg < ng; ++gg) {
+            const E4 h = __builtin_bit_cast(E4, donep[g0 + gg]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[gg * 4 + e] = (float)h[e];
-      }
+            for (int e = 0; e < 4; ++e) x[gg * 4 + e] = (float)h[e];
+          }
 #pragma unroll
-      for (int e = 0; e < NE; ++e) z[e] = __builtin_amdgcn_fmed3f(x[e] * 0.70710678118654752440f, -3.0f, 3.0f);
-      __builtin_amdgcn_sched_barrier(0);
-      mma1(1);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < NE; ++e) z[e] = __builtin_amdgcn_fmed3f(x[e] * 0.70710678118654752440f, -3.0f, 3.0f);
+        } else if constexpr (i == 1) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) { t[e] = z[e] * z[e]; p[e] = fmaf(4.07419588e-08f, t[e], -1.94481757e-06f); }
+          for (int e = 0; e < NE; ++e) { t[e] = z[e] * z[e]; p[e] = fmaf(4.07419588e-08f, t[e], -1.94481757e-06f); }
+        } else if constexpr (i <= 8) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) p[e] = fmaf(p[e], t[e], c[0]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 1; k < 7; ++k) {
-        mma1(1 + k);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < NE; ++e) p[e] = fmaf(p[e], t[e], c[k]);
-        if (k == 6) {
+          for (int e = 0; e < NE; ++e) p[e] = fmaf(p[e], t[e], c[i - 2]);
+        } else {
 #pragma unroll
           for (int e = 0; e < NE; ++e) { const float h = 0.5f * x[e]; x[e] = fmaf(z[e] * p[e], h, h); }
 #pragma unroll
           for (int gg = 0; gg < ng; ++gg) store_group(g0 + gg, pend_n0, pack4<E>(x[gg * 4], x[gg * 4 + 1], x[gg * 4 + 2], x[gg * 4 + 3]));
         }
+      };
+      static_for<0, NM>([&](auto N_) {
+        constexpr int n = decltype(N_)::value;
+        mma1(n);
         __builtin_amdgcn_sched_barrier(0);
-      }
+        static_for<(n * 10) / NM, ((n + 1) * 10) / NM>([&](auto I) { slice(I); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
     } else {
 #pragma unroll
-      for (int n = 0; n < 8; ++n) mma1(n);
+      for (int n = 0; n < NM; ++n) mma1(n);
       if constexpr (DEFER && with_epi && ng > 0) {
 #pragma unroll
         for (int gg = 0; gg < ng; ++gg) store_group(g0 + gg, pend_n0, donep[g0 + gg]);
       }
     }
-#if EFFOCR_EXP == 9
-    if (stamp) { asm volatile("s_nop 0" ::: "memory"); dbgw[s * 4 + 3] = __builtin_amdgcn_s_memtime(); }
-#endif
     ++s;
     slot = nslot;
   };
@@ -407,10 +417,10 @@ __global__ __launch_bounds__(512, 2) void panel_gemm_kernel(PanelArgs a) {
 #endif
 }
 
-template <typename E, int KD, bool FULL>
+template <typename E, int KD, bool FULL, int BMT>
 int launch_panel(int pro, int epi, const PanelArgs& a, hipStream_t s) {
-  const dim3 grid((unsigned)((a.M + PBM - 1) / PBM)), blk(512);
-#define EFFOCR_PANEL(P, EP, TOUT) hipLaunchKernelGGL((panel_gemm_kernel<E, KD, P, EP, TOUT, FULL>), grid, blk, 0, s, a)
+  const dim3 grid((unsigned)((a.M + BMT - 1) / BMT)), blk(Geo<BMT>::THREADS);
+#define EFFOCR_PANEL(P, EP, TOUT) hipLaunchKernelGGL((panel_gemm_kernel<E, KD, P, EP, TOUT, FULL, BMT>), grid, blk, 0, s, a)
   if (pro == PRO_LN) {
     switch (epi) {
       case EPI_BIAS: EFFOCR_PANEL(PRO_LN, EPI_BIAS, E); break;
@@ -432,8 +442,10 @@ int launch_panel(int pro, int epi, const PanelArgs& a, hipStream_t s) {
 
 template <typename E, int KD>
 int launch_panel_full(int pro, int epi, const PanelArgs& a, hipStream_t s) {
-  const bool full = (a.M % PBM == 0) || a.rows_padded;
-  return full ? launch_panel<E, KD, true>(pro, epi, a, s) : launch_panel<E, KD, false>(pro, epi, a, s);
+  const bool full = (a.M % 128 == 0) || a.rows_padded;
+  if (a.panel_rows == 64)
+    return full ? launch_panel<E, KD, true, 64>(pro, epi, a, s) : launch_panel<E, KD, false, 64>(pro, epi, a, s);
+  return full ? launch_panel<E, KD, true, 128>(pro, epi, a, s) : launch_panel<E, KD, false, 128>(pro, epi, a, s);
 }
 
 }  // namespace
@@ -446,7 +458,7 @@ int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s) {
   if (a.M <= 0) return EFFOCR_OK;
   if (!panel_gemm_supported(prec, a.N, a.K)) return fail(EFFOCR_EUNSUPPORTED, "panel_gemm: needs bf16/fp16, K in {128,384}, N % 128 == 0, N <= 4K");
   if (pro == PRO_COPY && (a.lda % 8) != 0) return fail(EFFOCR_EINVAL, "panel_gemm: A rows must be 16-byte aligned");
-  if ((int64_t)(a.M + PBM) * a.ldo * 4 >= ((int64_t)1 << 32)) return fail(EFFOCR_EUNSUPPORTED, "panel_gemm: output larger than 4 GB");
+  if ((int64_t)(a.M + 128) * a.ldo * 4 >= ((int64_t)1 << 32)) return fail(EFFOCR_EUNSUPPORTED, "panel_gemm: output larger than 4 GB");
   if (prec == PREC_BF16) return a.K == 384 ? launch_panel_full<__bf16, 384>(pro, epi, a, s) : launch_panel_full<__bf16, 128>(pro, epi, a, s);
   return a.K == 384 ? launch_panel_full<_Float16, 384>(pro, epi, a, s) : launch_panel_full<_Float16, 128>(pro, epi, a, s);
 }

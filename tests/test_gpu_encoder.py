@@ -100,10 +100,13 @@ def test_panel_and_streaming_paths_agree(dev):
     ref = encoder_forward("vit_small_patch16_224", sd, x)
     enc = HipEncoder("vit_small_patch16_224", sd, precision="bf16", device=dev)
     a = enc.forward(x.to(dev)).cpu()
+    enc.set_option("panel_rows", 64)             # 64-row panels, two workgroups per CU
+    c = enc.forward(x.to(dev)).cpu()
     enc.set_option("use_panel", 0)
     b = enc.forward(x.to(dev)).cpu()
-    assert rel_err(a, ref) <= REL["bf16"] and rel_err(b, ref) <= REL["bf16"]
+    assert rel_err(a, ref) <= REL["bf16"] and rel_err(b, ref) <= REL["bf16"] and rel_err(c, ref) <= REL["bf16"]
     assert rel_err(a, b) <= REL["bf16"]
+    assert torch.equal(a, c)                     # same arithmetic, same summation order -> bit-identical
 
 
 def test_input_validation(dev):

@@ -1,0 +1,91 @@
+// Per-CU vector-memory microbenchmarks (experiment, not product): LDS-DMA read rate from an L2-resident
+// buffer, and store rates for row-strided 8/16-byte-per-lane vs contiguous patterns, with 8 waves per CU.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o /tmp/microbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+// mode 0: each wave issues PIECES glds (1 KB each) per iteration, waits so that LAG iterations stay in flight
+template <int PIECES, int ROWB, bool BARRIER>
+__global__ __launch_bounds__(512, 2) void k_glds(const char* __restrict__ w, size_t wbytes, int iters, float* sink) {
+  constexpr int NSLOT = (150 / (8 * PIECES)) >= 3 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[150 * 1024];          // 1 workgroup per CU, like the panel kernel
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int LPR = ROWB / 16;
+  const int row = lane / LPR, ch = lane % LPR;
+  const size_t stage_bytes = (size_t)8 * PIECES * 1024;
+  size_t off = 0;
+  for (int it = 0; it < iters; ++it) {
+    char* dst = smem + (it % NSLOT) * stage_bytes;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int piece = wv * PIECES + i;
+      const char* g = w + off + (size_t)(piece * (64 / LPR) + row) * 768 + ch * 16;   // rows 768 B apart like W[n][384]
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+    if (PIECES == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (BARRIER) __builtin_amdgcn_s_barrier();
+    off += ROWB;                       // walk along K like the ring stages do
+    if (off + (size_t)8 * PIECES * 64 / LPR * 768 + 768 > wbytes) off = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<float*>(smem);
+}
+
+// mode 1: stores.  STRIDED: lane (t = lane&31, half) writes BYTES at row t (row pitch `pitch`), + half*BYTES
+//         contiguous: lane writes BYTES at base + lane*BYTES
+template <int BYTES, bool STRIDED>
+__global__ __launch_bounds__(512, 2) void k_store(char* __restrict__ out, size_t pitch, int iters, int per_iter) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t wg_base = (size_t)blockIdx.x * 128 * pitch;                 // 128 rows per workgroup
+  u32x4 v = {(unsigned)lane, (unsigned)wv, 3u, 4u};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 4
+    for (int i = 0; i < per_iter; ++i) {
+      const int col = (it * per_iter + i) * 2 * BYTES;                      // advances along the row
+      size_t a;
+      if (STRIDED) a = wg_base + (size_t)((wv & 3) * 32 + (lane & 31)) * pitch + (col % (pitch - 64)) + (lane >> 5) * BYTES;
+      else a = wg_base + (size_t)wv * 64 * BYTES * 64 + ((size_t)(it * per_iter + i) % 64) * 64 * BYTES + lane * BYTES;
+      if (BYTES == 8) { u32x2 q = {v[0], v[1]}; *reinterpret_cast<u32x2*>(out + a) = q; }
+      else *reinterpret_cast<u32x4*>(out + a) = v;
+    }
+  }
+}
+
+template <typename F> float timeit(F f, int reps = 5) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
+
+int main() {
+  const int NCU = 256;
+  const size_t wbytes = 2u << 20;                       // 2 MB "weights": L2 resident
+  char* w; CK(hipMalloc(&w, wbytes)); CK(hipMemset(w, 1, wbytes));
+  float* sink; CK(hipMalloc(&sink, 4096 * 4));
+  const size_t obytes = (size_t)1 << 30; char* out; CK(hipMalloc(&out, obytes));
+  const double clk = 2.1e9;
+  printf("== LDS-DMA (global_load_lds 16 B/lane) from a 2 MB L2-resident buffer, 256 workgroups x 8 waves, 1 WG/CU\n");
+  const int iters = 4000;
+#define GL(P, R, B) { float ms = timeit([&] { hipLaunchKernelGGL((k_glds<P, R, B>), dim3(NCU), dim3(512), 0, 0, w, wbytes, iters, sink); }); \
+    double bytes = (double)iters * 8 * P * 1024; printf("  pieces/wave %d rowB %3d barrier %d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  chip %5.2f TB/s  (%.0f cyc/iter)\n", P, R, (int)B, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, bytes * NCU / (ms * 1e-3) / 1e12, ms * 1e-3 * clk / iters); }
+  GL(1, 64, false) GL(2, 64, false) GL(2, 128, false) GL(2, 64, true) GL(2, 128, true) GL(4, 128, false) GL(4, 128, true) GL(8, 128, false) GL(8, 128, true)
+  printf("== stores, 256 workgroups x 8 waves; each store instruction = 64 lanes\n");
+  const int sit = 200, per = 16;
+#define ST(BY, STR, PITCH) { float ms = timeit([&] { hipLaunchKernelGGL((k_store<BY, STR>), dim3(NCU), dim3(512), 0, 0, out, (size_t)PITCH, sit, per); }); \
+    double instr = (double)sit * per * 8; double bytes = instr * 64 * BY; printf("  %2d B/lane %-10s pitch %5d: %7.1f us  %6.1f GB/s/CU  %5.2f cyc per store instr per CU  chip %5.2f TB/s\n", BY, STR ? "row-strided" : "contiguous", (int)PITCH, ms * 1e3, bytes / (ms * 1e-3) / 1e9, ms * 1e-3 * clk / instr, bytes * NCU / (ms * 1e-3) / 1e12); }
+  ST(8, true, 3072) ST(8, true, 2304) ST(8, false, 3072) ST(16, true, 1536) ST(16, false, 1536)
+  return 0;
+}
