@@ -135,6 +135,8 @@ def main():
         enc.set_option("debug", int(os.environ["EFFOCR_DEBUG"]))
     if a.panel_rows:
         enc.set_option("panel_rows", a.panel_rows)
+    if os.environ.get("EFFOCR_NO_BLOCKED"):
+        enc.set_option("use_blocked", 0)
     if os.environ.get("EFFOCR_NO_GEMM2"):
         enc.set_option("use_gemm2", 0)
     if a.panel_impl >= 0:

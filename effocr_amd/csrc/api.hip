@@ -55,6 +55,7 @@ struct effocr_encoder {
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
+  int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
   int panel_impl = 0;               // 0: LDS-panel panel.hip (default, faster), 1: token-stationary panelr.hip (experiment)
   int panel_rows = 128;             // row-panel height: 128 (1 workgroup/CU) or 64 (2 workgroups/CU)
@@ -303,14 +304,17 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   auto F = [&](size_t off) { return reinterpret_cast<const float*>(wb + off); };
   int rc;
   const double Md = (double)M, Dd = (double)D, Hd = (double)e->vit.mlp;
+  const bool panel = e->use_panel && panel_gemm_supported(prec, 3 * D, D) && panel_gemm_supported(prec, e->vit.mlp, D);
+  const bool g2 = e->use_gemm2 && gemm2_supported(prec, D, e->vit.mlp);
+  const bool g2p = e->use_gemm2 && gemm2_supported(prec, D, 768);
+  // fragment-blocked activations (x fp32, qkv, attention output, MLP hidden) need every producer/consumer on the fast path
+  const int blk = (e->use_blocked && panel && g2 && g2p && e->panel_impl == 0) ? 1 : 0;
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
-  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, s))) return rc;
+  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
   GemmArgs g{};
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
-  g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn;
-  const bool g2p = e->use_gemm2 && gemm2_supported(prec, D, 768);
+  g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn; g.blk_out = blk;
   if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return g2p ? gemm2_nt(prec, EPI_PATCH, g, s) : gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
-  const bool panel = e->use_panel && panel_gemm_supported(prec, 3 * D, D) && panel_gemm_supported(prec, e->vit.mlp, D);
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
     if (panel) {
@@ -318,15 +322,17 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       PanelArgs p{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
       p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
-      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
+      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
-      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s) : panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
       p = PanelArgs{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
       p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
     } else {
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
@@ -334,7 +340,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       g.X = xn; g.ldx = D; g.W = wb + L.qkvw; g.ldw = D; g.bias = F(L.qkvb); g.out = qkv; g.ldo = 3 * D;
       g.M = M; g.N = 3 * D; g.K = D;
       if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return gemm_nt(prec, EPI_BIAS, g, s); }))) return rc;
-      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, s); }))) return rc;
+      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, 0, s); }))) return rc;
       g = GemmArgs{};
       g.X = att; g.ldx = D; g.W = wb + L.projw; g.ldw = D; g.bias = F(L.projb); g.out = xs; g.ldo = D;
       g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = D;
@@ -347,11 +353,10 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     }
     g = GemmArgs{};
     g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
-    g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp;
-    const bool g2 = e->use_gemm2 && gemm2_supported(prec, D, e->vit.mlp);
+    g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp; g.blk_x = blk; g.blk_out = blk;
     if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] { return g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }
-  return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, emb, s); });
+  return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, blk, emb, s); });
 }
 
 struct ResWs { size_t col, a, b, c, total; };
@@ -518,6 +523,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "debug") { enc->debug = value; return EFFOCR_OK; }
   if (n == "panel_impl") { enc->panel_impl = value; return EFFOCR_OK; }
   if (n == "use_gemm2") { enc->use_gemm2 = value; return EFFOCR_OK; }
+  if (n == "use_blocked") { enc->use_blocked = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");
@@ -651,7 +657,7 @@ int effocr_op_layernorm(int out_precision, const float* x_dev, int64_t rows, int
 }
 
 int effocr_op_attention(int precision, const void* qkv_dev, void* out_dev, int batch, int tokens, int heads, void* stream) {
-  return attention(precision, qkv_dev, out_dev, batch, tokens, heads, S(stream));
+  return attention(precision, qkv_dev, out_dev, batch, tokens, heads, 0, S(stream));
 }
 
 }  // extern "C"

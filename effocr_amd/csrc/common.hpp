@@ -52,6 +52,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + in;
 }
 
+// Fragment-blocked activation layout (fast path): a [rows, cols] matrix of 16-byte chunks is stored as
+// cells [row/32][chunk][row%32][16 B] (512 B per cell).  In the swapped-MFMA C/D layout a lane owns 4
+// consecutive features of token (lane&31), so one wave store / load instruction covers ONE contiguous
+// cell per half-wave instead of 32 partial cache lines (78 -> <=37 TA cycles per instruction measured).
+__host__ __device__ __forceinline__ int64_t blk_off(int64_t row, int chunk, int nchunks) {
+  return ((row >> 5) * nchunks + chunk) * 512 + (row & 31) * 16;
+}
+
 // erf-based GELU (torch.nn.GELU default, what timm's Mlp uses): 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
 
   // per-lane DMA sources: piece p (1 KB = 8 rows x 128 B) of the stage image; pieces 0..31 = X, 32..47 = W
   const char* src[G2PIECES];
+  int sinc[G2PIECES];                                    // per-stage source advance (blocked X: 8 chunk cells)
 #pragma unroll
   for (int i = 0; i < G2PIECES; ++i) {
     const int piece = wv * G2PIECES + i;
@@ -57,10 +58,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
 #if EFFOCR_EXP == 13
       m = m & 1023;                      // experiment: X rows from a 3 MB window (L2 / MALL resident)
 #endif
-      src[i] = Xb + ((size_t)m * g.ldx) * sizeof(E) + ch * 16;
+      if (g.blk_x) { src[i] = Xb + blk_off(m, ch, (int)(g.ldx / 8)); sinc[i] = 8 * 512; }
+      else { src[i] = Xb + ((size_t)m * g.ldx) * sizeof(E) + ch * 16; sinc[i] = 128; }
     } else {
       row -= 256;
       src[i] = Wb + ((size_t)(n0 + row) * g.ldw) * sizeof(E) + ch * 16;
+      sinc[i] = 128;
     }
   }
   auto issue = [&](int s) {
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
     char* dst = smem + (s % G2RING) * G2STAGE;
 #pragma unroll
     for (int i = 0; i < G2PIECES; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * 128),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * sinc[i]),
                                        (__attribute__((address_space(3))) void*)(dst + (wv * G2PIECES + i) * 1024), 16, 0, 0);
   };
   issue(0);
@@ -156,7 +159,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
-          if constexpr (EPI == EPI_BIAS_RESID) rv[i][j][q] = *reinterpret_cast<const f32x4*>(g.resid + orow[j] * g.ldr + n);
+          if constexpr (EPI == EPI_BIAS_RESID) {
+            const char* rp = g.blk_out ? reinterpret_cast<const char*>(g.resid) + blk_off(orow[j], n >> 2, g.N >> 2)
+                                       : reinterpret_cast<const char*>(g.resid + orow[j] * g.ldr + n);
+            rv[i][j][q] = *reinterpret_cast<const f32x4*>(rp);
+          }
           else rv[i][j][q] = *reinterpret_cast<const f32x4*>(posrow[j] + n);
         }
 #pragma unroll
@@ -184,7 +191,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
           v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
         }
         TO* p = out + orow[j] * g.ldo + n;
-        if constexpr (sizeof(TO) == 4) { f32x4 o = {v0, v1, v2, v3}; *reinterpret_cast<f32x4*>(p) = o; }
+        if constexpr (sizeof(TO) == 4) {
+          if (g.blk_out) p = reinterpret_cast<TO*>(reinterpret_cast<char*>(out) + blk_off(orow[j], n >> 2, g.N >> 2));
+          f32x4 o = {v0, v1, v2, v3};
+          *reinterpret_cast<f32x4*>(p) = o;
+        }
         else *reinterpret_cast<u32x2*>(p) = pack4<TO>(v0, v1, v2, v3);
       }
     }

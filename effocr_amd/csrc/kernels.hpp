@@ -18,6 +18,8 @@ struct GemmArgs {
   const float* pos;                 // EPI_PATCH: pos_embed rows [1+P, N] fp32
   int M, N, K;
   int P;                            // EPI_PATCH: patches per image
+  int blk_x;                        // gemm2: X operand is fragment-blocked (16-B chunks of 8 elements)
+  int blk_out;                      // gemm2: out / resid (fp32, chunks of 4) are fragment-blocked
 };
 
 // gemm.hip
@@ -39,6 +41,8 @@ struct PanelArgs {
   int M, N, K;
   unsigned long long* dbg;          // optional timeline buffer (experiments)
   int debug;                        // experiment switches (bit0: skip epilogue stores)
+  int blk_a;                        // A (PRO_COPY: 16-bit, PRO_LN: fp32 x) is fragment-blocked
+  int blk_out;                      // out (and resid) are fragment-blocked
   int panel_rows;                   // 128 (one workgroup per CU) or 64 (two); 0 = default
   int rows_padded;                  // out / resid buffers are addressable up to the next multiple of 128 rows
 };
@@ -51,10 +55,10 @@ int panelr_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                    float eps, void* out, hipStream_t s);
 int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s);
-int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, hipStream_t s);
-int attention(int prec, const void* qkv, void* out, int B, int T, int heads, hipStream_t s);
+int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, hipStream_t s);
+int attention(int prec, const void* qkv, void* out, int B, int T, int heads, int blocked, hipStream_t s);
 int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, const float* beta, float eps,
-                   int l2norm, float* emb, hipStream_t s);
+                   int l2norm, int blocked, float* emb, hipStream_t s);
 
 // knn.hip
 size_t knn_workspace_bytes(int64_t B, int64_t N, int D, int k);

@@ -136,6 +136,43 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 
   // ---- A panel
   if constexpr (PRO == PRO_LN) {
+    if (a.blk_a) {
+      // fragment-blocked fp32 x: lane = (token tl of this wave's 16 rows, quarter `part` of the row): the 16
+      // token-lanes of a quarter read 256 contiguous bytes of one cell; statistics = lane-local sums over the
+      // quarter + a 4-lane-group exchange; exact two-pass variance from the registers.
+      constexpr int NQ = KD / 16;                        // float4 chunks per lane (KD/4 chunks / 4 parts)
+      const int tl = lane & 15, part = lane >> 4;
+      const int row = wv * 16 + tl;
+      int m = m0 + row;
+      m = m < a.M ? m : a.M - 1;
+      const char* xb = static_cast<const char*>(a.A);
+      f32x4 xv[NQ];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xb + blk_off(m, part + 4 * i, KD / 4));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / KD);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / KD) + a.eps);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int c = part + 4 * i;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + c * 4);
+        *reinterpret_cast<u32x2*>(sA + row * APITCH + c * 8) =
+            pack4<E>((xv[i][0] - mean) * rstd * gm[0] + bt[0], (xv[i][1] - mean) * rstd * gm[1] + bt[1],
+                     (xv[i][2] - mean) * rstd * gm[2] + bt[2], (xv[i][3] - mean) * rstd * gm[3] + bt[3]);
+      }
+    } else {
     constexpr int G = LnShape<KD>::G, V = LnShape<KD>::V, RPW = 64 / G;
     const float* X = static_cast<const float*>(a.A);
     const int sub = lane % G;
@@ -157,6 +194,7 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
       for (int i = 0; i < V; ++i)
         *reinterpret_cast<u32x2*>(sA + row * APITCH + (sub + G * i) * 8) = pack4<E>(y[i][0], y[i][1], y[i][2], y[i][3]);
     }
+    }
   } else {
     const E* X = static_cast<const E*>(a.A);
     constexpr int CPR = KD / 8;                          // 16-B chunks per row
@@ -165,15 +203,19 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int id = tid + NT * i;
-      const int row = id / CPR, c = id - row * CPR;
+      int row = id / CPR, c = id - row * CPR;
+      if (a.blk_a) { c = id / PBM; row = id - c * PBM; } // blocked A: consecutive threads = consecutive tokens of one cell
       int m = m0 + row;
       m = m < a.M ? m : a.M - 1;
-      v[i] = *reinterpret_cast<const u32x4*>(X + (int64_t)m * a.lda + c * 8);
+      const char* p = a.blk_a ? reinterpret_cast<const char*>(X) + blk_off(m, c, CPR)
+                              : reinterpret_cast<const char*>(X + (int64_t)m * a.lda + c * 8);
+      v[i] = *reinterpret_cast<const u32x4*>(p);
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int id = tid + NT * i;
-      const int row = id / CPR, c = id - row * CPR;
+      int row = id / CPR, c = id - row * CPR;
+      if (a.blk_a) { c = id / PBM; row = id - c * PBM; }
       *reinterpret_cast<u32x4*>(sA + row * APITCH + c * 16) = v[i];
     }
   }
@@ -211,7 +253,13 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
     mok[j] = FULL || m < a.M;
     mrow[j] = mok[j] ? m : a.M - 1;
     prow[j] = (uint32_t)(((int64_t)mrow[j] * a.ldo + wn * 32 + 4 * half) * (int64_t)sizeof(TO));
+    if (a.blk_out) {
+      // blocked: byte offset of (row, column wn*32 + 4*half); a column step of c elements moves (c / CH) cells
+      constexpr int CH = 16 / (int)sizeof(TO);
+      prow[j] = (uint32_t)(blk_off(mrow[j], (wn * 32 + 4 * half) / CH, (int)(a.ldo / CH)) + ((4 * half) % CH) * (int)sizeof(TO));
+    }
   }
+  const uint32_t colstep = a.blk_out ? 512u / (16 / (uint32_t)sizeof(TO)) * 1u : (uint32_t)sizeof(TO);   // bytes per column element step (in units of 1 element, for multiples of the chunk)
 
   // MFMA operand fragments.  W rows are the A-operand, tokens the B-operand.  W fragments of a whole
   // stage (4 k16 steps) are fetched one stage ahead (that frees the ring slot at the next barrier);
@@ -230,7 +278,8 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
   // group g = (token tile j = g>>2, feature quad q = g&3): 4 consecutive features of one token
   auto group_ptr = [&](int g, int n0) -> TO* {
     const int j = g >> 2, q = g & 3;
-    return reinterpret_cast<TO*>(reinterpret_cast<char*>(out) + (prow[j] + (uint32_t)((n0 + 8 * q) * (int)sizeof(TO))));
+    // columns advance in multiples of 8 elements here: row-major 8*sizeof bytes; blocked (8/CH) cells of 512 B
+    return reinterpret_cast<TO*>(reinterpret_cast<char*>(out) + (prow[j] + (uint32_t)(n0 + 8 * q) * colstep));
   };
   auto store_group = [&](int g, int n0, u32x2 v) {
     TO* p = group_ptr(g, n0);
@@ -398,7 +447,11 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rv[j][q] = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)mrow[j] * a.ldr + n0 + 8 * q + 4 * half);
+        for (int q = 0; q < 4; ++q) {
+          const char* rp = a.blk_out ? reinterpret_cast<const char*>(a.resid) + blk_off(mrow[j], (n0 + 8 * q + 4 * half) >> 2, (int)(a.ldr >> 2))
+                                     : reinterpret_cast<const char*>(a.resid + (int64_t)mrow[j] * a.ldr + n0 + 8 * q + 4 * half);
+          rv[j][q] = *reinterpret_cast<const f32x4*>(rp);
+        }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll

@@ -37,14 +37,21 @@ template <int G, int V>
 __global__ __launch_bounds__(256) void cls_norm_kernel(const float* __restrict__ x, int B, int T,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int l2norm,
-                                                       float* __restrict__ emb) {
+                                                       int blocked, float* __restrict__ emb) {
   constexpr int D = 4 * G * V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63, sub = lane % G;
   const int img = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
   const int ic = img < B ? img : B - 1;
-  f32x4 y[V];
-  ln_row<G, V>(x + (int64_t)ic * T * D, sub, gamma, beta, eps, y);
+  f32x4 y[V], v[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int chunk = sub + G * i;
+    const char* p = blocked ? reinterpret_cast<const char*>(x) + blk_off((int64_t)ic * T, chunk, D / 4)
+                            : reinterpret_cast<const char*>(x + (int64_t)ic * T * D + chunk * 4);
+    v[i] = *reinterpret_cast<const f32x4*>(p);
+  }
+  ln_apply<G, V>(v, sub, gamma, beta, eps, y);
   if (l2norm) {
     float ss = 0.f;
 #pragma unroll
@@ -96,12 +103,13 @@ __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__
 }
 
 // token 0 of every image = cls_token + pos_embed[0] (pre-added on the host at weight upload)
-__global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D) {
+__global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D, int blocked) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= (int64_t)B * D) return;
   const int d = (int)(id % D);
   const int64_t img = id / D;
-  x[img * T * D + d] = cls_pos0[d];
+  if (blocked) *reinterpret_cast<float*>(reinterpret_cast<char*>(x) + blk_off(img * T, d >> 2, D / 4) + (d & 3) * 4) = cls_pos0[d];
+  else x[img * T * D + d] = cls_pos0[d];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -117,7 +125,8 @@ __global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __rest
 // already a valid B-operand for O^T = V^T P^T provided V^T is read with the matching key
 // permutation (keys {0-3,8-11 | 4-7,12-15} + 16m per half-wave), so no permute instructions.
 // ------------------------------------------------------------------------------------------
-template <typename E, int NKT>
+// BLK: qkv and out are fragment-blocked (see blk_off): row = global token index, 16-B chunk = 8 features.
+template <typename E, int NKT, bool BLK>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__ qkv, E* __restrict__ out,
                                                            int B, int T, int heads) {
   typedef typename Op16<E>::V8 V8;
@@ -134,12 +143,19 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
   const int D = heads * 64;
   const int64_t ld = 3 * (int64_t)D;
   const E* base = qkv + (int64_t)b * T * ld + h * 64;
+  const int64_t tok0 = (int64_t)b * T;                   // first token of this image
+  const int nch = 3 * D / 8;                             // chunks per qkv row
+  // 16-B chunk `c8` (0..7) of section `sec` (0 q, 1 k, 2 v) of token t
+  auto qkv_ptr = [&](int t, int sec, int c8) -> const u32x4* {
+    if constexpr (BLK) return reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(qkv) + blk_off(tok0 + t, (sec * D + h * 64) / 8 + c8, nch));
+    else return reinterpret_cast<const u32x4*>(base + (int64_t)t * ld + sec * D + c8 * 8);
+  };
 
   // ---- stage K rows (zero rows beyond T)
   for (int id = tid; id < TP * 8; id += 256) {
     const int t = id >> 3, c = id & 7;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (t < T) v = *reinterpret_cast<const u32x4*>(base + (int64_t)t * ld + D + c * 8);
+    if (t < T) v = *qkv_ptr(t, 1, c);
     *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = v;
   }
   // ---- stage V transposed: dword (d, tp) = {V[2tp][d], V[2tp+1][d]}
@@ -147,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
     const int tp = id >> 3, c = id & 7;
     const int t0 = 2 * tp;
     u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-    if (t0 < T) v0 = *reinterpret_cast<const u32x4*>(base + (int64_t)t0 * ld + 2 * D + c * 8);
-    if (t0 + 1 < T) v1 = *reinterpret_cast<const u32x4*>(base + (int64_t)(t0 + 1) * ld + 2 * D + c * 8);
+    if (t0 < T) v0 = *qkv_ptr(t0, 2, c);
+    if (t0 + 1 < T) v1 = *qkv_ptr(t0 + 1, 2, c);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const uint32_t a = v0[jj], bq = v1[jj];
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
     V8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = *reinterpret_cast<const V8*>(base + (int64_t)tq * ld + ks * 16 + half * 8);
+      qf[ks] = __builtin_bit_cast(V8, *qkv_ptr(tq, 0, 2 * ks + half));
 
     // S^T tiles: rows = keys, cols = queries
     f32x16 s[NKT];
@@ -235,7 +251,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           const int d = db * 32 + 8 * q4 + 4 * half;
-          *reinterpret_cast<u32x2*>(orow + d) =
+          u32x2* dst = reinterpret_cast<u32x2*>(orow + d);
+          if constexpr (BLK) dst = reinterpret_cast<u32x2*>(reinterpret_cast<char*>(out) + blk_off(tok0 + tq, (h * 64 + db * 32 + 8 * q4) / 8, D / 8) + half * 8);
+          *dst =
               pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
         }
     }
@@ -318,14 +336,14 @@ int launch_im2col(const float* x, int B, int H, int W, TO* out, hipStream_t s) {
   return check_launch("im2col16");
 }
 
-template <typename E>
+template <typename E, bool BLK>
 int launch_attn_mfma(const E* qkv, E* out, int B, int T, int heads, hipStream_t s) {
   const int nkt = (T + 31) / 32;
   const dim3 grid((unsigned)(B * heads)), blk(256);
   switch (nkt) {
-    case 1: hipLaunchKernelGGL((attn_mfma_kernel<E, 1>), grid, blk, 0, s, qkv, out, B, T, heads); break;
-    case 2: hipLaunchKernelGGL((attn_mfma_kernel<E, 2>), grid, blk, 0, s, qkv, out, B, T, heads); break;
-    case 7: hipLaunchKernelGGL((attn_mfma_kernel<E, 7>), grid, blk, 0, s, qkv, out, B, T, heads); break;
+    case 1: hipLaunchKernelGGL((attn_mfma_kernel<E, 1, BLK>), grid, blk, 0, s, qkv, out, B, T, heads); break;
+    case 2: hipLaunchKernelGGL((attn_mfma_kernel<E, 2, BLK>), grid, blk, 0, s, qkv, out, B, T, heads); break;
+    case 7: hipLaunchKernelGGL((attn_mfma_kernel<E, 7, BLK>), grid, blk, 0, s, qkv, out, B, T, heads); break;
     default: return fail(EFFOCR_EUNSUPPORTED, "attention: token count must be <=64 or in (192,224]");
   }
   return check_launch("attention");
@@ -353,18 +371,23 @@ int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out,
   return fail(EFFOCR_EINVAL, "im2col: unknown precision");
 }
 
-int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, hipStream_t s) {
+int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, hipStream_t s) {
   const int64_t total = (int64_t)B * D;
   if (total <= 0) return EFFOCR_OK;
-  hipLaunchKernelGGL(set_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls_pos0, x, B, T, D);
+  hipLaunchKernelGGL(set_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls_pos0, x, B, T, D, blocked);
   return check_launch("set_cls_rows");
 }
 
-int attention(int prec, const void* qkv, void* out, int B, int T, int heads, hipStream_t s) {
+int attention(int prec, const void* qkv, void* out, int B, int T, int heads, int blocked, hipStream_t s) {
   if (B <= 0) return EFFOCR_OK;
+  if (blocked && prec == PREC_FP32) return fail(EFFOCR_EUNSUPPORTED, "attention(fp32): blocked layout not supported");
   switch (prec) {
-    case PREC_BF16: return launch_attn_mfma<__bf16>(static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), B, T, heads, s);
-    case PREC_FP16: return launch_attn_mfma<_Float16>(static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), B, T, heads, s);
+    case PREC_BF16:
+      return blocked ? launch_attn_mfma<__bf16, true>(static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), B, T, heads, s)
+                     : launch_attn_mfma<__bf16, false>(static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), B, T, heads, s);
+    case PREC_FP16:
+      return blocked ? launch_attn_mfma<_Float16, true>(static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), B, T, heads, s)
+                     : launch_attn_mfma<_Float16, false>(static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), B, T, heads, s);
     case PREC_FP32:
       if (T > ATT32_TMAX) return fail(EFFOCR_EUNSUPPORTED, "attention(fp32): more than 224 tokens");
       hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, s,
@@ -375,14 +398,14 @@ int attention(int prec, const void* qkv, void* out, int B, int T, int heads, hip
 }
 
 int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, const float* beta, float eps,
-                   int l2norm, float* emb, hipStream_t s) {
+                   int l2norm, int blocked, float* emb, hipStream_t s) {
   if (B <= 0) return EFFOCR_OK;
   if (D == 384) {
-    hipLaunchKernelGGL((cls_norm_kernel<32, 3>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, emb);
+    hipLaunchKernelGGL((cls_norm_kernel<32, 3>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb);
   } else if (D == 768) {
-    hipLaunchKernelGGL((cls_norm_kernel<64, 3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, emb);
+    hipLaunchKernelGGL((cls_norm_kernel<64, 3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb);
   } else if (D == 128) {
-    hipLaunchKernelGGL((cls_norm_kernel<32, 1>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, emb);
+    hipLaunchKernelGGL((cls_norm_kernel<32, 1>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb);
   } else {
     return fail(EFFOCR_EUNSUPPORTED, "final norm: embed dim must be 128, 384 or 768");
   }
