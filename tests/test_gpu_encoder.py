@@ -102,7 +102,7 @@ def test_panel_and_streaming_paths_agree(dev):
     a = enc.forward(x.to(dev)).cpu()
     enc.set_option("use_blocked", 0)             # row-major activations instead of fragment-blocked cells
     r = enc.forward(x.to(dev)).cpu()
-    assert rel_err(a, r) <= 2e-3                 # same arithmetic; the fused LayerNorm sums its row in a different lane order
+    assert rel_err(a, r) <= REL["bf16"]          # same arithmetic, but the fused LayerNorm sums in a different lane order -> bf16 roundings flip
     enc.set_option("use_blocked", 1)
     enc.set_option("panel_rows", 64)             # 64-row panels, two workgroups per CU
     c = enc.forward(x.to(dev)).cpu()
