@@ -96,6 +96,49 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
     }
   };
 
+  // epilogue rows, and the epilogue's global operands (bias, residual / pos-embed): fetched right after
+  // the LAST stage's barrier, where the DMA queue is empty, so they land under that stage's MFMAs
+  bool mok[2];
+  int64_t orow[2];
+  const float* posrow[2] = {nullptr, nullptr};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int m = m0 + wm * 64 + j * 32 + r31;
+    mok[j] = m < g.M;
+    m = mok[j] ? m : g.M - 1;
+    orow[j] = m;
+    if constexpr (EPI == EPI_PATCH) {
+      const int img = m / g.P, p = m - img * g.P;
+      orow[j] = (int64_t)img * (g.P + 1) + 1 + p;
+      posrow[j] = g.pos + (int64_t)(1 + p) * g.N;
+    }
+  }
+  constexpr bool kAdd = (EPI == EPI_BIAS_RESID || EPI == EPI_PATCH);
+  f32x4 bv[2][4];
+  f32x4 rv[kAdd ? 2 : 1][2][4];
+  auto fetch_epilogue = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * half);
+    if constexpr (kAdd) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+            if constexpr (EPI == EPI_BIAS_RESID) {
+              const char* rp = g.blk_out ? reinterpret_cast<const char*>(g.resid) + blk_off(orow[j], n >> 2, g.N >> 2)
+                                         : reinterpret_cast<const char*>(g.resid + orow[j] * g.ldr + n);
+              rv[i][j][q] = *reinterpret_cast<const f32x4*>(rp);
+            }
+            else rv[i][j][q] = *reinterpret_cast<const f32x4*>(posrow[j] + n);
+          }
+    }
+  };
+
   for (int s = 0; s < nst; ++s) {
     // stage s has landed for this wave's own pieces (stage s+1 may stay in flight) ...
     if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -104,6 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue(s + 2);
+    if (s + 1 == nst) fetch_epilogue();
     const char* st = smem + (s % G2RING) * G2STAGE;
     V8 wa[2], xa[2], wb[2], xb[2];
     load_f(wa, xa, st, 0);
@@ -128,44 +172,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
 #if EFFOCR_EXP == 12
   if (acc[0][0][0] != 12345.f) return;     // experiment: no epilogue traffic
 #endif
-  // ---- epilogue (all loads before the first store: out may alias resid)
+  // ---- epilogue (every load was issued in fetch_epilogue, before the first store: out may alias resid)
   TO* out = static_cast<TO*>(g.out);
-  f32x4 bv[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * half);
-  bool mok[2];
-  int64_t orow[2];
-  const float* posrow[2] = {nullptr, nullptr};
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int m = m0 + wm * 64 + j * 32 + r31;
-    mok[j] = m < g.M;
-    m = mok[j] ? m : g.M - 1;
-    orow[j] = m;
-    if constexpr (EPI == EPI_PATCH) {
-      const int img = m / g.P, p = m - img * g.P;
-      orow[j] = (int64_t)img * (g.P + 1) + 1 + p;
-      posrow[j] = g.pos + (int64_t)(1 + p) * g.N;
-    }
-  }
-  if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_PATCH) {
-    f32x4 rv[2][2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
-          if constexpr (EPI == EPI_BIAS_RESID) {
-            const char* rp = g.blk_out ? reinterpret_cast<const char*>(g.resid) + blk_off(orow[j], n >> 2, g.N >> 2)
-                                       : reinterpret_cast<const char*>(g.resid + orow[j] * g.ldr + n);
-            rv[i][j][q] = *reinterpret_cast<const f32x4*>(rp);
-          }
-          else rv[i][j][q] = *reinterpret_cast<const f32x4*>(posrow[j] + n);
-        }
+  if constexpr (kAdd) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll

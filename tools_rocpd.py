@@ -9,7 +9,8 @@ import json, os, re, sqlite3, sys
 
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
     ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
-    ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm_nt_kernelIDF16bLi2", "gemm_fc2_resid"),
+    ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm2_kernelIDF16bLi2", "gemm_fc2_resid"),
+    ("gemm2_kernelIDF16bLi3", "gemm_patch_embed"), ("gemm_nt_kernelIDF16bLi2", "gemm_fc2_resid"),
     ("gemm_nt_kernelIDF16bLi3", "gemm_patch_embed"), ("attn_mfma_kernel", "attention"), ("knn_partial", "knn_partial"),
     ("knn_merge", "knn_merge"), ("im2col16", "im2col_patch16"), ("cls_norm", "final_cls_norm"), ("layernorm_kernel", "layernorm"),
 ]
@@ -18,8 +19,8 @@ def cls(name):
     for sub, c in CLASSES:
         if sub in name:
             return c
-    if "gemm_nt_kernel<" in name:
-        return "gemm_fc2_resid"       # the only demangled gemm_nt instantiation on the bf16 ViT-S path
+    if "gemm2_kernel<" in name or "gemm_nt_kernel<" in name:
+        return "gemm_fc2_resid"       # rocprof half-demangles exactly one instantiation: the bf16 RESID one (fc2)
     return re.sub(r"_ZN6effocr12_GLOBAL__N_1\d*", "", name)[:48]
 
 def stats(db, out):
