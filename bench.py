@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--index-rows", type=int, default=10000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--chunk", type=int, default=0, help="encoder sub-batch (crops); 0 = library default")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="library option (set_option) for A/B runs, e.g. tail_split=0")
     ap.add_argument("--panel-impl", type=int, default=-1, help="1 token-stationary (default), 0 LDS-panel kernel")
     ap.add_argument("--panel-rows", type=int, default=0, help="row-panel height 64|128 (0 = library default)")
     ap.add_argument("--no-panel", action="store_true", help="A/B: K-streaming GEMM + standalone LayerNorm path")
@@ -135,6 +136,9 @@ def main():
         enc.set_option("debug", int(os.environ["EFFOCR_DEBUG"]))
     if a.panel_rows:
         enc.set_option("panel_rows", a.panel_rows)
+    for kv in a.opt:
+        name, _, val = kv.partition("=")
+        enc.set_option(name, int(val))
     if os.environ.get("EFFOCR_NO_BLOCKED"):
         enc.set_option("use_blocked", 0)
     if os.environ.get("EFFOCR_NO_GEMM2"):

@@ -55,6 +55,7 @@ struct effocr_encoder {
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
+  int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
   int panel_impl = 0;               // 0: LDS-panel panel.hip (default, faster), 1: token-stationary panelr.hip (experiment)
@@ -321,17 +322,17 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       // row-panel kernels: LayerNorm fused into the A-panel load, no xn buffer, no LayerNorm launches
       PanelArgs p{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
-      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
-      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.blk_a = blk; p.blk_out = blk;
+      p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split; p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s) : panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
       p = PanelArgs{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
-      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows;
+      p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
     } else {
@@ -524,6 +525,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "panel_impl") { enc->panel_impl = value; return EFFOCR_OK; }
   if (n == "use_gemm2") { enc->use_gemm2 = value; return EFFOCR_OK; }
   if (n == "use_blocked") { enc->use_blocked = value; return EFFOCR_OK; }
+  if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");

@@ -45,6 +45,8 @@ struct PanelArgs {
   int blk_out;                      // out (and resid) are fragment-blocked
   int panel_rows;                   // 128 (one workgroup per CU) or 64 (two); 0 = default
   int rows_padded;                  // out / resid buffers are addressable up to the next multiple of 128 rows
+  int no_tail_split;                // 1: one workgroup per panel even in the last, partially filled round (A/B switch)
+  int tail_first, tail_split;       // set by the launcher: panels >= tail_first are cut along N into tail_split workgroups
 };
 bool panel_gemm_supported(int prec, int N, int K);
 int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);

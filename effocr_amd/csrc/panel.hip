@@ -99,10 +99,20 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int wv = wave_id();
   const int wn = (BMT == 128) ? (wv >> 1) : wv, wm = (BMT == 128) ? (wv & 1) : 0;
-  const int m0 = blockIdx.x * PBM;
-  const int niter = a.N / PNT;
+  // Tail split: 1 workgroup/CU and ceil(M/PBM) panels rarely fill the last round of CUs, so the panels of
+  // that round (index >= tail_first) are cut along N into tail_split workgroups of niter/tail_split sweep
+  // steps each (each repeats the cheap prologue); they have the highest block ids = dispatched last.
+  int panel = blockIdx.x, niter = a.N / PNT, it_lo = 0;
+  if (a.tail_split > 1 && panel >= a.tail_first) {
+    const int t = panel - a.tail_first;
+    panel = a.tail_first + t / a.tail_split;
+    niter /= a.tail_split;
+    it_lo = (t - (t / a.tail_split) * a.tail_split) * niter;
+  }
+  const int m0 = panel * PBM;
+  const int nlo = it_lo * PNT;                           // first output column of this workgroup
   const int S = niter * NKS;
-  const char* Wb = static_cast<const char*>(a.W);
+  const char* Wb = static_cast<const char*>(a.W) + (size_t)nlo * KD * 2;
 
   // ---- W ring fill: stage s = (sweep step it, k-stage ks); 2 x 1 KB DMA pieces per wave.  Lane-linear
   // LDS image -> the bank swizzle goes on the SOURCE address: 128-B rows: chunk ^= (row>>1)&7, 64-B rows:
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 #endif
   issue_w(0, 0);
   issue_w(1, 1);
-  for (int n = tid; n < a.N; n += NT) sBias[n] = a.bias[n];
+  for (int n = tid; n < niter * PNT; n += NT) sBias[n] = a.bias[nlo + n];
 
   // ---- A panel
   if constexpr (PRO == PRO_LN) {
@@ -260,6 +270,8 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
     }
   }
   const uint32_t colstep = a.blk_out ? 512u / (16 / (uint32_t)sizeof(TO)) * 1u : (uint32_t)sizeof(TO);   // bytes per column element step (in units of 1 element, for multiples of the chunk)
+  prow[0] += (uint32_t)nlo * colstep;
+  prow[1] += (uint32_t)nlo * colstep;
 
   // MFMA operand fragments.  W rows are the A-operand, tokens the B-operand.  W fragments of a whole
   // stage (4 k16 steps) are fetched one stage ahead (that frees the ring slot at the next barrier);
@@ -299,7 +311,13 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[g * 4 + e] = acc[j][4 * q + e] + bv[e];
     }
-    if constexpr (EPI == EPI_BIAS_GELU) gelu_erf_fast_n<NG * 4>(v);
+    if constexpr (EPI == EPI_BIAS_GELU) {
+      // same argument rounding as the parked path below: every column's result is then independent of
+      // which sweep step was the workgroup's last (tail split, batch size) -> bitwise batch invariance
+#pragma unroll
+      for (int e = 0; e < NG * 4; ++e) v[e] = (float)(E)v[e];
+      gelu_erf_fast_n<NG * 4>(v);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       TO* p = group_ptr(g, n0);
@@ -448,8 +466,8 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const char* rp = a.blk_out ? reinterpret_cast<const char*>(a.resid) + blk_off(mrow[j], (n0 + 8 * q + 4 * half) >> 2, (int)(a.ldr >> 2))
-                                     : reinterpret_cast<const char*>(a.resid + (int64_t)mrow[j] * a.ldr + n0 + 8 * q + 4 * half);
+          const char* rp = a.blk_out ? reinterpret_cast<const char*>(a.resid) + blk_off(mrow[j], (nlo + n0 + 8 * q + 4 * half) >> 2, (int)(a.ldr >> 2))
+                                     : reinterpret_cast<const char*>(a.resid + (int64_t)mrow[j] * a.ldr + nlo + n0 + 8 * q + 4 * half);
           rv[j][q] = *reinterpret_cast<const f32x4*>(rp);
         }
 #pragma unroll
@@ -470,9 +488,32 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 #endif
 }
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
 template <typename E, int KD, bool FULL, int BMT>
-int launch_panel(int pro, int epi, const PanelArgs& a, hipStream_t s) {
-  const dim3 grid((unsigned)((a.M + BMT - 1) / BMT)), blk(Geo<BMT>::THREADS);
+int launch_panel(int pro, int epi, const PanelArgs& a_in, hipStream_t s) {
+  PanelArgs a = a_in;
+  const int npanels = (a.M + BMT - 1) / BMT, niter = a.N / PNT;
+  const int slots = num_cus() * (BMT == 128 ? 1 : 2);    // resident workgroups (LDS-limited)
+  const int tail = npanels % slots;
+  a.tail_first = npanels;
+  a.tail_split = 1;
+  if (!a.no_tail_split && tail > 0) {
+    int split = 1;
+    for (int d = 2; d <= niter && d * tail <= slots; ++d)
+      if (niter % d == 0) split = d;
+    a.tail_first = npanels - tail;
+    a.tail_split = split;
+  }
+  const dim3 grid((unsigned)(a.tail_first + (npanels - a.tail_first) * a.tail_split)), blk(Geo<BMT>::THREADS);
 #define EFFOCR_PANEL(P, EP, TOUT) hipLaunchKernelGGL((panel_gemm_kernel<E, KD, P, EP, TOUT, FULL, BMT>), grid, blk, 0, s, a)
   if (pro == PRO_LN) {
     switch (epi) {
