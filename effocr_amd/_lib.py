@@ -65,6 +65,8 @@ def _declare(lib):
         "effocr_knn_ip_topk": (i32, [f32p, i64, f32p, i64, i32, i32, f32p, i64p, vp, sz, vp]),
         "effocr_l2_normalize": (i32, [f32p, i64, i32, f32p, vp]),
         "effocr_gather_rows": (i32, [f32p, i64p, i64, i32, f32p, vp]),
+        "effocr_crop_transform": (i32, [vp, i32, i32, i64, vp, i32, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),
+                                        c.POINTER(c.c_float), f32p, vp]),
         "effocr_op_linear": (i32, [i32, i32, vp, vp, f32p, f32p, vp, i32, i32, i32, vp]),
         "effocr_op_layernorm": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
         "effocr_op_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),

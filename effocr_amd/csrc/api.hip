@@ -612,6 +612,16 @@ int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void
   return l2_normalize_rows(x_dev, n, d, y_dev, S(stream));
 }
 
+int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64_t row_stride, const int32_t* boxes_dev,
+                          int n, int size, int antialias, const float* mean, const float* stdv, const float* fill,
+                          float* out_dev, void* stream) {
+  if (n < 0 || height <= 0 || width <= 0 || row_stride < (int64_t)3 * width) return fail(EFFOCR_EINVAL, "crop_transform: bad image geometry");
+  if (n > 0 && (!image_dev || !boxes_dev || !out_dev || !mean || !stdv || !fill)) return fail(EFFOCR_EINVAL, "crop_transform: NULL pointer");
+  for (int c = 0; c < 3 && n > 0; ++c)
+    if (!(stdv[c] != 0.f)) return fail(EFFOCR_EINVAL, "crop_transform: std must be non-zero");
+  return crop_transform(image_dev, height, width, row_stride, boxes_dev, n, size, antialias, mean, stdv, fill, out_dev, S(stream));
+}
+
 int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64_t n_keep, int d, float* dst_dev, void* stream) {
   if (n_keep > 0 && (!src_dev || !keep_rows_dev || !dst_dev)) return fail(EFFOCR_EINVAL, "gather_rows: NULL device pointer");
   return gather_rows(src_dev, keep_rows_dev, n_keep, d, dst_dev, S(stream));

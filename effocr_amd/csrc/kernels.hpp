@@ -69,6 +69,10 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
 int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s);
 int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);
 
+// transform.hip — create_paired_transform over a box list (crop, pad to square, /255, bilinear resize, normalise)
+int crop_transform(const uint8_t* img, int H, int W, int64_t stride, const int* boxes, int n, int S, int antialias,
+                   const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s);
+
 // resnet.hip
 struct ConvArgs {
   const float* in;      // NHWC fp32 [B,H,W,Cin]

@@ -94,6 +94,22 @@ class Recognizer:
         _, indices = self.neighbors(crops)
         return indices_to_chars(indices, self.candidate_chars)
 
+    def recognize_boxes(self, image, char_bboxes, char_transform=None):
+        """infer_effocr.py:281-319 with the crop loop moved to the device: `image` is the HWC uint8 page /
+        line image, `char_bboxes` the localizer's (x0,y0,x1,y1[,score]) rows.  One uint8 upload, then
+        crop + pad + resize + normalise (effocr_crop_transform), encode, normalise, top-k — no per-crop
+        PCIe traffic.  Returns (nearest_chars, output_nns, output) as `EffOCR.infer` builds them
+        (:319, :337-338): list[B] of list[k] of str, list[B] of str, str."""
+        from .transforms import PairedTransform
+        if char_transform is None:
+            enc = self.recongizer_encoder
+            size = getattr(enc, "img_size", None) or getattr(getattr(enc, "_engine", None), "img_size", 224)
+            char_transform = PairedTransform(size=size)
+        crops = char_transform.boxes(image, char_bboxes)
+        if crops.shape[0] == 0:
+            return [], [], ""                                       # "No content detected!" (infer_effocr.py:304-306)
+        return self(crops)
+
 
 def run_recognizer_batches(char_crops, recognizer_engine, knn_func, candidate_chars, normalize=None):
     """Recognizer phase of ``run_effocr`` (infer_effocr_onnx_multi.py:347-375) without the thread

@@ -119,6 +119,23 @@ int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64
                        float* dst_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Crop pre-processing: `create_paired_transform(size)` applied to every box of one
+ * page / line image — utils/datasets_utils.py:69-90 (MedianPad(override) = pad right/bottom to a
+ * square), :166-172 (ToTensor, Resize((size,size)), Normalize); per-box call site
+ * infer_effocr.py:286-293, infer_effocr_onnx_multi.py:326-345.
+ *   image_dev  uint8 HWC RGB, `row_stride` bytes between rows (>= 3*width)
+ *   boxes_dev  int32 [n,4] = x0,y0,x1,y1 exactly as numpy slicing im[y0:y1, x0:x1] resolves them
+ *              (0 <= x0 < x1 <= width, 0 <= y0 < y1 <= height; the host wrapper rejects empty boxes
+ *              with ValueError like PIL does); an invalid box yields a zero crop, never a bad read
+ *   antialias  torchvision's tensor Resize default: 1 from 0.17 on, 0 before
+ *   mean/std/fill  3 host floats each (ImageNet mean/std, pad colour on the 0..255 scale)
+ *   out_dev    fp32 [n,3,size,size] (the encoder's input layout); size % 4 == 0, n <= 65535
+ * ------------------------------------------------------------------------------------------ */
+int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64_t row_stride,
+                          const int32_t* boxes_dev, int n, int size, int antialias, const float* mean,
+                          const float* std, const float* fill, float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Individual encoder operators (exported so that each kernel is parity-tested on its own).
  * Operand buffers are in `precision`'s element type unless stated fp32.
  * ------------------------------------------------------------------------------------------ */

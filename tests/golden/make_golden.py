@@ -12,6 +12,9 @@ Files (all small .npz):
   knn_c2small.npz     Q [32,384], X [1000,384] (unit rows), k=10: D, I  (C oracle, ascending-k fmaf)
   knn_ties.npz        exact-duplicate rows: pins the "lower id wins" rule
   pipeline.npz        create_batches case (70 crops, one None) + blacklist/compaction case
+  crop_transform.npz  image [48,80,3] u8, boxes [6,4] (python-slice semantics incl. negative / oversize), size 32:
+                      out_aa, out_plain [6,3,32,32] f32 (numpy restatement asserted equal to torch's
+                      interpolate first).  `python make_golden.py crop` regenerates only this file.
 """
 import os
 import sys
@@ -26,6 +29,25 @@ from effocr_amd.weights import init_state_dict          # noqa: E402
 from oracle import knn_ref                               # noqa: E402
 from oracle.encoders_ref import encoder_forward          # noqa: E402
 from oracle.hf_crosscheck import hf_encoder_forward      # noqa: E402
+from oracle import crop_transform_ref                    # noqa: E402
+
+
+def crop_golden():
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:48, 0:80]
+    img = 190 + 50 * np.sin(xx / 5.0)[..., None] * np.cos(yy / 3.0)[..., None] + rng.normal(0, 12, (48, 80, 3))
+    img[10:40, 20:24] = 15
+    img[22:26, 8:70] = 40
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    boxes = np.array([[2, 3, 30, 45], [0, 0, 80, 48], [50, 10, 57, 40], [5, 20, 75, 27], [-20, 4, 80, 44], [60, -8, 200, 100]], np.int32)
+    outs = {}
+    for aa in (True, False):
+        a = crop_transform_ref.transform_boxes(img, boxes, size=32, antialias=aa, use_torch=True)
+        b = crop_transform_ref.transform_boxes(img, boxes, size=32, antialias=aa, use_torch=False)
+        assert np.abs(a - b).max() <= (1e-5 if aa else 2e-4), (aa, np.abs(a - b).max())
+        outs["out_aa" if aa else "out_plain"] = a
+    np.savez_compressed(os.path.join(HERE, "crop_transform.npz"), image=img, boxes=boxes, size=32, **outs)
+    print("crop_transform", outs["out_aa"].shape)
 
 
 def unit(a):
@@ -33,6 +55,9 @@ def unit(a):
 
 
 def main():
+    crop_golden()
+    if sys.argv[1:] == ["crop"]:
+        return
     for arch, img, B, seed in [("resnet18", 32, 8, 11), ("vit_tiny_test", 64, 4, 12),
                                ("vit_small_patch16_224", 224, 4, 13), ("vit_base_patch16_224", 224, 2, 14)]:
         sd = init_state_dict(arch, seed=seed, img_size=img)

@@ -141,3 +141,18 @@ def test_product_package_never_imports_the_oracle():
     for p in root.rglob("*.py"):
         src = p.read_text()
         assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_transform_box_resolution_matches_numpy_slicing():
+    """effocr_amd.transforms.slice_boxes / round_boxes (host side of the device crop transform)."""
+    from effocr_amd.transforms import round_boxes, slice_boxes
+    im = np.zeros((30, 50, 3), np.uint8)
+    boxes = [(1, 2, 45, 29), (-10, 0, 50, 30), (0, -5, 80, 90), (49, 29, 50, 30)]
+    ib = slice_boxes(boxes, 30, 50)
+    for (x0, y0, x1, y1), b in zip(ib, boxes):
+        assert im[y0:y1, x0:x1].shape == im[b[1]:b[3], b[0]:b[2]].shape
+    assert ib.dtype == np.int32
+    for bad in [(5, 5, 5, 9), (9, 5, 3, 9), (60, 0, 70, 10), (0, 0, 10, -40)]:
+        with pytest.raises(ValueError):
+            slice_boxes([bad], 30, 50)
+    assert round_boxes([(0.5, 1.5, 2.5, 3.49, 0.9)]) == [(0, 2, 2, 3)]

@@ -98,3 +98,39 @@ def test_remove_ids_compaction_oracle():
     X = np.arange(40, dtype=np.float32).reshape(10, 4)
     Y = knn_ref.remove_ids(X, [0, 7, 3])
     assert Y.shape == (7, 4) and Y[0, 0] == 4 and Y[2, 0] == 16 and Y[-1, 0] == 36      # rows 1,2,4,5,6,8,9 survive
+
+
+# ---------------------------------------------------------------- crop pre-processing
+def test_crop_transform_restatement_matches_torch_and_golden():
+    from oracle import crop_transform_ref as R
+    g = load("crop_transform.npz")
+    img, boxes, size = g["image"], g["boxes"], int(g["size"])
+    for aa, key in ((True, "out_aa"), (False, "out_plain")):
+        via_torch = R.transform_boxes(img, boxes, size=size, antialias=aa, use_torch=True)
+        via_numpy = R.transform_boxes(img, boxes, size=size, antialias=aa, use_torch=False)
+        assert np.abs(via_torch - g[key]).max() <= 1e-6          # golden = torch path of the build container
+        assert np.abs(via_numpy - g[key]).max() <= (1e-5 if aa else 2e-4)
+
+
+@pytest.mark.parametrize("hw", [(17, 23), (224, 224), (300, 120), (1, 1), (3, 500), (448, 448)])
+def test_resize_weights_against_torch_interpolate(hw):
+    from oracle import crop_transform_ref as R
+    crop = np.random.default_rng(hw[0]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    x = R.pad_square_to_float(crop)
+    assert x.shape == (3, max(hw), max(hw)) and x[:, -1, -1].min() == 1.0 or hw[0] == hw[1]
+    for aa in (True, False):
+        a, b = R.resize_bilinear(x, 64, aa), R.resize_bilinear_torch(x, 64, aa)
+        assert np.abs(a - b).max() <= (1e-6 if aa else 4e-6 * max(hw) + 1e-6)
+    s, w, c = R.resize_weights(max(hw), 64, True)
+    assert np.allclose(w.sum(1), 1.0, atol=1e-6) and (s >= 0).all() and (s + c <= max(hw)).all()
+
+
+def test_python_slice_box_semantics():
+    from oracle import crop_transform_ref as R
+    im = np.arange(6 * 9 * 3, dtype=np.uint8).reshape(6, 9, 3)
+    for box in [(1, 2, 5, 4), (-3, 0, 9, 6), (0, -2, 20, 30), (7, 1, 3, 5), (2, 2, 2, 5)]:
+        x0, y0, x1, y1 = R.python_slice_box(box, 6, 9)
+        assert np.array_equal(im[y0:y1, x0:x1], im[box[1]:box[3], box[0]:box[2]])
+    assert R.round_box((0.5, 1.5, 2.5, 3.49)) == (0, 2, 2, 3)     # Python round: half to even
+    with pytest.raises(ValueError):
+        R.pad_square_to_float(im[2:2])
