@@ -29,7 +29,8 @@ namespace {
 struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std::vector<float> data; bool set; };
 
 struct VitCfg { int D, depth, heads, mlp; };
-struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w; };
+struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w;
+                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b; };   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
 struct ConvSpec { std::string w, bn; int cin, cout, k, stride, pad; size_t w_off, b_off; };
 
 }  // namespace
@@ -55,6 +56,7 @@ struct effocr_encoder {
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
+  int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
@@ -138,6 +140,17 @@ void build_vit(effocr_encoder* e) {
     L.fc1w = a.take((size_t)mlp * D * es);
     L.fc2w = a.take((size_t)D * mlp * es);
   }
+  if (e->prec != PREC_FP32) {
+    for (int i = 0; i < depth; ++i) {
+      VitLayerOff& L = e->layers[i];
+      L.fc2w_b = a.take((size_t)D * mlp * es);
+      if (D != 384 && D != 128) {                        // no row-panel kernels at this width: gemm3 runs every linear
+        L.qkvw_b = a.take((size_t)3 * D * D * es);
+        L.projw_b = a.take((size_t)D * D * es);
+        L.fc1w_b = a.take((size_t)mlp * D * es);
+      }
+    }
+  }
   e->wbytes = a.off;
 }
 
@@ -196,6 +209,20 @@ void put_op(std::vector<char>& blob, size_t off, const float* src, size_t n, int
   else for (size_t i = 0; i < n; ++i) d[i] = f32_to_f16(src[i]);
 }
 
+// [N,K] fp32 -> 16-bit fragment-blocked [N/32][K/8][32 rows][8 elements] (common.hpp blk_off); N % 32 == 0, K % 8 == 0
+void put_op_blocked(std::vector<char>& blob, size_t off, const float* src, int N, int K, int prec) {
+  uint16_t* d = reinterpret_cast<uint16_t*>(blob.data() + off);
+  const int kch = K / 8;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < kch; ++c) {
+      uint16_t* cell = d + ((size_t)(n >> 5) * kch + c) * 256 + (n & 31) * 8;
+      for (int e = 0; e < 8; ++e) {
+        const float v = src[(size_t)n * K + c * 8 + e];
+        cell[e] = prec == PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+      }
+    }
+}
+
 const std::vector<float>& P(const effocr_encoder* e, const std::string& n) { return e->params[e->index.at(n)].data; }
 
 void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
@@ -222,6 +249,14 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
     put_op(blob, L.projw, P(e, p + "attn.proj.weight").data(), (size_t)D * D, e->prec);
     put_op(blob, L.fc1w, P(e, p + "mlp.fc1.weight").data(), (size_t)e->vit.mlp * D, e->prec);
     put_op(blob, L.fc2w, P(e, p + "mlp.fc2.weight").data(), (size_t)D * e->vit.mlp, e->prec);
+    if (e->prec != PREC_FP32) {
+      put_op_blocked(blob, L.fc2w_b, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec);
+      if (D != 384 && D != 128) {
+        put_op_blocked(blob, L.qkvw_b, P(e, p + "attn.qkv.weight").data(), 3 * D, D, e->prec);
+        put_op_blocked(blob, L.projw_b, P(e, p + "attn.proj.weight").data(), D, D, e->prec);
+        put_op_blocked(blob, L.fc1w_b, P(e, p + "mlp.fc1.weight").data(), e->vit.mlp, D, e->prec);
+      }
+    }
   }
   put_f32(blob, e->off_normw, P(e, "norm.weight").data(), D);
   put_f32(blob, e->off_normb, P(e, "norm.bias").data(), D);
@@ -281,11 +316,12 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
   return rc;
 }
 
-struct VitWs { size_t x, xn, qkv, att, h, total; };
+struct VitWs { size_t x, xn, qkv, att, h, total, rows; };
 VitWs vit_ws(const effocr_encoder* e, int B) {
   // rows padded to the panel height (128) so that the row-panel kernels store without bounds checks
   const size_t M = align_up((size_t)B * e->T, 128), D = e->vit.D, es = prec_esize(e->prec);
   Alloc a; VitWs w;
+  w.rows = M;
   w.x = a.take(M * D * 4);
   w.xn = a.take(M * D * es);
   w.qkv = a.take(M * 3 * D * es);
@@ -310,6 +346,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool g2p = e->use_gemm2 && gemm2_supported(prec, D, 768);
   // fragment-blocked activations (x fp32, qkv, attention output, MLP hidden) need every producer/consumer on the fast path
   const int blk = (e->use_blocked && panel && g2 && g2p && e->panel_impl == 0) ? 1 : 0;
+  const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
   GemmArgs g{};
@@ -355,7 +392,9 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     g = GemmArgs{};
     g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
     g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp; g.blk_x = blk; g.blk_out = blk;
-    if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] { return g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
+    g.Wblk = wb + L.fc2w_b; g.rows_alloc = (int)w.rows;
+    if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] {
+          return g3 ? gemm3_nt(prec, EPI_BIAS_RESID, g, s) : g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }
   return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, blk, emb, s); });
 }
@@ -526,6 +565,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "use_gemm2") { enc->use_gemm2 = value; return EFFOCR_OK; }
   if (n == "use_blocked") { enc->use_blocked = value; return EFFOCR_OK; }
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
+  if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");

@@ -20,6 +20,8 @@ struct GemmArgs {
   int P;                            // EPI_PATCH: patches per image
   int blk_x;                        // gemm2: X operand is fragment-blocked (16-B chunks of 8 elements)
   int blk_out;                      // gemm2: out / resid (fp32, chunks of 4) are fragment-blocked
+  const void* Wblk;                 // gemm3: W in the fragment-blocked layout [N/32][K/8][32][16 B]
+  int rows_alloc;                   // gemm3: rows addressable in X / out / resid (multiple of 32; 0 = round M up)
 };
 
 // gemm.hip
@@ -28,6 +30,10 @@ int gemm_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 // gemm2.hip — K-streaming GEMM with a glds ring for both operands (long K: mlp.fc2, patch embedding)
 bool gemm2_supported(int prec, int N, int K);
 int gemm2_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
+
+// gemm3.hip — 256 x {192,256} tiles, 128-row wave tiles, all operands fragment-blocked (fc2; every ViT-B linear)
+bool gemm3_supported(int prec, int N, int K);
+int gemm3_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 
 // panel.hip — row-panel GEMM with optional fused LayerNorm prologue (K = embed dim)
 enum { PRO_COPY = 0, PRO_LN = 1 };
