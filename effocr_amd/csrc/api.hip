@@ -392,7 +392,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     g = GemmArgs{};
     g.X = hb; g.ldx = e->vit.mlp; g.W = wb + L.fc2w; g.ldw = e->vit.mlp; g.bias = F(L.fc2b); g.out = xs; g.ldo = D;
     g.resid = xs; g.ldr = D; g.M = M; g.N = D; g.K = e->vit.mlp; g.blk_x = blk; g.blk_out = blk;
-    g.Wblk = wb + L.fc2w_b; g.rows_alloc = (int)w.rows;
+    g.Wblk = wb + L.fc2w_b; g.rows_alloc = (int)w.rows; g.no_tail_split = !e->tail_split;
     if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] {
           return g3 ? gemm3_nt(prec, EPI_BIAS_RESID, g, s) : g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }

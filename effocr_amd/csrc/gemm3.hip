@@ -17,15 +17,36 @@
 //   * MFMA issued swapped (A-operand = W rows): a lane owns 4 consecutive features of one token.
 #include "common.hpp"
 #include "kernels.hpp"
+#include <type_traits>
+
+#ifndef EFFOCR_EXP
+#define EFFOCR_EXP 0
+#endif
+// timing experiments (never shipped): -DEFFOCR_EXP=1000+bits; 1 no epilogue, 2 no MFMA, 4 no DMA after the prologue,
+// 8 X from an L2-resident window, 16 no barrier, 32 no vmcnt wait, 64 no fragment reads
+#if EFFOCR_EXP >= 1000
+#define G3X (EFFOCR_EXP - 1000)
+#else
+#define G3X 0
+#endif
 
 namespace effocr {
 namespace {
 
-constexpr int G3M = 256, G3RING = 4;
+constexpr int G3RING = 4;
 
-template <typename E, int NT, int EPI, typename TO>
-__global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
-  constexpr int TN = NT * 64;
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// JT = 32-token tiles per wave: 4 (256-token workgroup tile, the main launch) or 1 / 2 (64 / 128-token tiles
+// for the leftover token tiles of the last, partially filled round of CUs — see gemm3_nt)
+template <typename E, int NT, int JT, int EPI, typename TO>
+__global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs g) {
+  constexpr int TN = NT * 64, G3M = JT * 64;
   constexpr int XS = G3M * 64, WS = TN * 64, STAGE = XS + WS;          // bytes per 32-k stage
   constexpr int PX = XS / 1024, PW = WS / 1024, PP = (PX + PW) / 4;    // 1 KB DMA pieces: X, W, per wave
   static_assert((PX + PW) % 4 == 0, "pieces must split evenly over 4 waves");
@@ -41,6 +62,12 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
   const int kch = g.K >> 3;                                            // 16-byte chunks per operand row
   const int last_rb = (g.rows_alloc >> 5) - 1;                         // last addressable X row block
 
+#if EFFOCR_EXP >= 26 && EFFOCR_EXP <= 28
+  // experiment: stagger half of the first round's workgroups by ~(EXP-25)/4 of a tile
+  if (JT == 4 && blockIdx.x < 256 && (blockIdx.x & 8)) {
+    for (int i = 0; i < (EFFOCR_EXP - 25) * 3; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   // per-lane DMA sources; piece q (1 KB = two adjacent 16-B chunk cells of one 32-row block) lands at q KB
   const char* src[PP];
 #pragma unroll
@@ -49,69 +76,116 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
     if (q < PX) {
       int rb = (m0 >> 5) + (q >> 1);
       rb = rb < last_rb ? rb : last_rb;                                // rows past the buffer: any valid block
+#if (G3X & 8)
+      rb &= 31;                                                        // experiment: X from a 3 MB window (L2 resident)
+#endif
       src[i] = static_cast<const char*>(g.X) + ((size_t)rb * kch + 2 * (q & 1)) * 512 + lane * 16;
     } else {
       const int qq = q - PX;
       src[i] = static_cast<const char*>(g.Wblk) + ((size_t)((n0 >> 5) + (qq >> 1)) * kch + 2 * (qq & 1)) * 512 + lane * 16;
     }
   }
-  auto issue = [&](int s) {
-    if (s >= nst) return;
+  auto issue_piece = [&](int s, int i) {                   // DMA piece i of stage s (caller checks s < nst)
     char* dst = smem + (s & (G3RING - 1)) * STAGE + wv * PP * 1024;
-#pragma unroll
-    for (int i = 0; i < PP; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * 2048),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * 2048),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
   };
-  issue(0); issue(1); issue(2); issue(3);
+#pragma unroll
+  for (int s = 0; s < G3RING; ++s)
+    if (s < nst) {
+#pragma unroll
+      for (int i = 0; i < PP; ++i) issue_piece(s, i);
+    }
 
-  f32x16 acc[NT][4];                                                   // [feature tile][token tile]
+  f32x16 acc[NT][JT];                                                  // [feature tile][token tile]
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int xo = (wm * 16 + half) * 512 + r31 * 16;                    // (row block wm*4 + j, chunk 2*c4 + half)
+  const int xo = (wm * JT * 4 + half) * 512 + r31 * 16;                // (row block wm*JT + j, chunk 2*c4 + half)
   const int wo = XS + (wn * NT * 4 + half) * 512 + r31 * 16;
-  struct Frags { V8 w[NT]; V8 x[4]; };
-  auto load_f = [&](Frags& f, const char* st, int c4) {
-#pragma unroll
-    for (int i = 0; i < NT; ++i) f.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 4 + 2 * c4) * 512);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) f.x[j] = *reinterpret_cast<const V8*>(st + xo + (j * 4 + 2 * c4) * 512);
+  struct Frags { V8 w[NT]; V8 x[JT]; };
+  constexpr int NF = NT + JT, NMM = NT * JT;                           // fragment reads / MFMAs per k16 step
+  // fragment n of a k16 step: n < NT -> W tile n, else token tile n - NT
+  auto load_one = [&](Frags& f, const char* st, int c4, auto N_) {
+    constexpr int n = decltype(N_)::value;
+#if (G3X & 64)
+    if (st == nullptr)
+#endif
+    if constexpr (n < NT) f.w[n] = *reinterpret_cast<const V8*>(st + wo + (n * 4 + 2 * c4) * 512);
+    else f.x[n - NT] = *reinterpret_cast<const V8*>(st + xo + ((n - NT) * 4 + 2 * c4) * 512);
   };
-  auto mma = [&](const Frags& f) {
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = Op16<E>::mfma(f.w[i], f.x[j], acc[i][j]);
+  // One k16 step: MFMA n = (feature tile n / JT, token tile n % JT); `between(n)` is issued in its shadow
+  // (with one wave per SIMD, whatever sits between two MFMAs instead of under one idles the matrix pipe).
+  auto mma_step = [&](const Frags& f, auto&& between) {
+    static_for<0, NMM>([&](auto N_) {
+      constexpr int n = decltype(N_)::value;
+      constexpr int i = n / JT, j = n % JT;
+#if (G3X & 2)
+      acc[i][j][n & 15] += (float)f.w[i][0] * (float)f.x[j][0];
+#else
+      acc[i][j] = Op16<E>::mfma(f.w[i], f.x[j], acc[i][j]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      between(N_);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // small tail tiles have fewer MFMAs than items to place: the rest goes after the last one
+    constexpr int NITEM = (PP > NF ? PP : NF);
+    static_for<NMM, NITEM>([&](auto N_) { between(N_); });
   };
 
   Frags fa, fb;
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PP) : "memory");        // stage 0 (own pieces) ...
   __builtin_amdgcn_s_barrier();                                        // ... and everybody's
   asm volatile("" ::: "memory");
-  load_f(fa, smem, 0);
+  static_for<0, NF>([&](auto N_) { load_one(fa, smem, 0, N_); });
 
-  for (int s = 0; s < nst; ++s) {
+  // One stage.  MORE: stage s+4 exists (DMA it), NEXT: stage s+1 exists (prefetch its fragments).  Both are
+  // compile-time so that the steady state is ONE basic block: with a single wave per SIMD every scalar
+  // branch between two MFMAs is a bubble in the matrix pipe (measured: 57% -> see profiles/README.md).
+  auto stage = [&](int s, auto MORE, auto NEXT) {
+    constexpr bool more = decltype(MORE)::value, next = decltype(NEXT)::value;
     const char* st = smem + (s & (G3RING - 1)) * STAGE;
-    load_f(fb, st, 1);
-    mma(fa);
+    const char* stn = smem + ((s + 1) & (G3RING - 1)) * STAGE;
+    // k16 step 0; the fragments of step 1 are read in its shadow
+    mma_step(fa, [&](auto N_) {
+      if constexpr (decltype(N_)::value < NF) load_one(fb, st, 1, N_);
+    });
     // stage s+1 landed (own pieces; s+2, s+3 may stay in flight), every wave holds its stage-s fragments
     // in registers -> past the barrier slot s&3 is free for stage s+4
-    if (s + 3 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
+#if !(G3X & 32)
+    if constexpr (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(G3X & 16)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
-    issue(s + 4);
-    if (s + 1 < nst) load_f(fa, smem + ((s + 1) & (G3RING - 1)) * STAGE, 0);
-    mma(fb);
+    // k16 step 1; in its shadow: DMA of stage s+4 and the fragments of stage s+1, step 0
+    mma_step(fb, [&](auto N_) {
+      constexpr int n = decltype(N_)::value;
+#if !(G3X & 4)
+      if constexpr (more && n < PP) issue_piece(s + 4, n);
+#endif
+      if constexpr (next && n < NF) load_one(fa, stn, 0, N_);
+    });
+  };
+  {
+    int s = 0;
+    for (; s + 4 < nst; ++s) stage(s, std::true_type{}, std::true_type{});
+    for (; s + 1 < nst; ++s) stage(s, std::false_type{}, std::true_type{});
+    stage(s, std::false_type{}, std::false_type{});
   }
 
-  // ---- epilogue: lane = token (m0 + wm*128 + j*32 + r31), 4 consecutive features per (i, q)
+#if (G3X & 1)
+  if (acc[0][0][0] != 12345.f) return;
+#endif
+  // ---- epilogue: lane = token (m0 + (wm*JT + j)*32 + r31), 4 consecutive features per (i, q)
   TO* out = static_cast<TO*>(g.out);
   constexpr int CH = 16 / (int)sizeof(TO);                             // elements per 16-byte output chunk
   const int nb = n0 + wn * NT * 32 + 4 * half;
@@ -121,8 +195,8 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(g.bias + nb + i * 32 + 8 * q);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 128 + j * 32 + r31;
+  for (int j = 0; j < JT; ++j) {
+    const int m = m0 + wm * JT * 32 + j * 32 + r31;
     const bool ok = m < g.M;
     const int mr = ok ? m : g.M - 1;
     if constexpr (EPI == EPI_BIAS_RESID) {
@@ -168,16 +242,59 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
   }
 }
 
-template <typename E, int NT>
-int launch3(int epi, const GemmArgs& g, hipStream_t s) {
-  const int grid = ((g.M + G3M - 1) / G3M) * (g.N / (NT * 64));
+int num_cus3() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
+template <typename E, int NT, int JT>
+int launch3_tile(int epi, const GemmArgs& g, hipStream_t s) {
+  const int grid = ((g.M + JT * 64 - 1) / (JT * 64)) * (g.N / (NT * 64));
   switch (epi) {
-    case EPI_BIAS:       hipLaunchKernelGGL((gemm3_kernel<E, NT, EPI_BIAS, E>), dim3(grid), dim3(256), 0, s, g); break;
-    case EPI_BIAS_GELU:  hipLaunchKernelGGL((gemm3_kernel<E, NT, EPI_BIAS_GELU, E>), dim3(grid), dim3(256), 0, s, g); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm3_kernel<E, NT, EPI_BIAS_RESID, float>), dim3(grid), dim3(256), 0, s, g); break;
+    case EPI_BIAS:       hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS, E>), dim3(grid), dim3(256), 0, s, g); break;
+    case EPI_BIAS_GELU:  hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_GELU, E>), dim3(grid), dim3(256), 0, s, g); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_RESID, float>), dim3(grid), dim3(256), 0, s, g); break;
     default: return fail(EFFOCR_EINVAL, "gemm3: unknown epilogue");
   }
   return check_launch("gemm3");
+}
+
+// One workgroup per CU (LDS) and ceil(M/256)*N/TN tiles rarely fill the last round of CUs.  The token tiles
+// of that round are therefore run by a second launch with 64- or 128-token tiles (4x / 2x the workgroups, a
+// fraction of the time each): rows [0, main_rows) with the big tile, the rest with the small one.
+template <typename E, int NT>
+int launch3(int epi, const GemmArgs& g, hipStream_t s) {
+  const int ntn = g.N / (NT * 64), mtiles = (g.M + 255) / 256, slots = num_cus3();
+  const int full_rounds = (mtiles * ntn) / slots;
+  int main_mt = g.no_tail_split ? mtiles : (full_rounds * slots) / ntn;   // whole token tiles inside the full rounds
+  int tail_wgs = (mtiles - main_mt) * ntn;
+  if (tail_wgs * 2 > slots) { main_mt = mtiles; tail_wgs = 0; }            // tail already fills most CUs
+  int rc = EFFOCR_OK;
+#if EFFOCR_EXP == 29
+  return launch3_tile<E, NT, 2>(epi, g, s);               // experiment: 128-token tiles, two workgroups per CU
+#endif
+  if (main_mt > 0) {
+    GemmArgs m = g;
+    m.M = main_mt * 256 < g.M ? main_mt * 256 : g.M;
+    if ((rc = launch3_tile<E, NT, 4>(epi, m, s))) return rc;
+  }
+  if (main_mt < mtiles) {
+    GemmArgs t = g;
+    const int64_t rb = (int64_t)main_mt * 8;                                // first row block of the tail
+    const int osz = epi == EPI_BIAS_RESID ? 4 : 2;
+    t.X = static_cast<const char*>(g.X) + rb * (g.K / 8) * 512;
+    t.out = static_cast<char*>(g.out) + rb * (g.N * osz / 16) * 512;
+    if (g.resid) t.resid = reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.resid) + rb * (g.N / 4) * 512);
+    t.M = g.M - main_mt * 256;
+    t.rows_alloc = g.rows_alloc - main_mt * 256;
+    rc = (tail_wgs * 4 <= slots) ? launch3_tile<E, NT, 1>(epi, t, s) : launch3_tile<E, NT, 2>(epi, t, s);
+  }
+  return rc;
 }
 
 }  // namespace

@@ -22,6 +22,7 @@ struct GemmArgs {
   int blk_out;                      // gemm2: out / resid (fp32, chunks of 4) are fragment-blocked
   const void* Wblk;                 // gemm3: W in the fragment-blocked layout [N/32][K/8][32][16 B]
   int rows_alloc;                   // gemm3: rows addressable in X / out / resid (multiple of 32; 0 = round M up)
+  int no_tail_split;                // gemm3: 1 = one launch of 256-token tiles only (A/B switch)
 };
 
 // gemm.hip
