@@ -345,7 +345,10 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool g2 = e->use_gemm2 && gemm2_supported(prec, D, e->vit.mlp);
   const bool g2p = e->use_gemm2 && gemm2_supported(prec, D, 768);
   // fragment-blocked activations (x fp32, qkv, attention output, MLP hidden) need every producer/consumer on the fast path
-  const int blk = (e->use_blocked && panel && g2 && g2p && e->panel_impl == 0) ? 1 : 0;
+  // widths without row-panel kernels (ViT-B): LayerNorm kernel + gemm3 for all four linears, everything blocked
+  const bool g3all = !panel && e->use_gemm3 && D != 384 && D != 128 && gemm3_supported(prec, 3 * D, D) && gemm3_supported(prec, D, D) &&
+                     gemm3_supported(prec, e->vit.mlp, D) && gemm3_supported(prec, D, e->vit.mlp);
+  const int blk = (e->use_blocked && g2p && ((panel && g2 && e->panel_impl == 0) || g3all)) ? 1 : 0;
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
@@ -372,6 +375,20 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
+    } else if (blk) {
+      auto lin = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi) {
+        GemmArgs q{};
+        q.X = X; q.ldx = K; q.Wblk = wb + wblk; q.bias = bias; q.out = out; q.ldo = N; q.M = M; q.N = N; q.K = K;
+        q.blk_x = 1; q.blk_out = 1; q.rows_alloc = (int)w.rows; q.no_tail_split = !e->tail_split;
+        if (epi == EPI_BIAS_RESID) { q.resid = xs; q.ldr = N; }
+        return gemm3_nt(prec, epi, q, s);
+      };
+      if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
+      if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return lin(xn, D, L.qkvw_b, F(L.qkvb), qkv, 3 * D, EPI_BIAS); }))) return rc;
+      if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, 1, s); }))) return rc;
+      if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return lin(att, D, L.projw_b, F(L.projb), xs, D, EPI_BIAS_RESID); }))) return rc;
+      if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
+      if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return lin(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;
     } else {
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
       g = GemmArgs{};

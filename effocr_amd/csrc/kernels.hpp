@@ -61,6 +61,8 @@ int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
 int panelr_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
 
 // vit_ops.hip
+int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
+                           float eps, void* out, hipStream_t s);
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                    float eps, void* out, hipStream_t s);
 int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s);

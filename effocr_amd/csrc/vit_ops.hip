@@ -32,6 +32,57 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// LayerNorm over the fragment-blocked layout: x fp32 cells [rows/32][D/4][32 rows][16 B] -> out 16-bit cells
+// [rows/32][D/8][32 rows][16 B].  One workgroup per 32-row block; wave w owns a quarter of the columns, lane =
+// (row tl = lane & 31, parity part = lane >> 5) holds the chunks w*D/16 + part + 2i in registers (every load is
+// a contiguous 512-byte cell per half-wave).  Statistics: lane sums -> xor-32 exchange -> 4-wave exchange in
+// LDS; exact two-pass variance from the registers (same arithmetic order class as ln_apply).  A lane with
+// part = 0 / 1 holds the even / odd fp32 chunks = the low / high 8 bytes of one 16-byte output chunk.
+template <int D, typename TO>
+__global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __restrict__ x, int64_t rows,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                TO* __restrict__ out) {
+  static_assert(sizeof(TO) == 2 && D % 32 == 0, "blocked LayerNorm writes 16-bit operands");
+  constexpr int NQ = D / 32;                               // float4 chunks per lane
+  __shared__ float red[2][4][32];
+  const int lane = threadIdx.x & 63, tl = lane & 31, part = lane >> 5, wv = threadIdx.x >> 6;
+  const int64_t rb = blockIdx.x;
+  const char* xb = reinterpret_cast<const char*>(x) + rb * (D / 4) * 512 + tl * 16;
+  const int c0 = wv * (D / 16) + part;
+  f32x4 v[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) v[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  s += __shfl_xor(s, 32, 64);
+  if (part == 0) red[0][wv][tl] = s;
+  __syncthreads();
+  const float mean = ((red[0][0][tl] + red[0][1][tl]) + (red[0][2][tl] + red[0][3][tl])) * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+  ss += __shfl_xor(ss, 32, 64);
+  if (part == 0) red[1][wv][tl] = ss;
+  __syncthreads();
+  const float var = ((red[1][0][tl] + red[1][1][tl]) + (red[1][2][tl] + red[1][3][tl])) * (1.0f / D);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (rb * 32 + tl >= rows) return;                        // padding rows of the last block: nothing to write
+  char* ob = reinterpret_cast<char*>(out) + rb * (D / 8) * 512 + tl * 16 + part * 8;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int c = c0 + 2 * i;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c * 4);
+    *reinterpret_cast<u32x2*>(ob + (size_t)(c >> 1) * 512) =
+        pack4<TO>((v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1],
+                  (v[i][2] - mean) * rstd * gm[2] + bt[2], (v[i][3] - mean) * rstd * gm[3] + bt[3]);
+  }
+}
+
 // final LayerNorm on the CLS row of every image (+ optional L2 normalisation) -> emb [B,D] fp32
 template <int G, int V>
 __global__ __launch_bounds__(256) void cls_norm_kernel(const float* __restrict__ x, int B, int T,
@@ -329,6 +380,18 @@ int launch_ln(const float* x, int64_t rows, int D, const float* gamma, const flo
 }
 
 template <typename TO>
+int launch_ln_blocked(const float* x, int64_t rows, int D, const float* gamma, const float* beta, float eps, TO* out,
+                      hipStream_t s) {
+  if (rows <= 0) return EFFOCR_OK;
+  const dim3 grid((unsigned)((rows + 31) / 32));
+  if (D == 768) hipLaunchKernelGGL((layernorm_blocked_kernel<768, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  else if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  else if (D == 128) hipLaunchKernelGGL((layernorm_blocked_kernel<128, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  else return fail(EFFOCR_EUNSUPPORTED, "layernorm(blocked): embed dim must be 128, 384 or 768");
+  return check_launch("layernorm_blocked");
+}
+
+template <typename TO>
 int launch_im2col(const float* x, int B, int H, int W, TO* out, hipStream_t s) {
   const int64_t total = (int64_t)B * (H / 16) * (W / 16) * 96;
   if (total <= 0) return EFFOCR_OK;
@@ -359,6 +422,16 @@ int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const floa
     case PREC_FP32: return launch_ln<float>(x, rows, D, gamma, beta, eps, static_cast<float*>(out), s);
   }
   return fail(EFFOCR_EINVAL, "layernorm: unknown precision");
+}
+
+// x and out fragment-blocked (common.hpp blk_off); the x buffer must be addressable up to the next multiple of 32 rows
+int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
+                           float eps, void* out, hipStream_t s) {
+  switch (prec_out) {
+    case PREC_BF16: return launch_ln_blocked<__bf16>(x, rows, D, gamma, beta, eps, static_cast<__bf16*>(out), s);
+    case PREC_FP16: return launch_ln_blocked<_Float16>(x, rows, D, gamma, beta, eps, static_cast<_Float16*>(out), s);
+  }
+  return fail(EFFOCR_EUNSUPPORTED, "layernorm(blocked): 16-bit output only");
 }
 
 int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s) {
