@@ -144,7 +144,7 @@ void build_vit(effocr_encoder* e) {
     for (int i = 0; i < depth; ++i) {
       VitLayerOff& L = e->layers[i];
       L.fc2w_b = a.take((size_t)D * mlp * es);
-      if (D != 384 && D != 128) {                        // no row-panel kernels at this width: gemm3 runs every linear
+      {                                                  // gemm3 can run every linear (default where no row-panel kernel exists)
         L.qkvw_b = a.take((size_t)3 * D * D * es);
         L.projw_b = a.take((size_t)D * D * es);
         L.fc1w_b = a.take((size_t)mlp * D * es);
@@ -251,7 +251,7 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
     put_op(blob, L.fc2w, P(e, p + "mlp.fc2.weight").data(), (size_t)D * e->vit.mlp, e->prec);
     if (e->prec != PREC_FP32) {
       put_op_blocked(blob, L.fc2w_b, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec);
-      if (D != 384 && D != 128) {
+      {
         put_op_blocked(blob, L.qkvw_b, P(e, p + "attn.qkv.weight").data(), 3 * D, D, e->prec);
         put_op_blocked(blob, L.projw_b, P(e, p + "attn.proj.weight").data(), D, D, e->prec);
         put_op_blocked(blob, L.fc1w_b, P(e, p + "mlp.fc1.weight").data(), e->vit.mlp, D, e->prec);
@@ -346,7 +346,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool g2p = e->use_gemm2 && gemm2_supported(prec, D, 768);
   // fragment-blocked activations (x fp32, qkv, attention output, MLP hidden) need every producer/consumer on the fast path
   // widths without row-panel kernels (ViT-B): LayerNorm kernel + gemm3 for all four linears, everything blocked
-  const bool g3all = !panel && e->use_gemm3 && D != 384 && D != 128 && gemm3_supported(prec, 3 * D, D) && gemm3_supported(prec, D, D) &&
+  const bool g3all = !panel && e->use_gemm3 && gemm3_supported(prec, 3 * D, D) && gemm3_supported(prec, D, D) &&
                      gemm3_supported(prec, e->vit.mlp, D) && gemm3_supported(prec, D, e->vit.mlp);
   const int blk = (e->use_blocked && g2p && ((panel && g2 && e->panel_impl == 0) || g3all)) ? 1 : 0;
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);

@@ -9,7 +9,8 @@ import json, os, re, sqlite3, sys
 
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
     ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
-    ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm2_kernelIDF16bLi2", "gemm_fc2_resid"),
+    ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm3_kernelIDF16bLi3ELi4ELi2", "gemm_fc2_resid"),
+    ("gemm3_kernel<", "gemm_fc2_resid_tail"), ("gemm2_kernelIDF16bLi2", "gemm_fc2_resid"),
     ("gemm2_kernelIDF16bLi3", "gemm_patch_embed"), ("gemm_nt_kernelIDF16bLi2", "gemm_fc2_resid"),
     ("gemm_nt_kernelIDF16bLi3", "gemm_patch_embed"), ("attn_mfma_kernel", "attention"), ("knn_partial", "knn_partial"),
     ("knn_merge", "knn_merge"), ("im2col16", "im2col_patch16"), ("cls_norm", "final_cls_norm"), ("layernorm_kernel", "layernorm"),
