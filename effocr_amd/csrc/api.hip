@@ -720,6 +720,23 @@ int effocr_dbg_ln_linear(int precision, int epilogue, const float* x_dev, const 
   return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
 
+int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev, const void* w_blk_dev, const float* bias_dev,
+                             const float* resid_blk_dev, void* out_blk_dev, int m, int n, int k, int rows_alloc, void* stream) {
+  if (epilogue < 0 || epilogue > 2) return fail(EFFOCR_EINVAL, "op_linear_blocked: unknown epilogue");
+  if (m > 0 && (!x_blk_dev || !w_blk_dev || !bias_dev || !out_blk_dev || (epilogue == EPI_BIAS_RESID && !resid_blk_dev)))
+    return fail(EFFOCR_EINVAL, "op_linear_blocked: NULL device pointer");
+  GemmArgs g{};
+  g.X = x_blk_dev; g.ldx = k; g.Wblk = w_blk_dev; g.bias = bias_dev; g.out = out_blk_dev; g.ldo = n;
+  g.resid = resid_blk_dev; g.ldr = n; g.M = m; g.N = n; g.K = k; g.blk_x = 1; g.blk_out = 1; g.rows_alloc = rows_alloc;
+  return gemm3_nt(precision, epilogue, g, S(stream));
+}
+
+int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,
+                                const float* beta_dev, float eps, void* out_blk_dev, void* stream) {
+  if (rows > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !out_blk_dev)) return fail(EFFOCR_EINVAL, "op_layernorm_blocked: NULL device pointer");
+  return layernorm_rows_blocked(out_precision, x_blk_dev, rows, d, gamma_dev, beta_dev, eps, out_blk_dev, S(stream));
+}
+
 int effocr_op_layernorm(int out_precision, const float* x_dev, int64_t rows, int d, const float* gamma_dev,
                         const float* beta_dev, float eps, void* out_dev, void* stream) {
   return layernorm_rows(out_precision, x_dev, rows, d, gamma_dev, beta_dev, eps, out_dev, S(stream));

@@ -147,3 +147,85 @@ def test_unsupported_shapes_fail_loudly(hip_lib, dev):
     assert rc == -2 and b"multiple" in hip_lib.effocr_last_error()
     rc = hip_lib.effocr_op_attention(0, _lib.ptr(x), _lib.ptr(o), 1, 100, 2, None)
     assert rc == -2
+
+
+# ---------------------------------------------------------------- fragment-blocked fast-path operators (gemm3, blocked LN)
+def to_blocked(t, rows_alloc):
+    """[rows, cols] tensor -> flat buffer in the cell layout [rows_alloc/32][cols/ch][32][ch] (ch = 16 bytes)."""
+    rows, cols = t.shape
+    ch = 16 // t.element_size()
+    buf = torch.zeros((rows_alloc, cols), dtype=t.dtype)
+    buf[:rows] = t
+    return buf.view(rows_alloc // 32, 32, cols // ch, ch).permute(0, 2, 1, 3).contiguous().view(-1)
+
+
+def from_blocked(flat, rows, cols, rows_alloc):
+    ch = 16 // flat.element_size()
+    return flat.view(rows_alloc // 32, cols // ch, 32, ch).permute(0, 2, 1, 3).contiguous().view(rows_alloc, cols)[:rows]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("epi", ["bias", "bias_gelu", "bias_resid"])
+@pytest.mark.parametrize("shape", [(197 * 40, 384, 1536), (300, 192, 128), (1000, 768, 768), (70000, 256, 160), (1, 2304, 768), (33, 3072, 768)])
+def test_linear_blocked_gemm3(hip_lib, dev, prec, epi, shape):
+    """gemm3 through effocr_op_linear_blocked: both tile widths (192 / 256), the small-tile tail launch
+    ((70000, 256): 274 token tiles -> one full round + tail), ragged last row blocks, K = 128 (4 stages = ring depth)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).to(TDT[prec])
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(TDT[prec])
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ra = (M + 127) // 128 * 128
+    xd, wd, bd = to_blocked(x, ra).to(dev), to_blocked(w, N).to(dev), bias.to(dev)
+    if epi == "bias_resid":
+        out = to_blocked(resid, ra).to(dev)
+        rd = out
+    else:
+        out = torch.zeros(ra * N, dtype=TDT[prec], device=dev)
+        rd = None
+    _lib.check(hip_lib.effocr_op_linear_blocked(_lib.PREC[prec], _lib.EPI[epi], _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd),
+                                                _lib.ptr(rd), _lib.ptr(out), M, N, K, ra, _stream(dev)), "op_linear_blocked")
+    torch.cuda.synchronize()
+    got = from_blocked(out.cpu(), M, N, ra).double()
+    ref = x.double() @ w.double().T + bias.double()
+    if epi == "bias_gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if epi == "bias_resid":
+        ref = ref + resid.double()
+    tol = {"bf16": 8e-3, "fp16": 1e-3}[prec] if epi != "bias_resid" else 2e-5
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+    assert err <= tol * scale, f"{prec} {epi} {shape}: err {err:.3e} scale {scale:.3e}"
+    if epi != "bias_resid":                                 # rows past M (padding of the last blocks) stay untouched
+        pad = from_blocked(out.cpu(), ra, N, ra)[M:]
+        assert not pad.any()
+
+
+def test_linear_blocked_argument_checks(hip_lib, dev):
+    z = torch.zeros(1 << 16, dtype=torch.bfloat16, device=dev)
+    f = torch.zeros(1 << 12, dtype=torch.float32, device=dev)
+    call = lambda m, n, k, ra: hip_lib.effocr_op_linear_blocked(0, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), None, _lib.ptr(z), m, n, k, ra, _stream(dev))
+    assert call(32, 128, 128, 32) == -2          # N neither % 192 nor % 256
+    assert call(32, 192, 100, 32) == -2          # K % 32
+    assert call(32, 192, 128, 16) == -1          # rows_alloc < m
+    assert call(0, 192, 128, 0) == 0
+    assert hip_lib.effocr_op_linear_blocked(2, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), None, _lib.ptr(z), 32, 192, 128, 32, _stream(dev)) == -2   # fp32
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,D", [(197 * 7, 768), (50, 384), (33, 128), (1, 768)])
+def test_layernorm_blocked(hip_lib, dev, prec, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + torch.randn(rows, 1, generator=g)
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ra = (rows + 31) // 32 * 32
+    xd = to_blocked(x, ra).to(dev)
+    out = torch.zeros(ra * D, dtype=TDT[prec], device=dev)
+    gd, bd = gamma.to(dev), beta.to(dev)                     # keep alive: ptr() of a temporary would dangle
+    _lib.check(hip_lib.effocr_op_layernorm_blocked(_lib.PREC[prec], _lib.ptr(xd), rows, D, _lib.ptr(gd), _lib.ptr(bd),
+                                                   1e-6, _lib.ptr(out), _stream(dev)), "op_layernorm_blocked")
+    torch.cuda.synchronize()
+    got = from_blocked(out.cpu(), rows, D, ra).double()
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6)
+    tol = {"bf16": 4e-3, "fp16": 5e-4}[prec]
+    assert ((got - ref).abs().max() / ref.abs().max()).item() <= tol
