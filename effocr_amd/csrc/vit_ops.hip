@@ -7,6 +7,10 @@
 #include "ln.hpp"
 #include <math.h>
 
+#ifndef EFFOCR_EXP
+#define EFFOCR_EXP 0
+#endif
+
 namespace effocr {
 namespace {
 
@@ -193,47 +197,83 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const int D = heads * 64;
   const int64_t ld = 3 * (int64_t)D;
-  const E* base = qkv + (int64_t)b * T * ld + h * 64;
   const int64_t tok0 = (int64_t)b * T;                   // first token of this image
   const int nch = 3 * D / 8;                             // chunks per qkv row
   // 16-B chunk `c8` (0..7) of section `sec` (0 q, 1 k, 2 v) of token t
   auto qkv_ptr = [&](int t, int sec, int c8) -> const u32x4* {
     if constexpr (BLK) return reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(qkv) + blk_off(tok0 + t, (sec * D + h * 64) / 8 + c8, nch));
-    else return reinterpret_cast<const u32x4*>(base + (int64_t)t * ld + sec * D + c8 * 8);
+    else return reinterpret_cast<const u32x4*>(qkv + (tok0 + t) * ld + sec * D + h * 64 + c8 * 8);
   };
 
-  // ---- stage K rows (zero rows beyond T)
-  for (int id = tid; id < TP * 8; id += 256) {
-    const int t = id >> 3, c = id & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (t < T) v = *qkv_ptr(t, 1, c);
-    *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = v;
-  }
-  // ---- stage V transposed: dword (d, tp) = {V[2tp][d], V[2tp+1][d]}
-  for (int id = tid; id < (TP / 2) * 8; id += 256) {
-    const int tp = id >> 3, c = id & 7;
-    const int t0 = 2 * tp;
-    u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-    if (t0 < T) v0 = *qkv_ptr(t0, 2, c);
-    if (t0 + 1 < T) v1 = *qkv_ptr(t0 + 1, 2, c);
+  auto load_q = [&](V8 (&q)[4], int qb) {
+    int tq = qb * 32 + r31;
+    tq = tq < T ? tq : T - 1;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const uint32_t a = v0[jj], bq = v1[jj];
-      sV[(c * 8 + 2 * jj) * VS + tp] = (a & 0xffffu) | (bq << 16);
-      sV[(c * 8 + 2 * jj + 1) * VS + tp] = (a >> 16) | (bq & 0xffff0000u);
+    for (int ks = 0; ks < 4; ++ks) q[ks] = __builtin_bit_cast(V8, *qkv_ptr(tq, 0, 2 * ks + half));
+  };
+  // K rows (zero rows beyond T) and V -> registers.  Every global load of the workgroup is issued before the
+  // first LDS write: ONE exposed memory latency per workgroup instead of one per loop iteration (2.50 -> 2.01 ms;
+  // prefetching the next head's K / V across a multi-head loop was tried and spills: the 224-key score row
+  // already occupies 112 registers)
+  constexpr int NKI = TP * 8 / 256;                         // K: 16-B chunks per thread
+  constexpr int NVI = ((TP / 2) * 8 + 255) / 256;           // V: key-pair chunks per thread
+  u32x4 kreg[NKI], v0reg[NVI], v1reg[NVI];
+  auto load_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int id = tid + 256 * i, t = id >> 3, c = id & 7;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      kreg[i] = z;
+      if (t < T) kreg[i] = *qkv_ptr(t, 1, c);
     }
-  }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+      const int id = tid + 256 * i, tp = id >> 3, c = id & 7, t0 = 2 * tp;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      v0reg[i] = z; v1reg[i] = z;
+      if (t0 < T) v0reg[i] = *qkv_ptr(t0, 2, c);
+      if (t0 + 1 < T) v1reg[i] = *qkv_ptr(t0 + 1, 2, c);
+    }
+  };
+  // registers -> LDS: K row-major, V transposed: dword (d, tp) = {V[2tp][d], V[2tp+1][d]}
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int id = tid + 256 * i, t = id >> 3, c = id & 7;
+      *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+      const int id = tid + 256 * i, tp = id >> 3, c = id & 7;
+      if (id < (TP / 2) * 8) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const uint32_t a = v0reg[i][jj], bq = v1reg[i][jj];
+          sV[(c * 8 + 2 * jj) * VS + tp] = (a & 0xffffu) | (bq << 16);
+          sV[(c * 8 + 2 * jj + 1) * VS + tp] = (a >> 16) | (bq & 0xffff0000u);
+        }
+      }
+    }
+  };
+
+  V8 qf[4], qn[4];
+  if (w * 32 < T) load_q(qf, w);                            // oldest in the VM queue: ready when the staging is
+#if EFFOCR_EXP != 32
+  load_kv();
+  store_kv();
+#endif
   __syncthreads();
+#if EFFOCR_EXP == 31
+  if (T > 0) return;                                       // experiment: staging only
+#endif
 
   const float cexp = 0.125f * 1.44269504088896340736f;     // head_dim^-0.5 * log2(e)
   for (int qb = w; qb * 32 < T; qb += 4) {
     int tq = qb * 32 + r31;
     const bool qvalid = tq < T;
     tq = qvalid ? tq : T - 1;
-    V8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = __builtin_bit_cast(V8, *qkv_ptr(tq, 0, 2 * ks + half));
+    const bool more = (qb + 4) * 32 < T;
+    if (more) load_q(qn, qb + 4);
 
     // S^T tiles: rows = keys, cols = queries
     f32x16 s[NKT];
@@ -296,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
     l += __shfl_xor(l, 32, 64);
     if (qvalid) {
       const float inv = 1.0f / l;
-      E* orow = out + ((int64_t)b * T + tq) * D + h * 64;
+      E* orow = out + (tok0 + tq) * D + h * 64;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -307,6 +347,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
           *dst =
               pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
         }
+    }
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
     }
   }
 }
