@@ -36,6 +36,18 @@ int gemm2_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 bool gemm3_supported(int prec, int N, int K);
 int gemm3_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 
+// mlp.hip — fused LayerNorm + fc1 + GELU + fc2 + residual over the blocked residual stream (hidden stays on chip)
+struct MlpArgs {
+  float* x;                         // fp32 residual stream, fragment-blocked, updated in place
+  const float* gamma; const float* beta; float eps;   // norm2
+  const void* W1b; const float* b1; // fc1 weight [H,D] fragment-blocked, bias [H]
+  const void* W2p; const float* b2; // fc2 weight [D,H] fragment-blocked with the k index permuted per 16 (see put_op_blocked), bias [D]
+  int M, D, H;
+  int rows_alloc;                   // rows addressable in x (multiple of 32, >= M)
+};
+bool mlp_fused_supported(int prec, int D, int H);
+int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);
+
 // panel.hip — row-panel GEMM with optional fused LayerNorm prologue (K = embed dim)
 enum { PRO_COPY = 0, PRO_LN = 1 };
 struct PanelArgs {

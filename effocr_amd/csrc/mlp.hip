@@ -1,0 +1,345 @@
+// Fused transformer MLP over the fragment-blocked residual stream (bf16 / f16 operands, gfx950):
+//     x <- x + fc2(GELU(fc1(LayerNorm(x))))          (timm Block.mlp + norm2 + residual; models/encoders.py:58,63)
+// The hidden activations [tokens, 4*D] never leave the CU: per block that removes 620 MB written + 620 MB read
+// (ViT-S, 1024 crops) and one 310 MB pass over x — the MLP was 52 % of the forward and its two GEMMs were bound
+// by exactly that traffic (profiles/README.md).
+//
+// One workgroup = 4 waves (one per SIMD, accumulators in AGPRs, gemm3.hip's regime) = a panel of 128 tokens;
+// wave w owns tokens 32w..32w+31 from LayerNorm to the final store, so nothing is exchanged between waves:
+//   prologue  LayerNorm of the wave's 32 rows, two lanes per row; lane (row r, half) loads exactly the fp32 chunks
+//             that make up ITS MFMA B-operand fragments (k chunks 2t+half), so the normalised panel never exists
+//             anywhere but in registers (D/16 fragments = 96 VGPRs at D = 384) — no LDS panel, no LDS reads for it;
+//   chunk c   (128 hidden features; H/128 chunks):
+//     phase A   hT[128 hid x 32 tok] = W1_c . xn^T          4 MFMA tiles x D/16 k-steps, W1 stages from the ring
+//     GELU      bias + GELU on the accumulators, rounded to the operand type.  In the SWAPPED MFMA C-layout a
+//               lane holds hidden {0-3, 8-11, 16-19, 24-27} (+4 for the upper half-wave) of its token: read as two
+//               8-element vectors that IS a valid B-operand for phase B, provided W2's k index is permuted the
+//               same way — done once on the host (fc2 weight copy "blocked + permuted", api.hip);
+//     phase B   outT[D x 32 tok] += W2[:, c] . h_c           D/32 MFMA tiles x 8 k-steps, B-operand from registers
+//   epilogue  x <- outT + bias2 + x (fp32, blocked).
+// Weights stream through an 8-slot ring of 16 KB stages (32 cells = 4 row blocks x 64 k) by global_load_lds, six
+// stages ahead (LDS holds nothing else but the biases); both weight copies are fragment-blocked so a stage is a
+// verbatim copy of 512-byte HBM cells and every fragment read is conflict-free without swizzles.  As in gemm3 the
+// barrier sits in the MIDDLE of a stage, so the first fragments of stage s+1 are read under stage s's last MFMAs.  GELU of chunk c is software-pipelined under phase A of
+// chunk c+1 (pre-activations parked as packed 16-bit values), so the stream of MFMAs never waits for it:
+//     A(0) | A(1)+gelu(0) | B(0) | A(2)+gelu(1) | B(1) | ... | A(n-1)+gelu(n-2) | B(n-2) | gelu(n-1) | B(n-1)
+#include "common.hpp"
+#include "kernels.hpp"
+#include <type_traits>
+
+namespace effocr {
+namespace {
+
+template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+constexpr int MLP_PT = 128;                              // tokens per workgroup
+constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
+constexpr int MLP_RING = 8;
+
+template <typename E, int D, int H>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
+  typedef typename Op16<E>::V8 V8;
+  constexpr int KC = D / 8;                              // 16-B k chunks per xn row
+  constexpr int NC = H / 128;                            // hidden chunks
+  constexpr int SA = D / 64;                             // ring stages per phase A
+  constexpr int OT = D / 32;                             // output tiles (32 features each) per token block
+  constexpr int OG = OT / 4;                             // output tile groups of 4 (one ring stage holds 4 row blocks)
+  constexpr int SB = 2 * OG;                             // ring stages per phase B: (group, k half)
+  constexpr int NS = NC * (SA + SB);                     // ring stages per panel
+  static_assert(D % 128 == 0 && H % 128 == 0, "mlp: D and H must be multiples of 128");
+  constexpr int NXF = D / 16;                            // xn B-operand fragments per lane (one per k16 step)
+  constexpr int R = MLP_RING;
+  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 3 * D) * 4];
+  char* sW = smem;
+  float* sB1 = reinterpret_cast<float*>(smem + R * MLP_STAGE);
+  float* sB2 = sB1 + H;
+  float* sG = sB2 + D;                                   // norm2 weight / bias: LDS reads do not queue behind the ring's DMAs
+  float* sBt = sG + D;
+
+  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  const int w = wave_id();
+  const int64_t rb = (int64_t)blockIdx.x * 4 + w;        // this wave's 32-row block of x
+  const char* W1 = static_cast<const char*>(a.W1b);
+  const char* W2 = static_cast<const char*>(a.W2p);
+
+  // ---- x rows first (oldest in the in-order VM queue: LayerNorm can start while the ring fills).
+  // lane = (row r31, half): 16-bit k chunk 2t+half of its row = fp32 chunks 4t+2half, 4t+2half+1
+  f32x4 xv[2 * NXF];
+  {
+    const int64_t rbc = rb < (a.rows_alloc >> 5) ? rb : (a.rows_alloc >> 5) - 1;
+    const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
+#pragma unroll
+    for (int t = 0; t < NXF; ++t) {
+      xv[2 * t] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half) * 512);
+      xv[2 * t + 1] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half + 1) * 512);
+    }
+  }
+  for (int n = tid; n < H; n += 256) sB1[n] = a.b1[n];
+  for (int n = tid; n < D; n += 256) { sB2[n] = a.b2[n]; sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; }
+  __syncthreads();                                       // parameters visible (and x has landed) before the ring starts filling
+
+  // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
+  // Wave w copies row block w of the stage: 4 pieces of 1 KB (two adjacent k-chunk cells each).
+  auto stage_src = [&](int s) -> const char* {
+    int c, r;
+    bool isA;
+    if (s < SA) { c = 0; r = s; isA = true; }
+    else {
+      const int t = s - SA, p = t / (SA + SB);
+      r = t - p * (SA + SB);
+      if (p < NC - 1) { isA = r < SA; c = isA ? p + 1 : p; r = isA ? r : r - SA; }
+      else { isA = false; c = NC - 1; }                  // trailing B(NC-1): r counts its stages
+    }
+    if (isA) return W1 + ((size_t)(4 * c + w) * KC + 8 * r) * 512;
+    const int g = r >> 1, kh = r & 1;
+    return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * c + 8 * kh) * 512;
+  };
+  auto issue_piece = [&](int s, int i) {                  // caller guarantees s < NS
+    const char* src = stage_src(s) + lane * 16;
+    char* dst = sW + (s & (R - 1)) * MLP_STAGE + w * 4096;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < R - 1; ++s0)
+    if (s0 < NS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issue_piece(s0, i);
+    }
+
+  // ---- LayerNorm in registers -> xf[t] = B-operand fragment of k16 step t
+  V8 xf[NXF];
+  {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NXF; ++i) sm += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NXF; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+#pragma unroll
+    for (int t = 0; t < NXF; ++t) {
+      u32x2 pk[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = 4 * t + 2 * half + j;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(sG + c * 4);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(sBt + c * 4);
+        const f32x4 v = xv[2 * t + j];
+        pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
+                         (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
+      }
+      const u32x4 q = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+      xf[t] = __builtin_bit_cast(V8, q);
+    }
+  }
+
+  f32x16 acc1[4];                                        // hT tiles of the current chunk
+  f32x16 acc2[OT];                                       // outT tiles
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+
+  const int wo = half * 512 + r31 * 16;                  // + (row block i * 8 + 2 * c4) * 512 inside a stage
+  int s = 0;                                             // ring stage counter
+  struct WF { V8 w[4]; };
+  auto load_w = [&](WF& f, const char* st, int c4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * c4) * 512);
+  };
+  // middle of stage s: stage s+1 has landed (own pieces; the R-3 younger stages may stay in flight) and, past
+  // the barrier, everybody's; every wave holds the rest of stage s in registers and is done with stage s-1, whose
+  // slot takes stage s+R-1
+  auto stage_mid = [&](auto STEADY) {
+    if constexpr (decltype(STEADY)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  WF wa, wb;                                             // wa: steps 0, 2 — wb: steps 1, 3
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
+  __builtin_amdgcn_s_barrier();                          // ... and everybody's
+  asm volatile("" ::: "memory");
+  load_w(wa, sW, 0);
+
+  // ---- GELU of a parked chunk: 8 units of 8 values (unit u = B-operand fragment u of phase B)
+  u32x4 parked[8];                                       // pre-activations (bias added), packed operand type
+  V8 hf[8];                                              // post-GELU B-operand fragments of the chunk in phase B
+  auto gelu_unit = [&](int u) {
+    typedef __attribute__((__vector_size__(8 * sizeof(E)))) E E8;
+    const E8 pv = __builtin_bit_cast(E8, parked[u]);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)pv[e];
+    gelu_erf_fast_n<8>(v);
+    E8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (E)v[e];
+    hf[u] = __builtin_bit_cast(V8, o);
+  };
+  // acc1 (+ bias1 of chunk c) -> parked, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
+  auto park = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m) + 4 * half);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
+        const u32x2 lo = pack4<E>(acc1[i][8 * m] + b0[0], acc1[i][8 * m + 1] + b0[1], acc1[i][8 * m + 2] + b0[2], acc1[i][8 * m + 3] + b0[3]);
+        const u32x2 hi = pack4<E>(acc1[i][8 * m + 4] + b1[0], acc1[i][8 * m + 5] + b1[1], acc1[i][8 * m + 6] + b1[2], acc1[i][8 * m + 7] + b1[3]);
+        const u32x4 p = {lo[0], lo[1], hi[0], hi[1]};
+        parked[2 * i + m] = p;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+    }
+  };
+
+  // One ring stage = 4 k16 steps x 4 MFMAs.  mfma4(c4) issues the step's MFMAs; fragments: step c4+1 is read
+  // under step c4, and the first step of stage s+1 under step 3 (it is visible after the mid-stage barrier).
+  // The DMA pieces of stage s+R-1 go after the first MFMAs of steps 2 and 3.
+  // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
+  // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
+  // is one basic block (a scalar branch between two MFMAs is a bubble with one wave per SIMD; see gemm3.hip).
+  auto ring_stage = [&](auto REM, auto&& mfma4) {
+    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1;
+    const char* st = sW + (s & (R - 1)) * MLP_STAGE;
+    const char* stn = sW + ((s + 1) & (R - 1)) * MLP_STAGE;
+    load_w(wb, st, 1);
+    mfma4(std::integral_constant<int, 0>{}, wa, [&](auto) {});
+    load_w(wa, st, 2);
+    mfma4(std::integral_constant<int, 1>{}, wb, [&](auto) {});
+    stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
+    load_w(wb, st, 3);
+    mfma4(std::integral_constant<int, 2>{}, wa, [&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (more && i < 2) issue_piece(s + R - 1, i);
+    });
+    if constexpr (next) load_w(wa, stn, 0);
+    mfma4(std::integral_constant<int, 3>{}, wb, [&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (more && i < 2) issue_piece(s + R - 1, 2 + i);
+    });
+    ++s;
+  };
+  constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
+
+  // ---- phase A of a chunk: SA stages x 4 k16 steps x 4 tiles; optionally GELU units of the parked chunk in the
+  // MFMA shadows (8 units spread over the SA*16 MFMAs)
+  auto phase_a = [&](auto WITH_GELU, auto AFTER) {        // AFTER = ring stages that follow the phase
+    constexpr bool with_gelu = decltype(WITH_GELU)::value;
+    constexpr int NMM = SA * 16;
+    sfor<0, SA>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
+      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, WF& f, auto&& between) {
+        constexpr int c4 = decltype(C4)::value;
+        sfor<0, 4>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          acc1[i] = Op16<E>::mfma(f.w[i], xf[ks * 4 + c4], acc1[i]);
+          __builtin_amdgcn_sched_barrier(0);
+          between(I);
+          if constexpr (with_gelu) {
+            constexpr int n = ks * 16 + c4 * 4 + i;      // MFMA index within the phase; unit u goes after MFMA ceil(u*NMM/8)
+            constexpr int u = (n * 8) / NMM;
+            if constexpr ((u * NMM + 7) / 8 == n && u < 8) gelu_unit(u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    });
+  };
+  // ---- phase B of a chunk: (group g, k half kh) stages; B-operand = hf[4*kh + c4]
+  auto phase_b = [&](auto AFTER) {
+    sfor<0, SB>([&](auto SBI) {
+      constexpr int sb = decltype(SBI)::value;
+      constexpr int g = sb >> 1, kh = sb & 1;
+      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SB - 1 - sb);
+      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, WF& f, auto&& between) {
+        constexpr int c4 = decltype(C4)::value;
+        sfor<0, 4>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          acc2[4 * g + i] = Op16<E>::mfma(f.w[i], hf[4 * kh + c4], acc2[4 * g + i]);
+          __builtin_amdgcn_sched_barrier(0);
+          between(I);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    });
+  };
+
+  static_assert(NC >= 3, "mlp: at least three hidden chunks");
+  typedef std::integral_constant<int, FAR> Far;
+  phase_a(std::false_type{}, Far{});                     // A(0)
+  park(0);
+  for (int c = 1; c < NC - 1; ++c) {
+    phase_a(std::true_type{}, Far{});                    // A(c) with gelu(c-1) in its shadow -> hf
+    phase_b(Far{});                                      // B(c-1); uses hf, which must survive until here:
+    park(c);                                             // ... so chunk c is parked only now
+  }
+  phase_a(std::true_type{}, std::integral_constant<int, 2 * SB>{});       // A(NC-1) + gelu(NC-2)
+  phase_b(std::integral_constant<int, SB>{});                             // B(NC-2)
+  park(NC - 1);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) gelu_unit(u);
+  phase_b(std::integral_constant<int, 0>{});                              // B(NC-1)
+
+  // ---- epilogue: x <- outT + bias2 + x.  lane = token r31 of row block rb; tile t, group q: features 32t+8q+4half..+3
+  if (rb * 32 + r31 < a.M) {
+    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + half * 512 + r31 * 16;    // + (8t + 2q) * 512
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      f32x4 rv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)(8 * t + 2 * q) * 512);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + t * 32 + 8 * q + 4 * half);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc2[t][4 * q + e] + bv[e] + rv[q][e];
+        *reinterpret_cast<f32x4*>(xr + (size_t)(8 * t + 2 * q) * 512) = o;
+      }
+    });
+  }
+}
+
+template <typename E>
+int launch_mlp(const MlpArgs& a, hipStream_t s) {
+  const dim3 grid((unsigned)((a.M + MLP_PT - 1) / MLP_PT)), blk(256);
+  if (a.D == 384 && a.H == 1536) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536>), grid, blk, 0, s, a);
+  else if (a.D == 128 && a.H == 512) hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512>), grid, blk, 0, s, a);
+  else return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
+  return check_launch("mlp_fused");
+}
+
+}  // namespace
+
+bool mlp_fused_supported(int prec, int D, int H) {
+  return (prec == PREC_BF16 || prec == PREC_FP16) && ((D == 384 && H == 1536) || (D == 128 && H == 512));
+}
+
+int mlp_fused(int prec, const MlpArgs& a, hipStream_t s) {
+  if (a.M <= 0) return EFFOCR_OK;
+  if (!mlp_fused_supported(prec, a.D, a.H)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: needs bf16/fp16 and (D, H) in {(384, 1536), (128, 512)}");
+  if (a.rows_alloc % 32 != 0 || a.rows_alloc < a.M) return fail(EFFOCR_EINVAL, "mlp_fused: rows_alloc must be a multiple of 32 covering M");
+  return prec == PREC_BF16 ? launch_mlp<__bf16>(a, s) : launch_mlp<_Float16>(a, s);
+}
+
+}  // namespace effocr

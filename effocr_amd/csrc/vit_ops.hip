@@ -256,6 +256,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
     }
   };
 
+#if EFFOCR_EXP >= 34 && EFFOCR_EXP <= 37
+  // experiment: put the second resident workgroup of every CU half a period out of phase, once
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < EFFOCR_EXP - 33; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   V8 qf[4], qn[4];
   if (w * 32 < T) load_q(qf, w);                            // oldest in the VM queue: ready when the staging is
 #if EFFOCR_EXP != 32

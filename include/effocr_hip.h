@@ -165,6 +165,14 @@ int effocr_op_attention(int precision, const void* qkv_dev, void* out_dev, int b
 int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev, const void* w_blk_dev,
                              const float* bias_dev, const float* resid_blk_dev, void* out_blk_dev, int m, int n, int k,
                              int rows_alloc, void* stream);
+/* Fused MLP of one transformer block on the blocked residual stream (timm Block: x + mlp(norm2(x)) with
+ * Linear(d,h) -> GELU(erf) -> Linear(h,d); models/encoders.py:58,63):  x_blk (fp32, in/out) <- x + fc2(gelu(fc1(LN(x)))).
+ * w1_blk: fc1.weight [h,d] 16-bit fragment-blocked.  w2_perm: fc2.weight [d,h] 16-bit fragment-blocked with the k
+ * (hidden) index permuted inside every group of 16: element e of 16-byte chunk c holds
+ * k = 16*(c/2) + (e&3) + 8*(e>>2) + 4*(c&1).  (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m. */
+int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                          const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                          int m, int d, int h, int rows_alloc, void* stream);
 int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,
                                 const float* beta_dev, float eps, void* out_blk_dev, void* stream);
 

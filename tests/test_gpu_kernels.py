@@ -229,3 +229,42 @@ def test_layernorm_blocked(hip_lib, dev, prec, rows, D):
     ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6)
     tol = {"bf16": 4e-3, "fp16": 5e-4}[prec]
     assert ((got - ref).abs().max() / ref.abs().max()).item() <= tol
+
+
+def perm16_columns(w):
+    """fc2 weight copy for the fused MLP: inside every group of 16 hidden indices the order is
+    [0-3, 8-11 | 4-7, 12-15] (what the swapped-MFMA C-layout hands over as a B-operand; include/effocr_hip.h)."""
+    base = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    idx = (torch.arange(w.shape[1] // 16)[:, None] * 16 + base[None, :]).reshape(-1)
+    return w[:, idx].contiguous()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(197 * 5, 384, 1536), (100, 128, 512), (1, 384, 1536), (128 * 3, 128, 512), (40000, 384, 1536)])
+def test_mlp_fused_blocked(hip_lib, dev, prec, shape):
+    """mlp.hip: x + fc2(gelu(fc1(LN(x)))) in one kernel vs an fp64 restatement with the same operand rounding points
+    (LN output and GELU output rounded to the operand type, as the unfused path does)."""
+    M, D, H = shape
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.3 * torch.randn(M, 1, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1 = (torch.randn(H, D, generator=g) / math.sqrt(D)).to(TDT[prec])
+    w2 = (torch.randn(D, H, generator=g) / math.sqrt(H)).to(TDT[prec])
+    b1, b2 = 0.5 * torch.randn(H, generator=g), 0.5 * torch.randn(D, generator=g)
+    ra = (M + 127) // 128 * 128
+    xd = to_blocked(x, ra).to(dev)
+    w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm16_columns(w2), D).to(dev)
+    gd, bd, b1d, b2d = gamma.to(dev), beta.to(dev), b1.to(dev), b2.to(dev)
+    _lib.check(hip_lib.effocr_op_mlp_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6, _lib.ptr(w1d), _lib.ptr(b1d),
+                                             _lib.ptr(w2d), _lib.ptr(b2d), M, D, H, ra, _stream(dev)), "op_mlp_blocked")
+    torch.cuda.synchronize()
+    got = from_blocked(xd.cpu(), M, D, ra).double()
+    xn = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6).to(TDT[prec]).double()
+    hid = torch.nn.functional.gelu(xn @ w1.double().T + b1.double()).to(TDT[prec]).double()
+    delta = hid @ w2.double().T + b2.double()
+    ref = x.double() + delta
+    tol = {"bf16": 1e-2, "fp16": 1.5e-3}[prec]
+    err, scale = (got - ref).abs().max().item(), delta.abs().max().item()
+    assert err <= tol * scale, f"{prec} {shape}: err {err:.3e} vs delta scale {scale:.3e}"
+    if ra > M:                                             # padding rows untouched
+        assert torch.equal(from_blocked(xd.cpu(), ra, D, ra)[M:], torch.zeros(ra - M, D))
