@@ -27,6 +27,17 @@
 #include "kernels.hpp"
 #include <type_traits>
 
+#ifndef EFFOCR_EXP
+#define EFFOCR_EXP 0
+#endif
+// timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
+// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop
+#if EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000
+#define MLX (EFFOCR_EXP - 2000)
+#else
+#define MLX 0
+#endif
+
 namespace effocr {
 namespace {
 
@@ -75,8 +86,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
 #pragma unroll
     for (int t = 0; t < NXF; ++t) {
+#if (MLX & 2)
+      const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f};
+      xv[2 * t] = cst; xv[2 * t + 1] = cst;
+      if (a.M < 0)
+#endif
+      {
       xv[2 * t] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half) * 512);
       xv[2 * t + 1] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half + 1) * 512);
+      }
     }
   }
   for (int n = tid; n < H; n += 256) sB1[n] = a.b1[n];
@@ -85,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 
   // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
   // Wave w copies row block w of the stage: 4 pieces of 1 KB (two adjacent k-chunk cells each).
-  auto stage_src = [&](int s) -> const char* {
+  auto stage_src = [&](int s) __attribute__((always_inline)) -> const char* {
     int c, r;
     bool isA;
     if (s < SA) { c = 0; r = s; isA = true; }
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     const int g = r >> 1, kh = r & 1;
     return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * c + 8 * kh) * 512;
   };
-  auto issue_piece = [&](int s, int i) {                  // caller guarantees s < NS
+  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS
     const char* src = stage_src(s) + lane * 16;
     char* dst = sW + (s & (R - 1)) * MLP_STAGE + w * 4096;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
@@ -158,148 +176,176 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   const int wo = half * 512 + r31 * 16;                  // + (row block i * 8 + 2 * c4) * 512 inside a stage
   int s = 0;                                             // ring stage counter
   struct WF { V8 w[4]; };
-  auto load_w = [&](WF& f, const char* st, int c4) {
+  auto load_w = [&](WF& f, const char* st, int c4) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) f.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * c4) * 512);
   };
   // middle of stage s: stage s+1 has landed (own pieces; the R-3 younger stages may stay in flight) and, past
   // the barrier, everybody's; every wave holds the rest of stage s in registers and is done with stage s-1, whose
   // slot takes stage s+R-1
-  auto stage_mid = [&](auto STEADY) {
+  auto stage_mid = [&](auto STEADY) __attribute__((always_inline)) {
     if constexpr (decltype(STEADY)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(MLX & 16)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
   };
-  WF wa, wb;                                             // wa: steps 0, 2 — wb: steps 1, 3
+  WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
   __builtin_amdgcn_s_barrier();                          // ... and everybody's
   asm volatile("" ::: "memory");
-  load_w(wa, sW, 0);
+  load_w(wf, sW, 0);
 
-  // ---- GELU of a parked chunk: 8 units of 8 values (unit u = B-operand fragment u of phase B)
-  u32x4 parked[8];                                       // pre-activations (bias added), packed operand type
-  V8 hf[8];                                              // post-GELU B-operand fragments of the chunk in phase B
-  auto gelu_unit = [&](int u) {
-    typedef __attribute__((__vector_size__(8 * sizeof(E)))) E E8;
-    const E8 pv = __builtin_bit_cast(E8, parked[u]);
-    float v[8];
+  // ---- chunk hand-over registers: the set holds the 8 B-operand fragments (8 values each) of one chunk, first as
+  // pre-activations (bias added, rounded to the operand type: "parked"), then GELU'd IN PLACE, 4 values at a time.
+  // (Two alternating sets, with the GELU spread over both phases, do not fit next to the 96 VGPRs of xn: spills.)
+  struct HSet { u32x4 u[8]; };
+  // half-unit q (0..15) = words 2*(q&1), 2*(q&1)+1 of unit q>>1: 4 values (keeps the polynomial's temporaries to 16 VGPRs)
+  auto gelu_unit = [&](HSet& hs, auto Q) __attribute__((always_inline)) {     // Q: compile-time -> static register indices
+    typedef __attribute__((__vector_size__(4 * sizeof(E)))) E E4;
+    constexpr int u = decltype(Q)::value >> 1, h2 = (decltype(Q)::value & 1) * 2;
+    const u32x2 pw = {hs.u[u][h2], hs.u[u][h2 + 1]};
+    const E4 pv = __builtin_bit_cast(E4, pw);
+    float v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)pv[e];
-    gelu_erf_fast_n<8>(v);
-    E8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (E)v[e];
-    hf[u] = __builtin_bit_cast(V8, o);
+    for (int e = 0; e < 4; ++e) v[e] = (float)pv[e];
+#if !(MLX & 4)
+    gelu_fold_n<E, 4>(v);
+#endif
+    const u32x2 o = pack4<E>(v[0], v[1], v[2], v[3]);
+    hs.u[u][h2] = o[0];
+    hs.u[u][h2 + 1] = o[1];
   };
-  // acc1 (+ bias1 of chunk c) -> parked, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
-  auto park = [&](int c) {
+  // acc1 (+ bias1 of chunk c) -> set, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
+  auto park = [&](HSet& hs, int c) __attribute__((always_inline)) {
+    sfor<0, 8>([&](auto U) {                             // one unit (8 values) at a time: bounds the live temporaries
+      constexpr int u = decltype(U)::value, i = u >> 1, m = u & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m) + 4 * half);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
+      const u32x2 lo = pack4<E>(acc1[i][8 * m] + b0[0], acc1[i][8 * m + 1] + b0[1], acc1[i][8 * m + 2] + b0[2], acc1[i][8 * m + 3] + b0[3]);
+      const u32x2 hi = pack4<E>(acc1[i][8 * m + 4] + b1[0], acc1[i][8 * m + 5] + b1[1], acc1[i][8 * m + 6] + b1[2], acc1[i][8 * m + 7] + b1[3]);
+      const u32x4 p = {lo[0], lo[1], hi[0], hi[1]};
+      hs.u[u] = p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m) + 4 * half);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
-        const u32x2 lo = pack4<E>(acc1[i][8 * m] + b0[0], acc1[i][8 * m + 1] + b0[1], acc1[i][8 * m + 2] + b0[2], acc1[i][8 * m + 3] + b0[3]);
-        const u32x2 hi = pack4<E>(acc1[i][8 * m + 4] + b1[0], acc1[i][8 * m + 5] + b1[1], acc1[i][8 * m + 6] + b1[2], acc1[i][8 * m + 7] + b1[3]);
-        const u32x4 p = {lo[0], lo[1], hi[0], hi[1]};
-        parked[2 * i + m] = p;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
-    }
+      for (int r = 8 * m; r < 8 * m + 8; ++r) acc1[i][r] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
-  // One ring stage = 4 k16 steps x 4 MFMAs.  mfma4(c4) issues the step's MFMAs; fragments: step c4+1 is read
-  // under step c4, and the first step of stage s+1 under step 3 (it is visible after the mid-stage barrier).
-  // The DMA pieces of stage s+R-1 go after the first MFMAs of steps 2 and 3.
   // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
   // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
   // is one basic block (a scalar branch between two MFMAs is a bubble with one wave per SIMD; see gemm3.hip).
-  auto ring_stage = [&](auto REM, auto&& mfma4) {
+  auto ring_stage = [&](auto REM, auto&& mfma1) __attribute__((always_inline)) {
+#if (MLX & 8)
+    constexpr bool more = false, next = decltype(REM)::value >= 1;
+#else
     constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1;
+#endif
     const char* st = sW + (s & (R - 1)) * MLP_STAGE;
     const char* stn = sW + ((s + 1) & (R - 1)) * MLP_STAGE;
-    load_w(wb, st, 1);
-    mfma4(std::integral_constant<int, 0>{}, wa, [&](auto) {});
-    load_w(wa, st, 2);
-    mfma4(std::integral_constant<int, 1>{}, wb, [&](auto) {});
-    stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
-    load_w(wb, st, 3);
-    mfma4(std::integral_constant<int, 2>{}, wa, [&](auto I) {
-      constexpr int i = decltype(I)::value;
-      if constexpr (more && i < 2) issue_piece(s + R - 1, i);
-    });
-    if constexpr (next) load_w(wa, stn, 0);
-    mfma4(std::integral_constant<int, 3>{}, wb, [&](auto I) {
-      constexpr int i = decltype(I)::value;
-      if constexpr (more && i < 2) issue_piece(s + R - 1, 2 + i);
+    // ONE fragment set, refilled in a rolling fashion: right after MFMA (c4, i) has consumed wf.w[i], the same
+    // registers receive fragment i of step c4+1 (of stage s+1's step 0 after step 3) — 16 VGPRs instead of 32
+    sfor<0, 4>([&](auto C4) {
+      constexpr int c4 = decltype(C4)::value;
+      if constexpr (c4 == 2) {
+#if (MLX & 8)
+        stage_mid(std::false_type{});
+#else
+        stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
+#endif
+      }
+      sfor<0, 4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        mfma1(C4, I, wf.w[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
+        else if constexpr (next) wf.w[i] = *reinterpret_cast<const V8*>(stn + wo + (i * 8) * 512);
+        if constexpr (more && c4 >= 2 && i < 2) issue_piece(s + R - 1, (c4 - 2) * 2 + i);
+      });
     });
     ++s;
   };
   constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
 
-  // ---- phase A of a chunk: SA stages x 4 k16 steps x 4 tiles; optionally GELU units of the parked chunk in the
-  // MFMA shadows (8 units spread over the SA*16 MFMAs)
-  auto phase_a = [&](auto WITH_GELU, auto AFTER) {        // AFTER = ring stages that follow the phase
-    constexpr bool with_gelu = decltype(WITH_GELU)::value;
-    constexpr int NMM = SA * 16;
+  // GELU half-units [U0, U1) of `gs` are placed in the MFMA shadows of a phase of NMM MFMAs, evenly spaced
+  // ---- phase A of a chunk: SA stages x 4 k16 steps x 4 tiles
+  auto phase_a = [&](auto AFTER, HSet* gs, auto U0, auto U1) __attribute__((always_inline)) {        // AFTER = ring stages that follow the phase
+    constexpr int NMM = SA * 16, u0 = decltype(U0)::value, nu = decltype(U1)::value - u0;
     sfor<0, SA>([&](auto KS) {
       constexpr int ks = decltype(KS)::value;
       constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
-      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, WF& f, auto&& between) {
-        constexpr int c4 = decltype(C4)::value;
-        sfor<0, 4>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          acc1[i] = Op16<E>::mfma(f.w[i], xf[ks * 4 + c4], acc1[i]);
-          __builtin_amdgcn_sched_barrier(0);
-          between(I);
-          if constexpr (with_gelu) {
-            constexpr int n = ks * 16 + c4 * 4 + i;      // MFMA index within the phase; unit u goes after MFMA ceil(u*NMM/8)
-            constexpr int u = (n * 8) / NMM;
-            if constexpr ((u * NMM + 7) / 8 == n && u < 8) gelu_unit(u);
+      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+#if (MLX & 32)
+        acc1[i][c4] += (float)wfrag[0] * (float)xf[ks * 4 + c4][1];
+#else
+        acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
+#endif
+        if constexpr (nu > 0) {
+          constexpr int n = ks * 16 + c4 * 4 + i;        // MFMA index within the phase; half-unit k goes after MFMA ceil(k*NMM/nu)
+          constexpr int k = (n * nu) / NMM;
+          if constexpr ((k * NMM + nu - 1) / nu == n && k < nu) {
+            __builtin_amdgcn_sched_barrier(0);
+            gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
           }
-          __builtin_amdgcn_sched_barrier(0);
-        });
+        }
       });
     });
   };
-  // ---- phase B of a chunk: (group g, k half kh) stages; B-operand = hf[4*kh + c4]
-  auto phase_b = [&](auto AFTER) {
+  // ---- phase B of a chunk: (group g, k half kh) stages; B-operand = fragment 4*kh + c4 of `hs`
+  auto phase_b = [&](auto AFTER, const HSet& hs, HSet* gs, auto U0, auto U1) __attribute__((always_inline)) {
+    constexpr int NMM = SB * 16, u0 = decltype(U0)::value, nu = decltype(U1)::value - u0;
     sfor<0, SB>([&](auto SBI) {
       constexpr int sb = decltype(SBI)::value;
       constexpr int g = sb >> 1, kh = sb & 1;
       constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SB - 1 - sb);
-      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, WF& f, auto&& between) {
-        constexpr int c4 = decltype(C4)::value;
-        sfor<0, 4>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          acc2[4 * g + i] = Op16<E>::mfma(f.w[i], hf[4 * kh + c4], acc2[4 * g + i]);
-          __builtin_amdgcn_sched_barrier(0);
-          between(I);
-          __builtin_amdgcn_sched_barrier(0);
-        });
+      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+        const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
+#if (MLX & 32)
+        acc2[4 * g + i][c4] += (float)wfrag[0] * (float)hb[1];
+#else
+        acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
+#endif
+        if constexpr (nu > 0) {
+          constexpr int n = sb * 16 + c4 * 4 + i;
+          constexpr int k = (n * nu) / NMM;
+          if constexpr ((k * NMM + nu - 1) / nu == n && k < nu) {
+            __builtin_amdgcn_sched_barrier(0);
+            gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
+          }
+        }
       });
     });
   };
 
+  // Schedule (ring stream order A(0) | A(1) | B(0) | A(2) | B(1) | ...).  ONE hand-over set: parked after A(c) — once B(c-1)
+  // has consumed the previous contents — activated in place under A(c+1), consumed by B(c):
+  //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
   static_assert(NC >= 3, "mlp: at least three hidden chunks");
   typedef std::integral_constant<int, FAR> Far;
-  phase_a(std::false_type{}, Far{});                     // A(0)
-  park(0);
+  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 16> U16_;
+  HSet S;
+  phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
+  park(S, 0);
+#pragma unroll 1
   for (int c = 1; c < NC - 1; ++c) {
-    phase_a(std::true_type{}, Far{});                    // A(c) with gelu(c-1) in its shadow -> hf
-    phase_b(Far{});                                      // B(c-1); uses hf, which must survive until here:
-    park(c);                                             // ... so chunk c is parked only now
+    phase_a(Far{}, &S, U0_{}, U16_{});                    // A(c) + gelu(c-1)
+    phase_b(Far{}, S, nullptr, U0_{}, U0_{});             // B(c-1)
+    park(S, c);
   }
-  phase_a(std::true_type{}, std::integral_constant<int, 2 * SB>{});       // A(NC-1) + gelu(NC-2)
-  phase_b(std::integral_constant<int, SB>{});                             // B(NC-2)
-  park(NC - 1);
-#pragma unroll
-  for (int u = 0; u < 8; ++u) gelu_unit(u);
-  phase_b(std::integral_constant<int, 0>{});                              // B(NC-1)
+  phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
+  phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
+  park(S, NC - 1);
+  sfor<0, 16>([&](auto Q) { gelu_unit(S, Q); });
+  phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
 
+#if (MLX & 1)
+  if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
+#endif
   // ---- epilogue: x <- outT + bias2 + x.  lane = token r31 of row block rb; tile t, group q: features 32t+8q+4half..+3
   if (rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + half * 512 + r31 * 16;    // + (8t + 2q) * 512
