@@ -56,6 +56,7 @@ struct effocr_encoder {
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
+  int use_rowlin = 0;               // 1: register-resident-input kernels (rowlin.hip) for LN1+qkv and proj+residual instead of the row-panel ones (measured 7 % slower: A/B switch)
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
@@ -355,6 +356,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool g3all = !panel && e->use_gemm3 && gemm3_supported(prec, 3 * D, D) && gemm3_supported(prec, D, D) &&
                      gemm3_supported(prec, e->vit.mlp, D) && gemm3_supported(prec, D, e->vit.mlp);
   const int blk = (e->use_blocked && g2p && ((panel && g2 && e->panel_impl == 0) || g3all)) ? 1 : 0;
+  const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
@@ -367,6 +369,16 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     const VitLayerOff& L = e->layers[i];
     if (panel) {
       // row-panel kernels: LayerNorm fused into the A-panel load, no xn buffer, no LayerNorm launches
+      if (rl) {
+        RowLinArgs q{};
+        q.x = xs; q.gamma = F(L.ln1w); q.beta = F(L.ln1b); q.eps = 1e-6f; q.Wb = wb + L.qkvw_b; q.bias = F(L.qkvb); q.out = qkv;
+        q.M = M; q.D = D; q.N = 3 * D; q.rows_alloc = (int)w.rows;
+        if ((rc = timed(e, "rowlin_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return rowlin(prec, ROWLIN_LN, q, s); }))) return rc;
+        if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
+        q = RowLinArgs{};
+        q.x = xs; q.A = att; q.Wb = wb + L.projw_b; q.bias = F(L.projb); q.M = M; q.D = D; q.N = D; q.rows_alloc = (int)w.rows;
+        if ((rc = timed(e, "rowlin_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return rowlin(prec, ROWLIN_RESID, q, s); }))) return rc;
+      } else {
       PanelArgs p{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
       p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
@@ -377,6 +389,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
       p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split; p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s) : panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
+      }
       if (mlpf) {
         MlpArgs m{};
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
@@ -384,7 +397,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         if ((rc = timed(e, "mlp_fused", 4.0 * Md * Hd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
         continue;
       }
-      p = PanelArgs{};
+      PanelArgs p{};
       p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
       p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
@@ -598,6 +611,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
+  if (n == "use_rowlin") { enc->use_rowlin = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");
@@ -755,6 +769,18 @@ int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_de
   a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_dev;
   a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc;
   return mlp_fused(precision, a, S(stream));
+}
+
+int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const void* a_blk_dev, const float* gamma_dev,
+                             const float* beta_dev, float eps, const void* w_blk_dev, const float* bias_dev, void* out_blk_dev,
+                             int m, int d, int n, int rows_alloc, void* stream) {
+  if (mode != ROWLIN_LN && mode != ROWLIN_RESID) return fail(EFFOCR_EINVAL, "op_rowlin_blocked: mode must be 0 (LN + linear) or 1 (linear + residual)");
+  if (m > 0 && (!x_blk_dev || !w_blk_dev || !bias_dev || (mode == ROWLIN_LN && (!gamma_dev || !beta_dev || !out_blk_dev)) || (mode == ROWLIN_RESID && !a_blk_dev)))
+    return fail(EFFOCR_EINVAL, "op_rowlin_blocked: NULL device pointer");
+  RowLinArgs q{};
+  q.x = x_blk_dev; q.A = a_blk_dev; q.gamma = gamma_dev; q.beta = beta_dev; q.eps = eps; q.Wb = w_blk_dev; q.bias = bias_dev; q.out = out_blk_dev;
+  q.M = m; q.D = d; q.N = n; q.rows_alloc = rows_alloc;
+  return rowlin(precision, mode, q, S(stream));
 }
 
 int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,

@@ -48,6 +48,20 @@ struct MlpArgs {
 bool mlp_fused_supported(int prec, int D, int H);
 int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);
 
+// rowlin.hip — LN + linear (16-bit out) / linear + residual over the blocked layout, input fragments in registers
+enum { ROWLIN_LN = 0, ROWLIN_RESID = 1 };
+struct RowLinArgs {
+  float* x;                         // ROWLIN_LN: fp32 blocked input of the LayerNorm; ROWLIN_RESID: fp32 blocked residual, updated in place
+  const void* A;                    // ROWLIN_RESID: 16-bit blocked input [M, D]
+  const float* gamma; const float* beta; float eps;
+  const void* Wb; const float* bias;   // weight [N, D] fragment-blocked, bias [N]
+  void* out;                        // ROWLIN_LN: 16-bit blocked output [M, N]
+  int M, D, N;
+  int rows_alloc;                   // rows addressable in x / A / out: a multiple of 128 >= M (padding rows are written)
+};
+bool rowlin_supported(int prec, int D, int N);
+int rowlin(int prec, int mode, const RowLinArgs& a, hipStream_t s);
+
 // panel.hip — row-panel GEMM with optional fused LayerNorm prologue (K = embed dim)
 enum { PRO_COPY = 0, PRO_LN = 1 };
 struct PanelArgs {

@@ -173,6 +173,14 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
                           const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
                           int m, int d, int h, int rows_alloc, void* stream);
+/* The two embed-dim linears of a block on the blocked layout (timm Block: norm1 + attn.qkv; attn.proj + residual):
+ *   mode 0: out_blk (16-bit [m,n]) = LayerNorm(x_blk fp32 [m,d]) . w^T + bias
+ *   mode 1: x_blk (fp32 [m,d], in/out) += a_blk (16-bit [m,d]) . w^T + bias          (n == d)
+ * w_blk [n,d] 16-bit fragment-blocked.  (d, n) in {(384,1152), (384,384), (128,384), (128,128)}.  rows_alloc is a
+ * multiple of 128 >= m: the padding rows of the last 128-row panel are written (garbage), never read. */
+int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const void* a_blk_dev, const float* gamma_dev,
+                             const float* beta_dev, float eps, const void* w_blk_dev, const float* bias_dev, void* out_blk_dev,
+                             int m, int d, int n, int rows_alloc, void* stream);
 int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,
                                 const float* beta_dev, float eps, void* out_blk_dev, void* stream);
 
