@@ -323,7 +323,7 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
   return rc;
 }
 
-struct VitWs { size_t x, xn, qkv, att, h, total, rows; };
+struct VitWs { size_t x, xn, qkv, att, h, total, rows, hbytes; };
 VitWs vit_ws(const effocr_encoder* e, int B) {
   // rows padded to the panel height (128) so that the row-panel kernels store without bounds checks
   const size_t M = align_up((size_t)B * e->T, 128), D = e->vit.D, es = prec_esize(e->prec);
@@ -334,7 +334,8 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
   w.qkv = a.take(M * 3 * D * es);
   w.att = a.take(M * D * es);
   size_t hb = M * e->vit.mlp * es, pb = (size_t)B * e->P * 768 * es;
-  w.h = a.take(hb > pb ? hb : pb);          // patches (im2col rows) alias the MLP hidden buffer
+  w.hbytes = hb > pb ? hb : pb;
+  w.h = a.take(w.hbytes);                   // patches (im2col rows) alias the MLP hidden buffer
   w.total = a.off;
   return w;
 }
@@ -394,6 +395,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         MlpArgs m{};
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
         m.W2p = wb + L.fc2w_p; m.b2 = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
+        m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split;   // the hidden buffer is free on this path
         if ((rc = timed(e, "mlp_fused", 4.0 * Md * Hd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
         continue;
       }
@@ -762,12 +764,12 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
 
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
                           const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
-                          int m, int d, int h, int rows_alloc, void* stream) {
+                          int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream) {
   if (m > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_dev))
     return fail(EFFOCR_EINVAL, "op_mlp_blocked: NULL device pointer");
   MlpArgs a{};
   a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_dev;
-  a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc;
+  a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
   return mlp_fused(precision, a, S(stream));
 }
 

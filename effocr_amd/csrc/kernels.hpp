@@ -44,6 +44,9 @@ struct MlpArgs {
   const void* W2p; const float* b2; // fc2 weight [D,H] fragment-blocked with the k index permuted per 16 (see put_op_blocked), bias [D]
   int M, D, H;
   int rows_alloc;                   // rows addressable in x (multiple of 32, >= M)
+  float* partial; size_t partial_bytes;   // optional scratch for the tail split (>= 4 * 64 * 128 * D * 4 bytes covers every case)
+  int no_tail_split;                // 1: single launch (A/B switch)
+  int panel0, tail_rb;              // set by the launcher
 };
 bool mlp_fused_supported(int prec, int D, int H);
 int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);

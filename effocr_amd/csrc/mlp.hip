@@ -52,17 +52,20 @@ constexpr int MLP_PT = 128;                              // tokens per workgroup
 constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
 constexpr int MLP_RING = 8;
 
-template <typename E, int D, int H>
+// NCW = hidden chunks run by one workgroup: H/128 (whole MLP of its panel), or — PARTIAL, second launch — a slice
+// of them for the panels of the last, partially filled round of CUs: the split workgroups write fp32 partial
+// outputs to a scratch buffer and mlp_reduce_kernel adds them, bias2 and the residual in a fixed order.
+template <typename E, int D, int H, int NCW, bool PARTIAL>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   typedef typename Op16<E>::V8 V8;
   constexpr int KC = D / 8;                              // 16-B k chunks per xn row
-  constexpr int NC = H / 128;                            // hidden chunks
+  constexpr int NC = NCW;                                // hidden chunks of this workgroup (H / 128 in total)
   constexpr int SA = D / 64;                             // ring stages per phase A
   constexpr int OT = D / 32;                             // output tiles (32 features each) per token block
   constexpr int OG = OT / 4;                             // output tile groups of 4 (one ring stage holds 4 row blocks)
   constexpr int SB = 2 * OG;                             // ring stages per phase B: (group, k half)
   constexpr int NS = NC * (SA + SB);                     // ring stages per panel
-  static_assert(D % 128 == 0 && H % 128 == 0, "mlp: D and H must be multiples of 128");
+  static_assert(D % 128 == 0 && H % 128 == 0 && (H / 128) % NCW == 0, "mlp: D and H must be multiples of 128");
   constexpr int NXF = D / 16;                            // xn B-operand fragments per lane (one per k16 step)
   constexpr int R = MLP_RING;
   __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 3 * D) * 4];
@@ -74,7 +77,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
-  const int64_t rb = (int64_t)blockIdx.x * 4 + w;        // this wave's 32-row block of x
+  constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
+  const int panel = a.panel0 + (int)blockIdx.x / SPLIT;
+  const int c0 = ((int)blockIdx.x % SPLIT) * NCW;        // first hidden chunk of this workgroup
+  const int64_t rb = (int64_t)panel * 4 + w;             // this wave's 32-row block of x
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
 
@@ -113,9 +119,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       if (p < NC - 1) { isA = r < SA; c = isA ? p + 1 : p; r = isA ? r : r - SA; }
       else { isA = false; c = NC - 1; }                  // trailing B(NC-1): r counts its stages
     }
-    if (isA) return W1 + ((size_t)(4 * c + w) * KC + 8 * r) * 512;
+    if (isA) return W1 + ((size_t)(4 * (c0 + c) + w) * KC + 8 * r) * 512;
     const int g = r >> 1, kh = r & 1;
-    return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * c + 8 * kh) * 512;
+    return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * (c0 + c) + 8 * kh) * 512;
   };
   auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS
     const char* src = stage_src(s) + lane * 16;
@@ -223,8 +229,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     sfor<0, 8>([&](auto U) {                             // one unit (8 values) at a time: bounds the live temporaries
       constexpr int u = decltype(U)::value, i = u >> 1, m = u & 1;
       __builtin_amdgcn_sched_barrier(0);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m) + 4 * half);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + c * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + (c0 + c) * 128 + i * 32 + 8 * (2 * m) + 4 * half);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + (c0 + c) * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
       const u32x2 lo = pack4<E>(acc1[i][8 * m] + b0[0], acc1[i][8 * m + 1] + b0[1], acc1[i][8 * m + 2] + b0[2], acc1[i][8 * m + 3] + b0[3]);
       const u32x2 hi = pack4<E>(acc1[i][8 * m + 4] + b1[0], acc1[i][8 * m + 5] + b1[1], acc1[i][8 * m + 6] + b1[2], acc1[i][8 * m + 7] + b1[3]);
       const u32x4 p = {lo[0], lo[1], hi[0], hi[1]};
@@ -346,8 +352,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 #if (MLX & 1)
   if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
 #endif
-  // ---- epilogue: x <- outT + bias2 + x.  lane = token r31 of row block rb; tile t, group q: features 32t+8q+4half..+3
-  if (rb * 32 + r31 < a.M) {
+  // ---- epilogue.  lane = token r31 of row block rb; tile t, group q: features 32t+8q+4half..+3
+  if constexpr (PARTIAL) {
+    // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
+    const int64_t rbl = rb - (int64_t)a.panel0 * 4;
+    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(blockIdx.x % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + half * 512 + r31 * 16;
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(pr + (size_t)(8 * t + 2 * q) * 512) = o;
+      }
+    });
+  } else if (rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + half * 512 + r31 * 16;    // + (8t + 2q) * 512
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
@@ -366,13 +384,79 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   }
 }
 
+// x[row block rb0 + i] += bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* partial, const float* b2, int64_t rb0, int tail_rb,
+                                                         int D, int nparts, int64_t M) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (row block, chunk, row) in blocked order
+  const int64_t per_rb = (int64_t)(D / 4) * 32;
+  if (id >= (int64_t)tail_rb * per_rb) return;
+  const int64_t rbl = id / per_rb;
+  const int rem = (int)(id - rbl * per_rb), chunk = rem >> 5, row = rem & 31;
+  if ((rb0 + rbl) * 32 + row >= M) return;
+  f32x4* xp = reinterpret_cast<f32x4*>(x) + (rb0 + rbl) * per_rb + rem;
+  f32x4 v = *xp;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + chunk * 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < nparts; ++p) {
+    const f32x4 pv = reinterpret_cast<const f32x4*>(partial)[((int64_t)p * tail_rb + rbl) * per_rb + rem];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += pv[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e] + v[e];
+  *xp = v;
+}
+
+int num_cus_mlp() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
 template <typename E>
-int launch_mlp(const MlpArgs& a, hipStream_t s) {
-  const dim3 grid((unsigned)((a.M + MLP_PT - 1) / MLP_PT)), blk(256);
-  if (a.D == 384 && a.H == 1536) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536>), grid, blk, 0, s, a);
-  else if (a.D == 128 && a.H == 512) hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512>), grid, blk, 0, s, a);
-  else return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
-  return check_launch("mlp_fused");
+int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
+  MlpArgs a = a_in;
+  const int npanels = (a.M + MLP_PT - 1) / MLP_PT;
+  if (a.D == 128 && a.H == 512) {
+    a.panel0 = 0;
+    hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512, 4, false>), dim3((unsigned)npanels), dim3(256), 0, s, a);
+    return check_launch("mlp_fused");
+  }
+  if (!(a.D == 384 && a.H == 1536)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
+  // One workgroup per CU: the panels of the last, partially filled round are cut along the hidden dimension into
+  // 4 (or 2) workgroups each, which write partial outputs to the caller's scratch; a small kernel reduces them.
+  const int slots = num_cus_mlp();
+  const int tail = a.no_tail_split ? 0 : npanels % slots;
+  int split = 1;
+  if (tail > 0 && tail * 4 <= slots) split = 4;
+  else if (tail > 0 && tail * 2 <= slots) split = 2;
+  const size_t need = (size_t)split * tail * MLP_PT * a.D * sizeof(float);
+  if (split > 1 && (!a.partial || a.partial_bytes < need)) split = 1;
+  const int main_panels = split > 1 ? npanels - tail : npanels;
+  if (main_panels > 0) {
+    a.panel0 = 0;
+    hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 12, false>), dim3((unsigned)main_panels), dim3(256), 0, s, a);
+    int rc = check_launch("mlp_fused");
+    if (rc) return rc;
+  }
+  if (split > 1) {
+    a.panel0 = main_panels;
+    a.tail_rb = tail * 4;
+    const dim3 grid((unsigned)(tail * split));
+    if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, true>), grid, dim3(256), 0, s, a);
+    int rc = check_launch("mlp_fused(tail)");
+    if (rc) return rc;
+    const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2,
+                       (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M);
+    return check_launch("mlp_reduce");
+  }
+  return EFFOCR_OK;
 }
 
 }  // namespace

@@ -169,10 +169,13 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
  * Linear(d,h) -> GELU(erf) -> Linear(h,d); models/encoders.py:58,63):  x_blk (fp32, in/out) <- x + fc2(gelu(fc1(LN(x)))).
  * w1_blk: fc1.weight [h,d] 16-bit fragment-blocked.  w2_perm: fc2.weight [d,h] 16-bit fragment-blocked with the k
  * (hidden) index permuted inside every group of 16: element e of 16-byte chunk c holds
- * k = 16*(c/2) + (e&3) + 8*(e>>2) + 4*(c&1).  (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m. */
+ * k = 16*(c/2) + (e&3) + 8*(e>>2) + 4*(c&1).  (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m.
+ * scratch_dev (optional, may be NULL): device scratch of scratch_bytes; with >= 64 MiB the 128-row panels of the last,
+ * partially filled round of CUs are split over the hidden dimension and reduced in a fixed order (same result
+ * bit for bit run to run; differs from the unsplit path only by fp32 summation order). */
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
                           const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
-                          int m, int d, int h, int rows_alloc, void* stream);
+                          int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream);
 /* The two embed-dim linears of a block on the blocked layout (timm Block: norm1 + attn.qkv; attn.proj + residual):
  *   mode 0: out_blk (16-bit [m,n]) = LayerNorm(x_blk fp32 [m,d]) . w^T + bias
  *   mode 1: x_blk (fp32 [m,d], in/out) += a_blk (16-bit [m,d]) . w^T + bias          (n == d)

@@ -115,7 +115,10 @@ def test_full_size_config2_properties(dev):
     assert torch.equal(e1, e2)                                                      # deterministic
     np.testing.assert_allclose(e1.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
     sub = enc.forward(x[100:164].contiguous(), normalize=True)
-    assert torch.equal(sub, e1[100:164])                                            # batch invariance
+    # batch invariance: which 128-row panels fall into the last, split round of CUs depends on the batch size, and
+    # the split changes the fp32 summation order of those panels (tail split) -> equal to the precision
+    # mode's noise, not bit for bit (the run-to-run determinism above is bitwise)
+    assert ((sub - e1[100:164]).abs().max() / e1.abs().max()).item() <= REL["bf16"]
     sel = [0, 511, 1023]
     ref = l2_normalize(encoder_forward(arch, sd, x[sel].cpu()))
     err = ((e1[sel].cpu() - ref).abs().max() / ref.abs().max()).item()

@@ -240,8 +240,9 @@ def perm16_columns(w):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(197 * 5, 384, 1536), (100, 128, 512), (1, 384, 1536), (128 * 3, 128, 512), (40000, 384, 1536)])
-def test_mlp_fused_blocked(hip_lib, dev, prec, shape):
+@pytest.mark.parametrize("scratch", [False, True])
+@pytest.mark.parametrize("shape", [(197 * 5, 384, 1536), (100, 128, 512), (1, 384, 1536), (128 * 3, 128, 512), (40000, 384, 1536), (128 * 140, 384, 1536)])
+def test_mlp_fused_blocked(hip_lib, dev, prec, shape, scratch):
     """mlp.hip: x + fc2(gelu(fc1(LN(x)))) in one kernel vs an fp64 restatement with the same operand rounding points
     (LN output and GELU output rounded to the operand type, as the unfused path does)."""
     M, D, H = shape
@@ -255,8 +256,12 @@ def test_mlp_fused_blocked(hip_lib, dev, prec, shape):
     xd = to_blocked(x, ra).to(dev)
     w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm16_columns(w2), D).to(dev)
     gd, bd, b1d, b2d = gamma.to(dev), beta.to(dev), b1.to(dev), b2.to(dev)
+    # with scratch the panels of the last partially filled round of CUs are split over the hidden dimension:
+    # M = 985 -> 8 panels x 4 parts; 40000 -> 256 + 57 x 4; 17920 -> 140 panels x 2 parts (140 * 4 > 256 CUs)
+    sc = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if scratch else None
     _lib.check(hip_lib.effocr_op_mlp_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6, _lib.ptr(w1d), _lib.ptr(b1d),
-                                             _lib.ptr(w2d), _lib.ptr(b2d), M, D, H, ra, _stream(dev)), "op_mlp_blocked")
+                                             _lib.ptr(w2d), _lib.ptr(b2d), M, D, H, ra, _lib.ptr(sc), sc.numel() if scratch else 0,
+                                             _stream(dev)), "op_mlp_blocked")
     torch.cuda.synchronize()
     got = from_blocked(xd.cpu(), M, D, ra).double()
     xn = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6).to(TDT[prec]).double()
