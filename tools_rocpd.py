@@ -8,6 +8,9 @@ FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of a wide co
 import json, os, re, sqlite3, sys
 
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
+    ("mlp_fused_kernelIDF16bLi384ELi1536ELi12ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "mlp_fused_tail"),
+    ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "mlp_fused_tail"), ("mlp_reduce_kernel", "mlp_fused_reduce"),
+    ("rowlin_kernel", "rowlin"), ("layernorm_blocked", "layernorm_blocked"),
     ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
     ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm3_kernelIDF16bLi3ELi4ELi2", "gemm_fc2_resid"),
     ("gemm3_kernel<", "gemm_fc2_resid_tail"), ("gemm2_kernelIDF16bLi2", "gemm_fc2_resid"),
@@ -58,7 +61,7 @@ def main(tag):
         f.write(f"# rocprofv3 --kernel-trace --pmc <set> (one pass per set, no other trace domain), per-dispatch averages, tag {tag}\n")
         f.write("# SQ_* cycle counters are quad-cycles summed over waves/SEs; SQ_VALU_MFMA_BUSY_CYCLES = 32 x N_mfma; FETCH/WRITE_SIZE in KB\n")
         for k, d in sorted(allc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-            if not any(s in k for s in ("panel", "gemm", "attention", "knn_partial")):
+            if not any(s in k for s in ("panel", "gemm", "attention", "knn_partial", "mlp", "rowlin")):
                 continue
             f.write(f"\n[{k}]\n")
             for c in ctrs:
@@ -74,6 +77,9 @@ def main(tag):
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             traffic[k] = {"read_bytes": 2 * d["FETCH_SIZE"] * 1024, "write_bytes": d["WRITE_SIZE"] * 1024,
                           "hbm_bytes_per_launch": 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024}
+    parts = [traffic[k] for k in ("mlp_fused_main", "mlp_fused_tail", "mlp_fused_reduce") if k in traffic]
+    if parts:   # bench.py times the three launches of the fused MLP as ONE class ("mlp_fused"): same aggregate here
+        traffic["mlp_fused"] = {key: sum(p[key] for p in parts) for key in parts[0]}
     with open(f"profiles/{tag}_traffic.json", "w") as f:
         json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md)",
                    "kernels": traffic}, f, indent=1)
