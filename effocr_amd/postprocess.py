@@ -1,0 +1,140 @@
+"""Line assembly around the recognizer: what `EffOCR.infer` does with the localizer's boxes
+before the crops are cut and with the recognised characters afterwards.  Host-side Python, no GPU work.
+
+Reference: `infer_effocr.py`
+  * `jp_preprocess` (:412-418)   character boxes sorted along the reading direction, score > score_thresh
+  * `en_preprocess` (:345-367)   the same for characters and words, plus `word_end_idx`: for every word box the
+                                 index of the character whose RIGHT edge lies right of the word's LEFT edge and
+                                 closest to it (i.e. the word's first character).  Quirk kept: `closest_idx` is
+                                 not reset between words, so a word without any candidate repeats the previous index
+  * `en_postprocess` (:370-410)  a space before every character in `word_end_idx`; with `anchor_margin` set,
+                                 case repair from box heights: the mean height of the "distinct lowercase" anchors
+                                 a/e/n/r decides which characters are lowered (height within margin), which of
+                                 w/u/o/s/v/c/x/z are raised (height > mean * (1 + margin * multiplier)), and which
+                                 "-" sitting on the baseline become ".".  Quirk kept: returns None when ANY input
+                                 (including `word_end_idx`) is empty
+  * `infer` (:255-343)           glue: boxes -> crops -> recognizer -> strings
+The optional homoglyph spell checker (`utils/spell_check_utils.py`, needs external dictionaries) is out of scope:
+`spell_check=True` raises NotImplementedError.
+"""
+import numpy as np
+
+DISTINCT_LOWERCASE = "aenr"          # utils/spell_check_utils.py:60-61
+NONDISTINCT_LOWERCASE = "wuosvcxz"   # utils/spell_check_utils.py:64-65
+LARGE_NUM = 1_000_000                # infer_effocr.py:239
+
+
+class LinePostprocessor:
+    def __init__(self, lang="jp", vertical=False, score_thresh=0.5, score_thresh_word=0.5, anchor_margin=None,
+                 anchor_multiplier=4, spell_check=False):
+        if lang not in ("jp", "en"):
+            raise ValueError("lang must be 'jp' or 'en'")
+        if spell_check:
+            raise NotImplementedError("the homoglyph spell checker needs the reference's external dictionaries")
+        self.lang, self.vertical = lang, bool(vertical)
+        self.score_thresh, self.score_thresh_word = score_thresh, score_thresh_word
+        self.anchor_margin, self.anchor_multiplier = anchor_margin, anchor_multiplier
+
+    # ---- before the recognizer -------------------------------------------------------------------------
+    def _sorted_kept(self, boxes, thresh):
+        b = np.asarray(boxes, dtype=np.float64).reshape(-1, 5)
+        order = np.argsort(b[:, 1 if self.vertical else 0], kind="stable")      # sorted() is stable too
+        b = b[order]
+        return [row[:4] for row in b if row[4] > thresh]
+
+    def jp_preprocess(self, result):
+        """result[0][0]: [n,5] character boxes (x0,y0,x1,y1,score) -> sorted list of [4] arrays."""
+        return self._sorted_kept(result[0][0], self.score_thresh)
+
+    def en_preprocess(self, result):
+        """result (or result[0]) = (char boxes [n,5], word boxes [m,5]) -> (sorted char boxes, word_end_idx)."""
+        bboxes_char, bboxes_word = result if isinstance(result[0], np.ndarray) else result[0]
+        chars = self._sorted_kept(bboxes_char, self.score_thresh)
+        words = self._sorted_kept(bboxes_word, self.score_thresh_word)
+        rights = np.array([c[2] for c in chars], dtype=np.float64)
+        word_end_idx, closest = [], 0
+        for wleft in (wb[0] for wb in words):
+            cand = np.nonzero(rights > wleft)[0]
+            if cand.size:                                                     # strict '<' keeps the FIRST minimum
+                d = np.abs(wleft - rights[cand])
+                if d.min() < LARGE_NUM:
+                    closest = int(cand[int(np.argmin(d))])
+            word_end_idx.append(closest)
+        return chars, word_end_idx
+
+    # ---- after the recognizer --------------------------------------------------------------------------
+    def en_postprocess(self, line_output, word_end_idx, charheights, charbottoms):
+        if not (len(line_output) == len(charheights) == len(charbottoms)):
+            raise AssertionError(f"{len(line_output)} == {len(charheights)} == {len(charbottoms)}; {line_output}")
+        if len(line_output) == 0 or len(word_end_idx) == 0:
+            return None
+        starts = set(word_end_idx)
+        chars, heights, bottoms = [], [], []
+        for idx, ch in enumerate(line_output):
+            if idx in starts:
+                chars.append(" "); heights.append(LARGE_NUM); bottoms.append(0)
+            chars.append(ch); heights.append(charheights[idx]); bottoms.append(charbottoms[idx])
+        if bottoms[0] == 0:
+            bottoms = bottoms[1:]
+        if heights[0] == LARGE_NUM:
+            heights = heights[1:]
+        line = "".join(chars).strip()
+        if len(heights) != len(line):
+            raise AssertionError(f"charheights_w_spaces = {len(heights)}; output = {len(line)}; {line}")
+        anchors = [i for i, c in enumerate(line) if c in DISTINCT_LOWERCASE]
+        if not anchors or self.anchor_margin is None:
+            return line
+        h = np.asarray(heights, dtype=np.float64)
+        b = np.asarray(bottoms, dtype=np.float64)
+        mean_h = sum(heights[i] for i in anchors) / len(anchors)
+        mean_b = sum(bottoms[i] for i in anchors) / len(anchors)
+        lower = np.abs(h - mean_h) < self.anchor_margin * mean_h
+        upper = (h - mean_h) > self.anchor_margin * self.anchor_multiplier * mean_h
+        period = np.abs(b - mean_b) < self.anchor_margin * mean_h
+        out = []
+        for i, c in enumerate(line):
+            if lower[i]:
+                c = c.lower()
+            if upper[i] and c in NONDISTINCT_LOWERCASE:
+                c = c.upper()
+            if line[i] == "-" and period[i]:
+                c = "."
+            out.append(c)
+        return "".join(out)
+
+
+class LineRecognizer:
+    """`EffOCR.infer` from the localizer result on (infer_effocr.py:268-343): boxes -> crops (on the device) ->
+    recognizer -> strings.  `recognizer` is an `effocr_amd.pipeline.Recognizer`; `double_clipped` crops span the
+    whole line height (or width when vertical) like the reference's flag (:288-292)."""
+
+    def __init__(self, recognizer, post: LinePostprocessor, double_clipped=False, char_transform=None):
+        self.recognizer, self.post = recognizer, post
+        self.double_clipped, self.char_transform = bool(double_clipped), char_transform
+
+    def infer(self, image, result):
+        post = self.post
+        if post.lang == "en":
+            _, word_bboxes = result if isinstance(result[0], np.ndarray) else result[0]
+            char_bboxes, word_end_idx = post.en_preprocess(result)
+        else:
+            char_bboxes, word_bboxes, word_end_idx = post.jp_preprocess(result), None, None
+        H, W = image.shape[0], image.shape[1]
+        boxes = []
+        for bb in char_bboxes:
+            x0, y0, x1, y1 = (int(round(float(v))) for v in bb)
+            if self.double_clipped:
+                x0, y0, x1, y1 = (0, y0, W, y1) if post.vertical else (x0, 0, x1, H)
+            boxes.append((x0, y0, x1, y1))
+        if not boxes:
+            return None, None, None, None                                   # "No content detected!" (:304-306)
+        from .transforms import PairedTransform
+        tf = self.char_transform or PairedTransform(size=getattr(self.recognizer.recongizer_encoder, "img_size", 224))
+        crops = tf.boxes(image, boxes, already_int=True)
+        nearest_chars, output_nns, output = self.recognizer(crops)
+        if post.lang == "en":
+            heights = [float(bb[3] - bb[1]) for bb in char_bboxes]
+            bottoms = [float(bb[3]) for bb in char_bboxes]
+            first = "".join(x[0] for x in nearest_chars)                     # un-stripped: one character per box
+            output = post.en_postprocess(first if len(first) == len(heights) else output, word_end_idx, heights, bottoms)
+        return output, output_nns, char_bboxes, word_bboxes

@@ -128,3 +128,33 @@ def test_recognize_boxes_end_to_end(dev):
     same = sum([chars[j] for j in I_ref[i]] == nearest[i] for i in range(len(boxes)))
     assert same >= len(boxes) - 1                      # fp32 GPU vs CPU embeddings: at most one near-tie may swap
     assert rec.recognize_boxes(img, []) == ([], [], "")
+
+
+def test_line_recognizer_en_end_to_end(dev):
+    """infer_effocr.py:268-343 on the device path: localizer result (char + word boxes) -> crops -> encoder -> kNN ->
+    en_postprocess.  Each box retrieves its own glyph (index = the boxes' own embeddings); the word boxes put spaces."""
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import FaissKNN, IndexFlatIP
+    from effocr_amd.pipeline import Recognizer
+    from effocr_amd.postprocess import LinePostprocessor, LineRecognizer
+    from effocr_amd.transforms import PairedTransform
+    from effocr_amd.weights import init_state_dict
+    img = _image(60, 400, 9)
+    text = "theCATran"
+    xs = [5 + 40 * i for i in range(len(text))]
+    chars_b = np.array([[x, 10, x + 30, 50, 0.9] for x in xs] + [[380, 10, 395, 50, 0.1]], dtype=np.float32)[::-1].copy()   # reversed + a low-score box
+    words_b = np.array([[3, 8, 116, 52, 0.9], [124, 8, 236, 52, 0.9], [244, 8, 356, 52, 0.9]], dtype=np.float32)
+    sd = init_state_dict("resnet18", seed=2)
+    enc = HipEncoder("resnet18", sd, img_size=32, precision="fp32", device=dev)
+    tf = PairedTransform(size=32, device=dev)
+    emb = enc.forward(tf.boxes(img, [(x, 10, x + 30, 50) for x in xs], already_int=True), normalize=True)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
+    knn.train(emb)
+    rec = Recognizer(enc, knn, list(text), knn=3)
+    lr = LineRecognizer(rec, LinePostprocessor(lang="en"), char_transform=tf)
+    out, nns, cb, wb = lr.infer(img, (chars_b, words_b))
+    assert out == "the CAT ran" and len(nns) == len(text) and len(cb) == len(text) and wb.shape == (3, 5)
+    jp = LineRecognizer(rec, LinePostprocessor(lang="jp"), char_transform=tf)
+    out_jp, _, cb_jp, wb_jp = jp.infer(img, [[chars_b]])
+    assert out_jp == text and wb_jp is None
+    assert jp.infer(img, [[chars_b[:1] * 0]]) == (None, None, None, None)            # nothing above the score threshold

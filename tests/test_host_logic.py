@@ -156,3 +156,73 @@ def test_transform_box_resolution_matches_numpy_slicing():
         with pytest.raises(ValueError):
             slice_boxes([bad], 30, 50)
     assert round_boxes([(0.5, 1.5, 2.5, 3.49, 0.9)]) == [(0, 2, 2, 3)]
+
+
+# ---------------------------------------------------------------- line pre/post-processing
+def _boxes(specs):
+    return np.array(specs, dtype=np.float32)
+
+
+def test_en_preprocess_word_starts_and_quirks():
+    from effocr_amd.postprocess import LinePostprocessor
+    from oracle import postprocess_ref as R
+    #            x0  y0  x1  y1  score           characters given out of order, one below threshold
+    chars = _boxes([[30, 2, 38, 20, .9], [0, 2, 8, 20, .9], [10, 5, 18, 20, .9], [20, 3, 28, 20, .4], [44, 2, 52, 20, .8], [54, 2, 60, 20, .7]])
+    words = _boxes([[43, 0, 61, 22, .9], [0, 0, 39, 22, .95], [100, 0, 120, 22, .9], [5, 0, 9, 9, .2]])
+    post = LinePostprocessor(lang="en")
+    got_c, got_w = post.en_preprocess((chars, words))
+    ref_c, ref_w = R.en_preprocess(chars, words)
+    assert [list(map(float, c)) for c in got_c] == [list(map(float, c)) for c in ref_c]
+    assert [c[0] for c in got_c] == [0, 10, 30, 44, 54]               # sorted by x0, score 0.4 dropped
+    # word at x=0 starts at char 0, word at x=43 at char 3; the word at x=100 has no candidate and REPEATS 3
+    assert got_w == ref_w == [0, 3, 3]
+    # mmdet-style nesting: result[0] = (chars, words)
+    assert post.en_preprocess([(chars, words)])[1] == got_w
+    # vertical: sort by y0
+    v = LinePostprocessor(lang="en", vertical=True)
+    assert [c[1] for c in v.en_preprocess((chars, words))[0]] == sorted(c[1] for c in ref_c)
+    jp = LinePostprocessor(lang="jp", score_thresh=0.75)
+    assert [c[0] for c in jp.jp_preprocess([[chars]])] == [0, 10, 30, 44]
+
+
+def test_en_postprocess_spaces_case_and_period():
+    from effocr_amd.postprocess import LinePostprocessor
+    from oracle import postprocess_ref as R
+    line = "theCATran-"
+    #        t   h   e   C   A   T   r   a   n   -
+    hts = [18, 18, 10, 10, 10, 18, 10, 10, 10, 3]
+    bots = [20, 20, 20, 20, 20, 20, 20, 20, 20, 19.5]
+    wei = [0, 3, 6]
+    for margin in (None, 0.15):
+        post = LinePostprocessor(lang="en", anchor_margin=margin)
+        got = post.en_postprocess(line, wei, hts, bots)
+        assert got == R.en_postprocess(line, wei, hts, bots, anchor_margin=margin)
+    assert LinePostprocessor(lang="en").en_postprocess(line, wei, hts, bots) == "the CAT ran-"
+    # anchors e, a, n, r (height 10): chars within 15 % are lowered (C, A -> c, a); '-' on the baseline -> '.'
+    assert LinePostprocessor(lang="en", anchor_margin=0.15).en_postprocess(line, wei, hts, bots) == "the caT ran."
+    # raising: a nondistinct lowercase letter far taller than the anchors
+    got = LinePostprocessor(lang="en", anchor_margin=0.1).en_postprocess("anso", [0], [10, 10, 20, 10], [5, 5, 5, 5])
+    assert got == R.en_postprocess("anso", [0], [10, 10, 20, 10], [5, 5, 5, 5], anchor_margin=0.1) == "anSo"
+    # quirks: no word boxes -> None; length mismatch -> AssertionError
+    assert LinePostprocessor(lang="en").en_postprocess("abc", [], [1, 1, 1], [1, 1, 1]) is None
+    assert R.en_postprocess("abc", [], [1, 1, 1], [1, 1, 1]) is None
+    with pytest.raises(AssertionError):
+        LinePostprocessor(lang="en").en_postprocess("abc", [0], [1, 1], [1, 1, 1])
+    with pytest.raises(NotImplementedError):
+        LinePostprocessor(lang="en", spell_check=True)
+
+
+def test_postprocess_matches_restatement_on_random_lines():
+    from effocr_amd.postprocess import LinePostprocessor
+    from oracle import postprocess_ref as R
+    rng = np.random.default_rng(0)
+    alphabet = list("aenrwuosvcxzTHKQ-.")
+    for trial in range(200):
+        n = int(rng.integers(1, 30))
+        line = "".join(rng.choice(alphabet, n))
+        hts = [float(h) for h in rng.choice([3, 9, 10, 11, 18, 19, 60], n)]
+        bots = [float(b) for b in rng.choice([19.0, 20.0, 20.5, 25.0], n)]
+        wei = sorted(set(int(i) for i in rng.integers(0, n, int(rng.integers(1, 5)))))
+        margin = [None, 0.1, 0.25][trial % 3]
+        post = LinePostprocessor(lang="en", anchor_margin=margin)
+        assert post.en_postprocess(line, wei, hts, bots) == R.en_postprocess(line, wei, hts, bots, anchor_margin=margin), (line, wei)
