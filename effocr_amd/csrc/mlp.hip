@@ -109,8 +109,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 
   // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
   // Wave w copies row block w of the stage: 4 pieces of 1 KB (two adjacent k-chunk cells each).
-  auto stage_src = [&](int s) __attribute__((always_inline)) -> const char* {
-    int c, r;
+  auto stage_src = [&](int s_in) __attribute__((always_inline)) -> const char* {
+    const int s = s_in < NS ? s_in : NS - 1;             // a stage index past the end (the rolled loop's "plenty follows"
+    int c, r;                                            // flag is optimistic in its last iteration for small D) re-reads the last stage
+
     bool isA;
     if (s < SA) { c = 0; r = s; isA = true; }
     else {
