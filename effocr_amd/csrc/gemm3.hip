@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
       if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = (float)(E)v[e];              // same argument rounding as panel.hip
-        gelu_erf_fast_n<16>(v);
+        gelu_fold_n<E, 16>(v);
       }
       if (ok) {
 #pragma unroll
