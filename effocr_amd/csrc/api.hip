@@ -30,7 +30,7 @@ struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std:
 
 struct VitCfg { int D, depth, heads, mlp; };
 struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w;
-                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, fc2w_p; };   // _p: blocked + k permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
+                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, fc2w_p, projw_pp, fc2w_pp, projb_p, fc2b_p; };   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // _p: blocked + k permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
 struct ConvSpec { std::string w, bn; int cin, cout, k, stride, pad; size_t w_off, b_off; };
 
 }  // namespace
@@ -57,6 +57,7 @@ struct effocr_encoder {
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
   int use_rowlin = 0;               // 1: register-resident-input kernels (rowlin.hip) for LN1+qkv and proj+residual instead of the row-panel ones (measured 7 % slower: A/B switch)
+  int use_projf = 0;                // 1: attn.proj + residual fused in front of the fused MLP kernel (correct and tested; measured 0.5 ms slower than the separate row-panel launch: A/B switch)
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
@@ -147,6 +148,10 @@ void build_vit(effocr_encoder* e) {
       VitLayerOff& L = e->layers[i];
       L.fc2w_b = a.take((size_t)D * mlp * es);
       L.fc2w_p = a.take((size_t)D * mlp * es);
+      L.fc2w_pp = a.take((size_t)D * mlp * es);
+      L.projw_pp = a.take((size_t)D * D * es);
+      L.projb_p = a.take((size_t)D * 4);
+      L.fc2b_p = a.take((size_t)D * 4);
       {                                                  // gemm3 can run every linear (default where no row-panel kernel exists)
         L.qkvw_b = a.take((size_t)3 * D * D * es);
         L.projw_b = a.take((size_t)D * D * es);
@@ -214,19 +219,31 @@ void put_op(std::vector<char>& blob, size_t off, const float* src, size_t n, int
 
 // [N,K] fp32 -> 16-bit fragment-blocked [N/32][K/8][32 rows][8 elements] (common.hpp blk_off); N % 32 == 0, K % 8 == 0
 // perm16: element e of chunk c holds k = 16*(c/2) + (e&3) + 8*(e>>2) + 4*(c&1) instead of 8c + e — the order in
-// which the swapped-MFMA C-layout of the previous GEMM hands its values over as a B-operand (mlp.hip); K % 16 == 0
-void put_op_blocked(std::vector<char>& blob, size_t off, const float* src, int N, int K, int prec, bool perm16 = false) {
+// which the swapped-MFMA C-layout of the previous GEMM hands its values over as a B-operand (mlp.hip); K % 16 == 0.
+// rowperm: packed row 32b + p holds source row 32b + rowperm32(p) — then the swapped C-layout gives every lane 8
+// CONSECUTIVE output features per register octet (= the B-operand / LayerNorm layout of the next stage).
+int rowperm32(int p) {
+  const int h = (p >> 2) & 1, r = (p & 3) + 4 * (p >> 3);
+  return 8 * (2 * (r >> 3) + h) + (r & 7);
+}
+void put_op_blocked(std::vector<char>& blob, size_t off, const float* src, int N, int K, int prec, bool perm16 = false, bool rowperm = false) {
   uint16_t* d = reinterpret_cast<uint16_t*>(blob.data() + off);
   const int kch = K / 8;
-  for (int n = 0; n < N; ++n)
+  for (int n = 0; n < N; ++n) {
+    const int ns = rowperm ? (n & ~31) + rowperm32(n & 31) : n;
     for (int c = 0; c < kch; ++c) {
       uint16_t* cell = d + ((size_t)(n >> 5) * kch + c) * 256 + (n & 31) * 8;
       for (int e = 0; e < 8; ++e) {
         const int k = perm16 ? 16 * (c >> 1) + (e & 3) + 8 * (e >> 2) + 4 * (c & 1) : c * 8 + e;
-        const float v = src[(size_t)n * K + k];
+        const float v = src[(size_t)ns * K + k];
         cell[e] = prec == PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
       }
     }
+  }
+}
+void put_f32_rowperm(std::vector<char>& blob, size_t off, const float* src, int n) {
+  float* d = reinterpret_cast<float*>(blob.data() + off);
+  for (int i = 0; i < n; ++i) d[i] = src[(i & ~31) + rowperm32(i & 31)];
 }
 
 const std::vector<float>& P(const effocr_encoder* e, const std::string& n) { return e->params[e->index.at(n)].data; }
@@ -258,6 +275,10 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
     if (e->prec != PREC_FP32) {
       put_op_blocked(blob, L.fc2w_b, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec);
       put_op_blocked(blob, L.fc2w_p, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec, true);
+      put_op_blocked(blob, L.fc2w_pp, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec, true, true);
+      put_op_blocked(blob, L.projw_pp, P(e, p + "attn.proj.weight").data(), D, D, e->prec, false, true);
+      put_f32_rowperm(blob, L.projb_p, P(e, p + "attn.proj.bias").data(), D);
+      put_f32_rowperm(blob, L.fc2b_p, P(e, p + "mlp.fc2.bias").data(), D);
       {
         put_op_blocked(blob, L.qkvw_b, P(e, p + "attn.qkv.weight").data(), 3 * D, D, e->prec);
         put_op_blocked(blob, L.projw_b, P(e, p + "attn.proj.weight").data(), D, D, e->prec);
@@ -359,6 +380,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const int blk = (e->use_blocked && g2p && ((panel && g2 && e->panel_impl == 0) || g3all)) ? 1 : 0;
   const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
+  const bool projf = mlpf && !rl && e->use_projf;
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
@@ -386,16 +408,23 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
+      if (!projf) {
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
       p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split; p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s) : panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
+      }
       }
       if (mlpf) {
         MlpArgs m{};
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
         m.W2p = wb + L.fc2w_p; m.b2 = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
         m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split;   // the hidden buffer is free on this path
+        if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
+          m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p); m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b);
+          if ((rc = timed(e, "proj_mlp_fused", 4.0 * Md * Hd * Dd + 2.0 * Md * Dd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
+          continue;
+        }
         if ((rc = timed(e, "mlp_fused", 4.0 * Md * Hd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
         continue;
       }
@@ -613,6 +642,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
+  if (n == "use_projf") { enc->use_projf = value; return EFFOCR_OK; }
   if (n == "use_rowlin") { enc->use_rowlin = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
@@ -769,6 +799,19 @@ int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_de
     return fail(EFFOCR_EINVAL, "op_mlp_blocked: NULL device pointer");
   MlpArgs a{};
   a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_dev;
+  a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
+  return mlp_fused(precision, a, S(stream));
+}
+
+int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_blk_dev, const void* wp_perm_dev, const float* bp_perm_dev,
+                               const float* gamma_dev, const float* beta_dev, float eps, const void* w1_blk_dev, const float* b1_dev,
+                               const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev, int m, int d, int h, int rows_alloc,
+                               void* scratch_dev, size_t scratch_bytes, void* stream) {
+  if (m > 0 && (!x_blk_dev || !a_blk_dev || !wp_perm_dev || !bp_perm_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_perm_dev || !b2_dev))
+    return fail(EFFOCR_EINVAL, "op_proj_mlp_blocked: NULL device pointer");
+  MlpArgs a{};
+  a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_perm_dev;
+  a.b2_logical = b2_dev; a.A = a_blk_dev; a.Wpp = wp_perm_dev; a.bp = bp_perm_dev;
   a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
   return mlp_fused(precision, a, S(stream));
 }

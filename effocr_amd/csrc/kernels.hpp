@@ -47,6 +47,10 @@ struct MlpArgs {
   float* partial; size_t partial_bytes;   // optional scratch for the tail split (>= 4 * 64 * 128 * D * 4 bytes covers every case)
   int no_tail_split;                // 1: single launch (A/B switch)
   int panel0, tail_rb;              // set by the launcher
+  // optional leading projection + residual (attn.proj): x <- x + A . Wp^T + bp, fused in front of the MLP.  Then Wpp is
+  // Wp fragment-blocked with the rows of every 32-row block permuted, bp / b2 permuted alike, W2p additionally row-
+  // permuted (put_op_blocked rowperm), and b2_logical is the unpermuted fc2 bias (tail reduction)
+  const void* A; const void* Wpp; const float* bp; const float* b2_logical;
 };
 bool mlp_fused_supported(int prec, int D, int H);
 int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);

@@ -31,7 +31,7 @@
 #define EFFOCR_EXP 0
 #endif
 // timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
-// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop
+// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 no residual loads after the projection
 #if EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000
 #define MLX (EFFOCR_EXP - 2000)
 #else
@@ -55,7 +55,11 @@ constexpr int MLP_RING = 8;
 // NCW = hidden chunks run by one workgroup: H/128 (whole MLP of its panel), or — PARTIAL, second launch — a slice
 // of them for the panels of the last, partially filled round of CUs: the split workgroups write fp32 partial
 // outputs to a scratch buffer and mlp_reduce_kernel adds them, bias2 and the residual in a fixed order.
-template <typename E, int D, int H, int NCW, bool PARTIAL>
+// PROJ: the attention output projection + residual runs first, in the same workgroup:  x <- x + a . Wp^T + bp.
+// Its weight copy has the rows of every 32-row block permuted (api.hip put_op_blocked rowperm) so that the swapped
+// C-layout hands each lane 8 CONSECUTIVE output features per (tile, register octet) — exactly the fp32 chunks
+// 4t+2half, 4t+2half+1 the LayerNorm below expects in xv[]: accumulators -> (+bias, +residual) -> xv, no exchange.
+template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   typedef typename Op16<E>::V8 V8;
   constexpr int KC = D / 8;                              // 16-B k chunks per xn row
@@ -64,16 +68,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   constexpr int OT = D / 32;                             // output tiles (32 features each) per token block
   constexpr int OG = OT / 4;                             // output tile groups of 4 (one ring stage holds 4 row blocks)
   constexpr int SB = 2 * OG;                             // ring stages per phase B: (group, k half)
-  constexpr int NS = NC * (SA + SB);                     // ring stages per panel
+  constexpr int SP = PROJ ? OG * SA : 0;                 // ring stages of the projection: (output group, k stage)
+  constexpr int NS = SP + NC * (SA + SB);                // ring stages per panel
   static_assert(D % 128 == 0 && H % 128 == 0 && (H / 128) % NCW == 0, "mlp: D and H must be multiples of 128");
   constexpr int NXF = D / 16;                            // xn B-operand fragments per lane (one per k16 step)
   constexpr int R = MLP_RING;
-  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 3 * D) * 4];
+  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 4 * D) * 4];
   char* sW = smem;
   float* sB1 = reinterpret_cast<float*>(smem + R * MLP_STAGE);
   float* sB2 = sB1 + H;
   float* sG = sB2 + D;                                   // norm2 weight / bias: LDS reads do not queue behind the ring's DMAs
   float* sBt = sG + D;
+  float* sBp = sBt + D;                                  // proj bias (row-permuted like its weight)
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
@@ -84,12 +90,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
 
-  // ---- x rows first (oldest in the in-order VM queue: LayerNorm can start while the ring fills).
+  // ---- input rows first (oldest in the in-order VM queue: work can start while the ring fills).
   // lane = (row r31, half): 16-bit k chunk 2t+half of its row = fp32 chunks 4t+2half, 4t+2half+1
   f32x4 xv[2 * NXF];
-  {
-    const int64_t rbc = rb < (a.rows_alloc >> 5) ? rb : (a.rows_alloc >> 5) - 1;
-    const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
+  V8 xf[NXF];                                            // B-operand fragments: attention output (PROJ), then LayerNorm(x)
+  const int64_t rbc = rb < (a.rows_alloc >> 5) ? rb : (a.rows_alloc >> 5) - 1;
+  const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
+  if constexpr (PROJ) {
+    const char* ab = static_cast<const char*>(a.A) + rbc * KC * 512 + half * 512 + r31 * 16;
+#pragma unroll
+    for (int t = 0; t < NXF; ++t) xf[t] = *reinterpret_cast<const V8*>(ab + (size_t)t * 1024);
+  } else {
 #pragma unroll
     for (int t = 0; t < NXF; ++t) {
 #if (MLX & 2)
@@ -104,14 +115,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     }
   }
   for (int n = tid; n < H; n += 256) sB1[n] = a.b1[n];
-  for (int n = tid; n < D; n += 256) { sB2[n] = a.b2[n]; sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; }
+  for (int n = tid; n < D; n += 256) { sB2[n] = a.b2[n]; sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; if constexpr (PROJ) sBp[n] = a.bp[n]; }
   __syncthreads();                                       // parameters visible (and x has landed) before the ring starts filling
 
   // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
   // Wave w copies row block w of the stage: 4 pieces of 1 KB (two adjacent k-chunk cells each).
   auto stage_src = [&](int s_in) __attribute__((always_inline)) -> const char* {
-    const int s = s_in < NS ? s_in : NS - 1;             // a stage index past the end (the rolled loop's "plenty follows"
+    int s = s_in < NS ? s_in : NS - 1;                   // a stage index past the end (the rolled loop's "plenty follows"
     int c, r;                                            // flag is optimistic in its last iteration for small D) re-reads the last stage
+    if constexpr (PROJ) {
+      if (s < SP) {                                      // projection: stage (group g = s / SA, k stage s % SA)
+        const int g = s / SA, ks = s - g * SA;
+        return static_cast<const char*>(a.Wpp) + ((size_t)(4 * g + w) * KC + 8 * ks) * 512;
+      }
+      s -= SP;
+    }
 
     bool isA;
     if (s < SA) { c = 0; r = s; isA = true; }
@@ -138,9 +156,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       for (int i = 0; i < 4; ++i) issue_piece(s0, i);
     }
 
-  // ---- LayerNorm in registers -> xf[t] = B-operand fragment of k16 step t
-  V8 xf[NXF];
-  {
+  // ---- LayerNorm in registers: xv (this lane's half of the row, fp32) -> xf[t] = B-operand fragment of k16 step t
+  auto layernorm_to_xf = [&]() __attribute__((always_inline)) {
     float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < 2 * NXF; ++i) sm += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
@@ -168,7 +185,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       const u32x4 q = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
       xf[t] = __builtin_bit_cast(V8, q);
     }
-  }
+  };
+  if constexpr (!PROJ) layernorm_to_xf();
 
   f32x16 acc1[4];                                        // hT tiles of the current chunk
   f32x16 acc2[OT];                                       // outT tiles
@@ -330,6 +348,53 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     });
   };
 
+  if constexpr (PROJ) {
+    // ---- projection: outT[D x 32 tok] = Wpp . a^T, (group g, k stage) ring stages; B-operand = attention fragments
+    sfor<0, OG>([&](auto G_) {
+      constexpr int g = decltype(G_)::value;
+      sfor<0, SA>([&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        ring_stage(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+          constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+          acc2[4 * g + i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc2[4 * g + i]);
+        });
+      });
+    });
+    // x_new = outT + bias + x: with the row-permuted weight, registers 4q..4q+3 of tile t are the fp32 chunk
+    // 8t + 4(q>>1) + 2half + (q&1) of the row = xv[2(2t + (q>>1)) + (q&1)].  Nothing is stored here: acc2 keeps
+    // outT + bias, fc2 accumulates on top of it and the final epilogue adds the (old) residual once.  Of a split
+    // tail panel only part 0 keeps it (the reduction adds every part to the old x).
+    const bool keep = !PARTIAL || c0 == 0;
+    __builtin_amdgcn_sched_barrier(0);                   // the 48 residual loads must not move up into the projection,
+    asm volatile("" ::: "memory");                       // where the attention fragments still hold 96 VGPRs
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#if (MLX & 128)
+        const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f + q};
+        xv[2 * (2 * t + (q >> 1)) + (q & 1)] = cst;
+        if (a.M < 0)
+#endif
+        xv[2 * (2 * t + (q >> 1)) + (q & 1)] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
+      }
+    });
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sBp + t * 32 + 8 * q + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pb = acc2[t][4 * q + e] + bv[e];
+          xv[2 * (2 * t + (q >> 1)) + (q & 1)][e] += pb;
+          acc2[t][4 * q + e] = keep ? pb : 0.f;
+        }
+      }
+    });
+    layernorm_to_xf();
+  }
+
   // Schedule (ring stream order A(0) | A(1) | B(0) | A(2) | B(1) | ...).  ONE hand-over set: parked after A(c) — once B(c-1)
   // has consumed the previous contents — activated in place under A(c+1), consumed by B(c):
   //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
@@ -354,33 +419,35 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 #if (MLX & 1)
   if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
 #endif
-  // ---- epilogue.  lane = token r31 of row block rb; tile t, group q: features 32t+8q+4half..+3
+  // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row:
+  // standard C-layout 8t + 2q + half; with PROJ (row-permuted weight copies) 8t + 4(q>>1) + 2half + (q&1)
+  auto cq = [&](int t, int q) __attribute__((always_inline)) { return PROJ ? 8 * t + 4 * (q >> 1) + 2 * half + (q & 1) : 8 * t + 2 * q + half; };
   if constexpr (PARTIAL) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
     const int64_t rbl = rb - (int64_t)a.panel0 * 4;
-    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(blockIdx.x % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + half * 512 + r31 * 16;
+    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(blockIdx.x % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + r31 * 16;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(pr + (size_t)(8 * t + 2 * q) * 512) = o;
+        *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
   } else if (rb * 32 + r31 < a.M) {
-    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + half * 512 + r31 * 16;    // + (8t + 2q) * 512
+    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
       f32x4 rv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)(8 * t + 2 * q) * 512);
+      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)cq(t, q) * 512);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + t * 32 + 8 * q + 4 * half);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = acc2[t][4 * q + e] + bv[e] + rv[q][e];
-        *reinterpret_cast<f32x4*>(xr + (size_t)(8 * t + 2 * q) * 512) = o;
+        *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
       }
     });
   }
@@ -419,13 +486,13 @@ int num_cus_mlp() {
   return n;
 }
 
-template <typename E>
+template <typename E, bool PROJ>
 int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   MlpArgs a = a_in;
   const int npanels = (a.M + MLP_PT - 1) / MLP_PT;
   if (a.D == 128 && a.H == 512) {
     a.panel0 = 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512, 4, false>), dim3((unsigned)npanels), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512, 4, false, PROJ>), dim3((unsigned)npanels), dim3(256), 0, s, a);
     return check_launch("mlp_fused");
   }
   if (!(a.D == 384 && a.H == 1536)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
@@ -441,7 +508,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   const int main_panels = split > 1 ? npanels - tail : npanels;
   if (main_panels > 0) {
     a.panel0 = 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 12, false>), dim3((unsigned)main_panels), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 12, false, PROJ>), dim3((unsigned)main_panels), dim3(256), 0, s, a);
     int rc = check_launch("mlp_fused");
     if (rc) return rc;
   }
@@ -449,12 +516,12 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
     a.panel0 = main_panels;
     a.tail_rb = tail * 4;
     const dim3 grid((unsigned)(tail * split));
-    if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, true>), grid, dim3(256), 0, s, a);
+    if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, true, PROJ>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, true, PROJ>), grid, dim3(256), 0, s, a);
     int rc = check_launch("mlp_fused(tail)");
     if (rc) return rc;
     const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2,
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical ? a.b2_logical : a.b2,
                        (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M);
     return check_launch("mlp_reduce");
   }
@@ -471,7 +538,10 @@ int mlp_fused(int prec, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return EFFOCR_OK;
   if (!mlp_fused_supported(prec, a.D, a.H)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: needs bf16/fp16 and (D, H) in {(384, 1536), (128, 512)}");
   if (a.rows_alloc % 32 != 0 || a.rows_alloc < a.M) return fail(EFFOCR_EINVAL, "mlp_fused: rows_alloc must be a multiple of 32 covering M");
-  return prec == PREC_BF16 ? launch_mlp<__bf16>(a, s) : launch_mlp<_Float16>(a, s);
+  const bool proj = a.A != nullptr;
+  if (proj && (!a.Wpp || !a.bp)) return fail(EFFOCR_EINVAL, "mlp_fused: the projection needs its weight and bias");
+  if (prec == PREC_BF16) return proj ? launch_mlp<__bf16, true>(a, s) : launch_mlp<__bf16, false>(a, s);
+  return proj ? launch_mlp<_Float16, true>(a, s) : launch_mlp<_Float16, false>(a, s);
 }
 
 }  // namespace effocr

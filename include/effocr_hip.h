@@ -176,6 +176,19 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
                           const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
                           int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* attn.proj + residual fused in front of the MLP (everything a timm Block does after attention):
+ *   x_blk <- y + fc2(gelu(fc1(LN(y)))),  y = x + a . wp^T + bp.
+ * a_blk [m,d] 16-bit blocked (attention output).  Row permutation P32 inside every block of 32 rows / entries:
+ * position p holds source index 8*(2*(r>>3) + hh) + (r&7) with hh = (p>>2)&1, r = (p&3) + 4*(p>>3).
+ *   wp_perm  attn.proj.weight [d,d] blocked, rows P32-permuted;  bp_perm  its bias, P32-permuted
+ *   w2_perm  mlp.fc2.weight [d,h] blocked, k permuted per 16 (as in op_mlp_blocked) AND rows P32-permuted
+ *   b2_perm  fc2 bias P32-permuted;  b2  the same bias unpermuted (used by the tail reduction)
+ * Other arguments as effocr_op_mlp_blocked. */
+int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_blk_dev, const void* wp_perm_dev, const float* bp_perm_dev,
+                               const float* gamma_dev, const float* beta_dev, float eps, const void* w1_blk_dev, const float* b1_dev,
+                               const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev, int m, int d, int h, int rows_alloc,
+                               void* scratch_dev, size_t scratch_bytes, void* stream);
+
 /* The two embed-dim linears of a block on the blocked layout (timm Block: norm1 + attn.qkv; attn.proj + residual):
  *   mode 0: out_blk (16-bit [m,n]) = LayerNorm(x_blk fp32 [m,d]) . w^T + bias
  *   mode 1: x_blk (fp32 [m,d], in/out) += a_blk (16-bit [m,d]) . w^T + bias          (n == d)

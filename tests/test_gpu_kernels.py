@@ -314,3 +314,49 @@ def test_rowlin_blocked(hip_lib, dev, prec, mode, shape):
         tol, scale = 2e-5, ref.abs().max().item()
     err = (got - ref).abs().max().item()
     assert err <= tol * scale, f"{prec} {mode} {shape}: err {err:.3e} scale {scale:.3e}"
+
+
+def perm32_rows(t):
+    """P32 of include/effocr_hip.h along dim 0: position p of every block of 32 holds source index
+    8*(2*(r>>3) + hh) + (r&7), hh = (p>>2)&1, r = (p&3) + 4*(p>>3)."""
+    p = torch.arange(32)
+    hh, r = (p >> 2) & 1, (p & 3) + 4 * (p >> 3)
+    src = 8 * (2 * (r >> 3) + hh) + (r & 7)
+    idx = (torch.arange(t.shape[0] // 32)[:, None] * 32 + src[None, :]).reshape(-1)
+    return t[idx].contiguous()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("scratch", [False, True])
+@pytest.mark.parametrize("shape", [(197 * 5, 384, 1536), (100, 128, 512), (40000, 384, 1536)])
+def test_proj_mlp_fused_blocked(hip_lib, dev, prec, shape, scratch):
+    """mlp.hip with the attention projection in front: y = x + a.Wp^T + bp; x <- y + fc2(gelu(fc1(LN(y))))."""
+    M, D, H = shape
+    g = torch.Generator().manual_seed(M + D + 1)
+    x = torch.randn(M, D, generator=g) * 2 + 0.3 * torch.randn(M, 1, generator=g)
+    av = torch.randn(M, D, generator=g).to(TDT[prec])
+    wp = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(TDT[prec])
+    bp = 0.5 * torch.randn(D, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1 = (torch.randn(H, D, generator=g) / math.sqrt(D)).to(TDT[prec])
+    w2 = (torch.randn(D, H, generator=g) / math.sqrt(H)).to(TDT[prec])
+    b1, b2 = 0.5 * torch.randn(H, generator=g), 0.5 * torch.randn(D, generator=g)
+    ra = (M + 127) // 128 * 128
+    xd, ad = to_blocked(x, ra).to(dev), to_blocked(av, ra).to(dev)
+    wpd, bpd = to_blocked(perm32_rows(wp), D).to(dev), perm32_rows(bp).to(dev)
+    w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm32_rows(perm16_columns(w2)), D).to(dev)
+    gd, btd, b1d, b2pd, b2d = gamma.to(dev), beta.to(dev), b1.to(dev), perm32_rows(b2).to(dev), b2.to(dev)
+    sc = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if scratch else None
+    _lib.check(hip_lib.effocr_op_proj_mlp_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(ad), _lib.ptr(wpd), _lib.ptr(bpd), _lib.ptr(gd), _lib.ptr(btd),
+                                                  1e-6, _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(w2d), _lib.ptr(b2pd), _lib.ptr(b2d), M, D, H, ra,
+                                                  _lib.ptr(sc), sc.numel() if scratch else 0, _stream(dev)), "op_proj_mlp_blocked")
+    torch.cuda.synchronize()
+    got = from_blocked(xd.cpu(), M, D, ra).double()
+    y = x.double() + av.double() @ wp.double().T + bp.double()
+    xn = torch.nn.functional.layer_norm(y, (D,), gamma.double(), beta.double(), 1e-6).to(TDT[prec]).double()
+    hid = torch.nn.functional.gelu(xn @ w1.double().T + b1.double()).to(TDT[prec]).double()
+    delta = hid @ w2.double().T + b2.double()
+    ref = y + delta
+    tol = {"bf16": 1e-2, "fp16": 1.5e-3}[prec]
+    err, scale = (got - ref).abs().max().item(), delta.abs().max().item()
+    assert err <= tol * scale, f"{prec} {shape}: err {err:.3e} vs delta scale {scale:.3e}"
