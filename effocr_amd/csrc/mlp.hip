@@ -1,534 +1,14 @@
-// Fused transformer MLP over the fragment-blocked residual stream (bf16 / f16 operands, gfx950):
-//     x <- x + fc2(GELU(fc1(LayerNorm(x))))          (timm Block.mlp + norm2 + residual; models/encoders.py:58,63)
-// The hidden activations [tokens, 4*D] never leave the CU: per block that removes 620 MB written + 620 MB read
-// (ViT-S, 1024 crops) and one 310 MB pass over x — the MLP was 52 % of the forward and its two GEMMs were bound
-// by exactly that traffic (profiles/README.md).
-//
-// One workgroup = 4 waves (one per SIMD, accumulators in AGPRs, gemm3.hip's regime) = a panel of 128 tokens;
-// wave w owns tokens 32w..32w+31 from LayerNorm to the final store, so nothing is exchanged between waves:
-//   prologue  LayerNorm of the wave's 32 rows, two lanes per row; lane (row r, half) loads exactly the fp32 chunks
-//             that make up ITS MFMA B-operand fragments (k chunks 2t+half), so the normalised panel never exists
-//             anywhere but in registers (D/16 fragments = 96 VGPRs at D = 384) — no LDS panel, no LDS reads for it;
-//   chunk c   (128 hidden features; H/128 chunks):
-//     phase A   hT[128 hid x 32 tok] = W1_c . xn^T          4 MFMA tiles x D/16 k-steps, W1 stages from the ring
-//     GELU      bias + GELU on the accumulators, rounded to the operand type.  In the SWAPPED MFMA C-layout a
-//               lane holds hidden {0-3, 8-11, 16-19, 24-27} (+4 for the upper half-wave) of its token: read as two
-//               8-element vectors that IS a valid B-operand for phase B, provided W2's k index is permuted the
-//               same way — done once on the host (fc2 weight copy "blocked + permuted", api.hip);
-//     phase B   outT[D x 32 tok] += W2[:, c] . h_c           D/32 MFMA tiles x 8 k-steps, B-operand from registers
-//   epilogue  x <- outT + bias2 + x (fp32, blocked).
-// Weights stream through an 8-slot ring of 16 KB stages (32 cells = 4 row blocks x 64 k) by global_load_lds, six
-// stages ahead (LDS holds nothing else but the biases); both weight copies are fragment-blocked so a stage is a
-// verbatim copy of 512-byte HBM cells and every fragment read is conflict-free without swizzles.  As in gemm3 the
-// barrier sits in the MIDDLE of a stage, so the first fragments of stage s+1 are read under stage s's last MFMAs.  GELU of chunk c is software-pipelined under phase A of
-// chunk c+1 (pre-activations parked as packed 16-bit values), so the stream of MFMAs never waits for it:
-//     A(0) | A(1)+gelu(0) | B(0) | A(2)+gelu(1) | B(1) | ... | A(n-1)+gelu(n-2) | B(n-2) | gelu(n-1) | B(n-1)
+// Fused transformer MLP: dispatcher (kernel and launcher in mlp_kernel.hpp, instantiated in mlp_bf16.hip, mlp_bf16p.hip,
+// mlp_f16.hip, mlp_f16p.hip — "p" = with the attention projection phase in front).
 #include "common.hpp"
 #include "kernels.hpp"
-#include <type_traits>
-
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
-// timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
-// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 no residual loads after the projection
-#if EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000
-#define MLX (EFFOCR_EXP - 2000)
-#else
-#define MLX 0
-#endif
 
 namespace effocr {
-namespace {
 
-template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    sfor<I + 1, N>(f);
-  }
-}
-
-constexpr int MLP_PT = 128;                              // tokens per workgroup
-constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
-constexpr int MLP_RING = 8;
-
-// NCW = hidden chunks run by one workgroup: H/128 (whole MLP of its panel), or — PARTIAL, second launch — a slice
-// of them for the panels of the last, partially filled round of CUs: the split workgroups write fp32 partial
-// outputs to a scratch buffer and mlp_reduce_kernel adds them, bias2 and the residual in a fixed order.
-// PROJ: the attention output projection + residual runs first, in the same workgroup:  x <- x + a . Wp^T + bp.
-// Its weight copy has the rows of every 32-row block permuted (api.hip put_op_blocked rowperm) so that the swapped
-// C-layout hands each lane 8 CONSECUTIVE output features per (tile, register octet) — exactly the fp32 chunks
-// 4t+2half, 4t+2half+1 the LayerNorm below expects in xv[]: accumulators -> (+bias, +residual) -> xv, no exchange.
-template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ>
-__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
-  typedef typename Op16<E>::V8 V8;
-  constexpr int KC = D / 8;                              // 16-B k chunks per xn row
-  constexpr int NC = NCW;                                // hidden chunks of this workgroup (H / 128 in total)
-  constexpr int SA = D / 64;                             // ring stages per phase A
-  constexpr int OT = D / 32;                             // output tiles (32 features each) per token block
-  constexpr int OG = OT / 4;                             // output tile groups of 4 (one ring stage holds 4 row blocks)
-  constexpr int SB = 2 * OG;                             // ring stages per phase B: (group, k half)
-  constexpr int SP = PROJ ? OG * SA : 0;                 // ring stages of the projection: (output group, k stage)
-  constexpr int NS = SP + NC * (SA + SB);                // ring stages per panel
-  static_assert(D % 128 == 0 && H % 128 == 0 && (H / 128) % NCW == 0, "mlp: D and H must be multiples of 128");
-  constexpr int NXF = D / 16;                            // xn B-operand fragments per lane (one per k16 step)
-  constexpr int R = MLP_RING;
-  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 4 * D) * 4];
-  char* sW = smem;
-  float* sB1 = reinterpret_cast<float*>(smem + R * MLP_STAGE);
-  float* sB2 = sB1 + H;
-  float* sG = sB2 + D;                                   // norm2 weight / bias: LDS reads do not queue behind the ring's DMAs
-  float* sBt = sG + D;
-  float* sBp = sBt + D;                                  // proj bias (row-permuted like its weight)
-
-  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
-  const int w = wave_id();
-  constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
-  const int panel = a.panel0 + (int)blockIdx.x / SPLIT;
-  const int c0 = ((int)blockIdx.x % SPLIT) * NCW;        // first hidden chunk of this workgroup
-  const int64_t rb = (int64_t)panel * 4 + w;             // this wave's 32-row block of x
-  const char* W1 = static_cast<const char*>(a.W1b);
-  const char* W2 = static_cast<const char*>(a.W2p);
-
-  // ---- input rows first (oldest in the in-order VM queue: work can start while the ring fills).
-  // lane = (row r31, half): 16-bit k chunk 2t+half of its row = fp32 chunks 4t+2half, 4t+2half+1
-  f32x4 xv[2 * NXF];
-  V8 xf[NXF];                                            // B-operand fragments: attention output (PROJ), then LayerNorm(x)
-  const int64_t rbc = rb < (a.rows_alloc >> 5) ? rb : (a.rows_alloc >> 5) - 1;
-  const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
-  if constexpr (PROJ) {
-    const char* ab = static_cast<const char*>(a.A) + rbc * KC * 512 + half * 512 + r31 * 16;
-#pragma unroll
-    for (int t = 0; t < NXF; ++t) xf[t] = *reinterpret_cast<const V8*>(ab + (size_t)t * 1024);
-  } else {
-#pragma unroll
-    for (int t = 0; t < NXF; ++t) {
-#if (MLX & 2)
-      const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f};
-      xv[2 * t] = cst; xv[2 * t + 1] = cst;
-      if (a.M < 0)
-#endif
-      {
-      xv[2 * t] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half) * 512);
-      xv[2 * t + 1] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half + 1) * 512);
-      }
-    }
-  }
-  for (int n = tid; n < H; n += 256) sB1[n] = a.b1[n];
-  for (int n = tid; n < D; n += 256) { sB2[n] = a.b2[n]; sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; if constexpr (PROJ) sBp[n] = a.bp[n]; }
-  __syncthreads();                                       // parameters visible (and x has landed) before the ring starts filling
-
-  // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
-  // Wave w copies row block w of the stage: 4 pieces of 1 KB (two adjacent k-chunk cells each).
-  auto stage_src = [&](int s_in) __attribute__((always_inline)) -> const char* {
-    int s = s_in < NS ? s_in : NS - 1;                   // a stage index past the end (the rolled loop's "plenty follows"
-    int c, r;                                            // flag is optimistic in its last iteration for small D) re-reads the last stage
-    if constexpr (PROJ) {
-      if (s < SP) {                                      // projection: stage (group g = s / SA, k stage s % SA)
-        const int g = s / SA, ks = s - g * SA;
-        return static_cast<const char*>(a.Wpp) + ((size_t)(4 * g + w) * KC + 8 * ks) * 512;
-      }
-      s -= SP;
-    }
-
-    bool isA;
-    if (s < SA) { c = 0; r = s; isA = true; }
-    else {
-      const int t = s - SA, p = t / (SA + SB);
-      r = t - p * (SA + SB);
-      if (p < NC - 1) { isA = r < SA; c = isA ? p + 1 : p; r = isA ? r : r - SA; }
-      else { isA = false; c = NC - 1; }                  // trailing B(NC-1): r counts its stages
-    }
-    if (isA) return W1 + ((size_t)(4 * (c0 + c) + w) * KC + 8 * r) * 512;
-    const int g = r >> 1, kh = r & 1;
-    return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * (c0 + c) + 8 * kh) * 512;
-  };
-  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS
-    const char* src = stage_src(s) + lane * 16;
-    char* dst = sW + (s & (R - 1)) * MLP_STAGE + w * 4096;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-  };
-#pragma unroll
-  for (int s0 = 0; s0 < R - 1; ++s0)
-    if (s0 < NS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) issue_piece(s0, i);
-    }
-
-  // ---- LayerNorm in registers: xv (this lane's half of the row, fp32) -> xf[t] = B-operand fragment of k16 step t
-  auto layernorm_to_xf = [&]() __attribute__((always_inline)) {
-    float sm = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2 * NXF; ++i) sm += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
-    sm += __shfl_xor(sm, 32, 64);
-    const float mean = sm * (1.0f / D);
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2 * NXF; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
-    ss += __shfl_xor(ss, 32, 64);
-    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
-#pragma unroll
-    for (int t = 0; t < NXF; ++t) {
-      u32x2 pk[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = 4 * t + 2 * half + j;
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(sG + c * 4);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(sBt + c * 4);
-        const f32x4 v = xv[2 * t + j];
-        pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
-                         (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
-      }
-      const u32x4 q = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
-      xf[t] = __builtin_bit_cast(V8, q);
-    }
-  };
-  if constexpr (!PROJ) layernorm_to_xf();
-
-  f32x16 acc1[4];                                        // hT tiles of the current chunk
-  f32x16 acc2[OT];                                       // outT tiles
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
-#pragma unroll
-  for (int t = 0; t < OT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
-
-  const int wo = half * 512 + r31 * 16;                  // + (row block i * 8 + 2 * c4) * 512 inside a stage
-  int s = 0;                                             // ring stage counter
-  struct WF { V8 w[4]; };
-  auto load_w = [&](WF& f, const char* st, int c4) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * c4) * 512);
-  };
-  // middle of stage s: stage s+1 has landed (own pieces; the R-3 younger stages may stay in flight) and, past
-  // the barrier, everybody's; every wave holds the rest of stage s in registers and is done with stage s-1, whose
-  // slot takes stage s+R-1
-  auto stage_mid = [&](auto STEADY) __attribute__((always_inline)) {
-    if constexpr (decltype(STEADY)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !(MLX & 16)
-    __builtin_amdgcn_s_barrier();
-#endif
-    asm volatile("" ::: "memory");
-  };
-  WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
-  __builtin_amdgcn_s_barrier();                          // ... and everybody's
-  asm volatile("" ::: "memory");
-  load_w(wf, sW, 0);
-
-  // ---- chunk hand-over registers: the set holds the 8 B-operand fragments (8 values each) of one chunk, first as
-  // pre-activations (bias added, rounded to the operand type: "parked"), then GELU'd IN PLACE, 4 values at a time.
-  // (Two alternating sets, with the GELU spread over both phases, do not fit next to the 96 VGPRs of xn: spills.)
-  struct HSet { u32x4 u[8]; };
-  // half-unit q (0..15) = words 2*(q&1), 2*(q&1)+1 of unit q>>1: 4 values (keeps the polynomial's temporaries to 16 VGPRs)
-  auto gelu_unit = [&](HSet& hs, auto Q) __attribute__((always_inline)) {     // Q: compile-time -> static register indices
-    typedef __attribute__((__vector_size__(4 * sizeof(E)))) E E4;
-    constexpr int u = decltype(Q)::value >> 1, h2 = (decltype(Q)::value & 1) * 2;
-    const u32x2 pw = {hs.u[u][h2], hs.u[u][h2 + 1]};
-    const E4 pv = __builtin_bit_cast(E4, pw);
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (float)pv[e];
-#if !(MLX & 4)
-    gelu_fold_n<E, 4>(v);
-#endif
-    const u32x2 o = pack4<E>(v[0], v[1], v[2], v[3]);
-    hs.u[u][h2] = o[0];
-    hs.u[u][h2 + 1] = o[1];
-  };
-  // acc1 (+ bias1 of chunk c) -> set, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
-  auto park = [&](HSet& hs, int c) __attribute__((always_inline)) {
-    sfor<0, 8>([&](auto U) {                             // one unit (8 values) at a time: bounds the live temporaries
-      constexpr int u = decltype(U)::value, i = u >> 1, m = u & 1;
-      __builtin_amdgcn_sched_barrier(0);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + (c0 + c) * 128 + i * 32 + 8 * (2 * m) + 4 * half);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + (c0 + c) * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
-      const u32x2 lo = pack4<E>(acc1[i][8 * m] + b0[0], acc1[i][8 * m + 1] + b0[1], acc1[i][8 * m + 2] + b0[2], acc1[i][8 * m + 3] + b0[3]);
-      const u32x2 hi = pack4<E>(acc1[i][8 * m + 4] + b1[0], acc1[i][8 * m + 5] + b1[1], acc1[i][8 * m + 6] + b1[2], acc1[i][8 * m + 7] + b1[3]);
-      const u32x4 p = {lo[0], lo[1], hi[0], hi[1]};
-      hs.u[u] = p;
-#pragma unroll
-      for (int r = 8 * m; r < 8 * m + 8; ++r) acc1[i][r] = 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-
-  // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
-  // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
-  // is one basic block (a scalar branch between two MFMAs is a bubble with one wave per SIMD; see gemm3.hip).
-  auto ring_stage = [&](auto REM, auto&& mfma1) __attribute__((always_inline)) {
-#if (MLX & 8)
-    constexpr bool more = false, next = decltype(REM)::value >= 1;
-#else
-    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1;
-#endif
-    const char* st = sW + (s & (R - 1)) * MLP_STAGE;
-    const char* stn = sW + ((s + 1) & (R - 1)) * MLP_STAGE;
-    // ONE fragment set, refilled in a rolling fashion: right after MFMA (c4, i) has consumed wf.w[i], the same
-    // registers receive fragment i of step c4+1 (of stage s+1's step 0 after step 3) — 16 VGPRs instead of 32
-    sfor<0, 4>([&](auto C4) {
-      constexpr int c4 = decltype(C4)::value;
-      if constexpr (c4 == 2) {
-#if (MLX & 8)
-        stage_mid(std::false_type{});
-#else
-        stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
-#endif
-      }
-      sfor<0, 4>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        mfma1(C4, I, wf.w[i]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
-        else if constexpr (next) wf.w[i] = *reinterpret_cast<const V8*>(stn + wo + (i * 8) * 512);
-        if constexpr (more && c4 >= 2 && i < 2) issue_piece(s + R - 1, (c4 - 2) * 2 + i);
-      });
-    });
-    ++s;
-  };
-  constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
-
-  // GELU half-units [U0, U1) of `gs` are placed in the MFMA shadows of a phase of NMM MFMAs, evenly spaced
-  // ---- phase A of a chunk: SA stages x 4 k16 steps x 4 tiles
-  auto phase_a = [&](auto AFTER, HSet* gs, auto U0, auto U1) __attribute__((always_inline)) {        // AFTER = ring stages that follow the phase
-    constexpr int NMM = SA * 16, u0 = decltype(U0)::value, nu = decltype(U1)::value - u0;
-    sfor<0, SA>([&](auto KS) {
-      constexpr int ks = decltype(KS)::value;
-      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
-      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
-        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
-#if (MLX & 32)
-        acc1[i][c4] += (float)wfrag[0] * (float)xf[ks * 4 + c4][1];
-#else
-        acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
-#endif
-        if constexpr (nu > 0) {
-          constexpr int n = ks * 16 + c4 * 4 + i;        // MFMA index within the phase; half-unit k goes after MFMA ceil(k*NMM/nu)
-          constexpr int k = (n * nu) / NMM;
-          if constexpr ((k * NMM + nu - 1) / nu == n && k < nu) {
-            __builtin_amdgcn_sched_barrier(0);
-            gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
-          }
-        }
-      });
-    });
-  };
-  // ---- phase B of a chunk: (group g, k half kh) stages; B-operand = fragment 4*kh + c4 of `hs`
-  auto phase_b = [&](auto AFTER, const HSet& hs, HSet* gs, auto U0, auto U1) __attribute__((always_inline)) {
-    constexpr int NMM = SB * 16, u0 = decltype(U0)::value, nu = decltype(U1)::value - u0;
-    sfor<0, SB>([&](auto SBI) {
-      constexpr int sb = decltype(SBI)::value;
-      constexpr int g = sb >> 1, kh = sb & 1;
-      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SB - 1 - sb);
-      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
-        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
-        const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
-#if (MLX & 32)
-        acc2[4 * g + i][c4] += (float)wfrag[0] * (float)hb[1];
-#else
-        acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
-#endif
-        if constexpr (nu > 0) {
-          constexpr int n = sb * 16 + c4 * 4 + i;
-          constexpr int k = (n * nu) / NMM;
-          if constexpr ((k * NMM + nu - 1) / nu == n && k < nu) {
-            __builtin_amdgcn_sched_barrier(0);
-            gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
-          }
-        }
-      });
-    });
-  };
-
-  if constexpr (PROJ) {
-    // ---- projection: outT[D x 32 tok] = Wpp . a^T, (group g, k stage) ring stages; B-operand = attention fragments
-    sfor<0, OG>([&](auto G_) {
-      constexpr int g = decltype(G_)::value;
-      sfor<0, SA>([&](auto KS) {
-        constexpr int ks = decltype(KS)::value;
-        ring_stage(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
-          constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
-          acc2[4 * g + i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc2[4 * g + i]);
-        });
-      });
-    });
-    // x_new = outT + bias + x: with the row-permuted weight, registers 4q..4q+3 of tile t are the fp32 chunk
-    // 8t + 4(q>>1) + 2half + (q&1) of the row = xv[2(2t + (q>>1)) + (q&1)].  Nothing is stored here: acc2 keeps
-    // outT + bias, fc2 accumulates on top of it and the final epilogue adds the (old) residual once.  Of a split
-    // tail panel only part 0 keeps it (the reduction adds every part to the old x).
-    const bool keep = !PARTIAL || c0 == 0;
-    __builtin_amdgcn_sched_barrier(0);                   // the 48 residual loads must not move up into the projection,
-    asm volatile("" ::: "memory");                       // where the attention fragments still hold 96 VGPRs
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#if (MLX & 128)
-        const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f + q};
-        xv[2 * (2 * t + (q >> 1)) + (q & 1)] = cst;
-        if (a.M < 0)
-#endif
-        xv[2 * (2 * t + (q >> 1)) + (q & 1)] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
-      }
-    });
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sBp + t * 32 + 8 * q + 4 * half);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pb = acc2[t][4 * q + e] + bv[e];
-          xv[2 * (2 * t + (q >> 1)) + (q & 1)][e] += pb;
-          acc2[t][4 * q + e] = keep ? pb : 0.f;
-        }
-      }
-    });
-    layernorm_to_xf();
-  }
-
-  // Schedule (ring stream order A(0) | A(1) | B(0) | A(2) | B(1) | ...).  ONE hand-over set: parked after A(c) — once B(c-1)
-  // has consumed the previous contents — activated in place under A(c+1), consumed by B(c):
-  //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
-  static_assert(NC >= 3, "mlp: at least three hidden chunks");
-  typedef std::integral_constant<int, FAR> Far;
-  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 16> U16_;
-  HSet S;
-  phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
-  park(S, 0);
-#pragma unroll 1
-  for (int c = 1; c < NC - 1; ++c) {
-    phase_a(Far{}, &S, U0_{}, U16_{});                    // A(c) + gelu(c-1)
-    phase_b(Far{}, S, nullptr, U0_{}, U0_{});             // B(c-1)
-    park(S, c);
-  }
-  phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
-  phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
-  park(S, NC - 1);
-  sfor<0, 16>([&](auto Q) { gelu_unit(S, Q); });
-  phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
-
-#if (MLX & 1)
-  if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
-#endif
-  // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row:
-  // standard C-layout 8t + 2q + half; with PROJ (row-permuted weight copies) 8t + 4(q>>1) + 2half + (q&1)
-  auto cq = [&](int t, int q) __attribute__((always_inline)) { return PROJ ? 8 * t + 4 * (q >> 1) + 2 * half + (q & 1) : 8 * t + 2 * q + half; };
-  if constexpr (PARTIAL) {
-    // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
-    const int64_t rbl = rb - (int64_t)a.panel0 * 4;
-    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(blockIdx.x % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + r31 * 16;
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
-      }
-    });
-  } else if (rb * 32 + r31 < a.M) {
-    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-      f32x4 rv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)cq(t, q) * 512);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + t * 32 + 8 * q + 4 * half);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc2[t][4 * q + e] + bv[e] + rv[q][e];
-        *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
-      }
-    });
-  }
-}
-
-// x[row block rb0 + i] += bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
-__global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* partial, const float* b2, int64_t rb0, int tail_rb,
-                                                         int D, int nparts, int64_t M) {
-  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (row block, chunk, row) in blocked order
-  const int64_t per_rb = (int64_t)(D / 4) * 32;
-  if (id >= (int64_t)tail_rb * per_rb) return;
-  const int64_t rbl = id / per_rb;
-  const int rem = (int)(id - rbl * per_rb), chunk = rem >> 5, row = rem & 31;
-  if ((rb0 + rbl) * 32 + row >= M) return;
-  f32x4* xp = reinterpret_cast<f32x4*>(x) + (rb0 + rbl) * per_rb + rem;
-  f32x4 v = *xp;
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + chunk * 4);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < nparts; ++p) {
-    const f32x4 pv = reinterpret_cast<const f32x4*>(partial)[((int64_t)p * tail_rb + rbl) * per_rb + rem];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += pv[e];
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e] + v[e];
-  *xp = v;
-}
-
-int num_cus_mlp() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n = v;
-  }
-  return n;
-}
-
-template <typename E, bool PROJ>
-int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
-  MlpArgs a = a_in;
-  const int npanels = (a.M + MLP_PT - 1) / MLP_PT;
-  if (a.D == 128 && a.H == 512) {
-    a.panel0 = 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512, 4, false, PROJ>), dim3((unsigned)npanels), dim3(256), 0, s, a);
-    return check_launch("mlp_fused");
-  }
-  if (!(a.D == 384 && a.H == 1536)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
-  // One workgroup per CU: the panels of the last, partially filled round are cut along the hidden dimension into
-  // 4 (or 2) workgroups each, which write partial outputs to the caller's scratch; a small kernel reduces them.
-  const int slots = num_cus_mlp();
-  const int tail = a.no_tail_split ? 0 : npanels % slots;
-  int split = 1;
-  if (tail > 0 && tail * 4 <= slots) split = 4;
-  else if (tail > 0 && tail * 2 <= slots) split = 2;
-  const size_t need = (size_t)split * tail * MLP_PT * a.D * sizeof(float);
-  if (split > 1 && (!a.partial || a.partial_bytes < need)) split = 1;
-  const int main_panels = split > 1 ? npanels - tail : npanels;
-  if (main_panels > 0) {
-    a.panel0 = 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 12, false, PROJ>), dim3((unsigned)main_panels), dim3(256), 0, s, a);
-    int rc = check_launch("mlp_fused");
-    if (rc) return rc;
-  }
-  if (split > 1) {
-    a.panel0 = main_panels;
-    a.tail_rb = tail * 4;
-    const dim3 grid((unsigned)(tail * split));
-    if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, true, PROJ>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, true, PROJ>), grid, dim3(256), 0, s, a);
-    int rc = check_launch("mlp_fused(tail)");
-    if (rc) return rc;
-    const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical ? a.b2_logical : a.b2,
-                       (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M);
-    return check_launch("mlp_reduce");
-  }
-  return EFFOCR_OK;
-}
-
-}  // namespace
+int mlp_launch_bf16(const MlpArgs& a, hipStream_t s);
+int mlp_launch_bf16p(const MlpArgs& a, hipStream_t s);
+int mlp_launch_f16(const MlpArgs& a, hipStream_t s);
+int mlp_launch_f16p(const MlpArgs& a, hipStream_t s);
 
 bool mlp_fused_supported(int prec, int D, int H) {
   return (prec == PREC_BF16 || prec == PREC_FP16) && ((D == 384 && H == 1536) || (D == 128 && H == 512));
@@ -540,8 +20,8 @@ int mlp_fused(int prec, const MlpArgs& a, hipStream_t s) {
   if (a.rows_alloc % 32 != 0 || a.rows_alloc < a.M) return fail(EFFOCR_EINVAL, "mlp_fused: rows_alloc must be a multiple of 32 covering M");
   const bool proj = a.A != nullptr;
   if (proj && (!a.Wpp || !a.bp)) return fail(EFFOCR_EINVAL, "mlp_fused: the projection needs its weight and bias");
-  if (prec == PREC_BF16) return proj ? launch_mlp<__bf16, true>(a, s) : launch_mlp<__bf16, false>(a, s);
-  return proj ? launch_mlp<_Float16, true>(a, s) : launch_mlp<_Float16, false>(a, s);
+  if (prec == PREC_BF16) return proj ? mlp_launch_bf16p(a, s) : mlp_launch_bf16(a, s);
+  return proj ? mlp_launch_f16p(a, s) : mlp_launch_f16(a, s);
 }
 
 }  // namespace effocr
