@@ -83,3 +83,38 @@ def test_knn_workspace_and_argument_checks(hip_lib):
     assert L.effocr_knn_ip_topk(p, 1024, p, 10000, 384, 10, p, p, p, 16, None) == -3    # workspace too small
     assert L.effocr_knn_ip_topk(None, 4, p, 10, 384, 5, p, p, p, 1 << 30, None) == -1
     assert L.effocr_knn_ip_topk(p, 0, p, 10, 384, 5, p, p, p, 0, None) == 0            # empty query batch is a no-op
+
+
+def test_fast_path_operator_argument_checks(hip_lib):
+    """The blocked-layout operators and the crop transform reject bad requests before any device work
+    (dummy non-NULL pointers are never dereferenced on these paths)."""
+    L = hip_lib
+    p = ctypes.c_void_p(4096)
+    f3 = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
+    z3 = (ctypes.c_float * 3)(0.0, 1.0, 1.0)
+    # crop transform: geometry, NULLs, std == 0, output size, box count
+    assert L.effocr_crop_transform(p, 0, 10, 30, p, 1, 224, 1, f3, f3, f3, p, None) == -1
+    assert L.effocr_crop_transform(p, 10, 10, 29, p, 1, 224, 1, f3, f3, f3, p, None) == -1            # row stride < 3*width
+    assert L.effocr_crop_transform(None, 10, 10, 30, p, 1, 224, 1, f3, f3, f3, p, None) == -1
+    assert L.effocr_crop_transform(p, 10, 10, 30, p, 1, 224, 1, f3, z3, f3, p, None) == -1
+    assert L.effocr_crop_transform(p, 10, 10, 30, p, 1, 30, 1, f3, f3, f3, p, None) == -2             # size % 4
+    assert L.effocr_crop_transform(p, 10, 10, 30, p, 70000, 224, 1, f3, f3, f3, p, None) == -2
+    assert L.effocr_crop_transform(p, 10, 10, 30, p, 0, 224, 1, f3, f3, f3, p, None) == 0
+    # gemm3 / blocked LayerNorm
+    assert L.effocr_op_linear_blocked(0, 0, p, p, p, None, p, 32, 128, 128, 32, None) == -2            # N % 192 / 256
+    assert L.effocr_op_linear_blocked(0, 2, p, p, p, None, p, 32, 192, 128, 32, None) == -1            # residual epilogue without residual
+    assert L.effocr_op_linear_blocked(0, 5, p, p, p, None, p, 32, 192, 128, 32, None) == -1
+    assert L.effocr_op_layernorm_blocked(2, p, 32, 384, p, p, 1e-6, p, None) == -2                     # fp32 output
+    assert L.effocr_op_layernorm_blocked(0, p, 32, 100, p, p, 1e-6, p, None) == -2
+    # fused MLP (+ projection), row-block linears
+    assert L.effocr_op_mlp_blocked(0, p, p, p, 1e-6, p, p, p, p, 32, 256, 1024, 32, None, 0, None) == -2
+    assert L.effocr_op_mlp_blocked(2, p, p, p, 1e-6, p, p, p, p, 32, 384, 1536, 32, None, 0, None) == -2   # fp32
+    assert L.effocr_op_mlp_blocked(0, p, p, p, 1e-6, p, p, p, p, 33, 384, 1536, 32, None, 0, None) == -1   # rows_alloc < m
+    assert L.effocr_op_mlp_blocked(0, None, p, p, 1e-6, p, p, p, p, 32, 384, 1536, 32, None, 0, None) == -1
+    assert L.effocr_op_mlp_blocked(0, p, p, p, 1e-6, p, p, p, p, 0, 384, 1536, 0, None, 0, None) == 0
+    assert L.effocr_op_proj_mlp_blocked(0, p, None, p, p, p, p, 1e-6, p, p, p, p, p, 32, 384, 1536, 32, None, 0, None) == -1
+    assert L.effocr_op_rowlin_blocked(0, 3, p, p, p, p, 1e-6, p, p, p, 32, 384, 1152, 128, None) == -1     # unknown mode
+    assert L.effocr_op_rowlin_blocked(0, 1, p, p, None, None, 0.0, p, p, None, 32, 384, 1152, 128, None) == -1   # residual mode needs n == d
+    assert L.effocr_op_rowlin_blocked(0, 0, p, None, p, p, 1e-6, p, p, p, 32, 384, 1152, 96, None) == -1   # rows_alloc % 128
+    assert L.effocr_op_rowlin_blocked(0, 0, p, None, p, p, 1e-6, p, p, p, 32, 256, 768, 128, None) == -2
+    assert b"rowlin" in L.effocr_last_error()
