@@ -128,3 +128,28 @@ def test_input_validation(dev):
     bad.pop("norm.weight")
     with pytest.raises(ValueError):
         HipEncoder("vit_tiny_test", bad, img_size=64, device=dev)
+
+
+@pytest.mark.parametrize("B", [1, 3, 70])
+def test_every_switchable_path_matches_the_oracle(dev, B):
+    """Default path (row-panel qkv / proj + fused MLP) and every A/B switch of the library — unfused MLP, projection
+    fused into the MLP kernel, register-resident row-block linears, gemm2 instead of gemm3, no tail split — against
+    oracle A at batch sizes that exercise single-panel, ragged and multi-panel grids."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    sd = init_state_dict(arch, seed=6, img_size=224)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(B))
+    ref = encoder_forward(arch, sd, x)
+    for prec in ("bf16", "fp16"):
+        enc = HipEncoder(arch, sd, precision=prec, device=dev)
+        outs = {"default": enc.forward(x.to(dev)).cpu()}
+        for name, opts in [("unfused_mlp", {"use_mlp": 0}), ("proj_in_mlp", {"use_projf": 1}), ("rowlin", {"use_rowlin": 1}),
+                           ("gemm2_fc2", {"use_mlp": 0, "use_gemm3": 0}), ("no_tail_split", {"tail_split": 0})]:
+            for k, v in opts.items():
+                enc.set_option(k, v)
+            outs[name] = enc.forward(x.to(dev)).cpu()
+            for k in opts:                                   # back to the defaults
+                enc.set_option(k, {"use_mlp": 1, "use_projf": 0, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1}[k])
+        assert torch.equal(outs["default"], enc.forward(x.to(dev)).cpu())          # switches restored, run-to-run bitwise
+        for name, o in outs.items():
+            assert rel_err(o, ref) <= REL[prec], (name, prec, B, rel_err(o, ref))
