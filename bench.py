@@ -58,7 +58,6 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--chunk", type=int, default=0, help="encoder sub-batch (crops); 0 = library default")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="library option (set_option) for A/B runs, e.g. tail_split=0")
-    ap.add_argument("--panel-impl", type=int, default=-1, help="1 token-stationary (default), 0 LDS-panel kernel")
     ap.add_argument("--panel-rows", type=int, default=0, help="row-panel height 64|128 (0 = library default)")
     ap.add_argument("--no-panel", action="store_true", help="A/B: K-streaming GEMM + standalone LayerNorm path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,8 +142,6 @@ def main():
         enc.set_option("use_blocked", 0)
     if os.environ.get("EFFOCR_NO_GEMM2"):
         enc.set_option("use_gemm2", 0)
-    if a.panel_impl >= 0:
-        enc.set_option("panel_impl", a.panel_impl)
     if a.no_panel:
         enc.set_option("use_panel", 0)
     gi = torch.Generator().manual_seed(0)

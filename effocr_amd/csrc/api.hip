@@ -63,7 +63,6 @@ struct effocr_encoder {
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
-  int panel_impl = 0;               // 0: LDS-panel panel.hip (default, faster), 1: token-stationary panelr.hip (experiment)
   int panel_rows = 128;             // row-panel height: 128 (1 workgroup/CU) or 64 (2 workgroups/CU)
   int use_panel = 1;                // 0: force the K-streaming GEMM + standalone LayerNorm path (A/B switch)
   int chunk = 0;                    // crops per internal sub-batch of the ViT forward (0 = whole batch)
@@ -377,7 +376,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   // widths without row-panel kernels (ViT-B): LayerNorm kernel + gemm3 for all four linears, everything blocked
   const bool g3all = !panel && e->use_gemm3 && gemm3_supported(prec, 3 * D, D) && gemm3_supported(prec, D, D) &&
                      gemm3_supported(prec, e->vit.mlp, D) && gemm3_supported(prec, D, e->vit.mlp);
-  const int blk = (e->use_blocked && g2p && ((panel && g2 && e->panel_impl == 0) || g3all)) ? 1 : 0;
+  const int blk = (e->use_blocked && g2p && ((panel && g2) || g3all)) ? 1 : 0;
   const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
   const bool projf = mlpf && !rl && e->use_projf;
@@ -406,13 +405,13 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
       p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
-      if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
+      if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
       if (!projf) {
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
       p.M = M; p.N = D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split; p.blk_a = blk; p.blk_out = blk;
-      if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s) : panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
+      if ((rc = timed(e, "panel_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_COPY, EPI_BIAS_RESID, p, s); }))) return rc;
       }
       }
       if (mlpf) {
@@ -432,7 +431,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       p.A = xs; p.lda = D; p.gamma = F(L.ln2w); p.beta = F(L.ln2b); p.eps = 1e-6f; p.W = wb + L.fc1w; p.bias = F(L.fc1b);
       p.out = hb; p.ldo = e->vit.mlp; p.M = M; p.N = e->vit.mlp; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
-      if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return e->panel_impl ? panelr_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s) : panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
+      if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
     } else if (blk) {
       auto lin = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi) {
         GemmArgs q{};
@@ -636,7 +635,6 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   const std::string n = name;
   if (n == "use_panel") { enc->use_panel = value; return EFFOCR_OK; }
   if (n == "debug") { enc->debug = value; return EFFOCR_OK; }
-  if (n == "panel_impl") { enc->panel_impl = value; return EFFOCR_OK; }
   if (n == "use_gemm2") { enc->use_gemm2 = value; return EFFOCR_OK; }
   if (n == "use_blocked") { enc->use_blocked = value; return EFFOCR_OK; }
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }

@@ -90,8 +90,6 @@ struct PanelArgs {
 };
 bool panel_gemm_supported(int prec, int N, int K);
 int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
-// panelr.hip — token-stationary variant (token fragments resident in registers, W ring only in LDS)
-int panelr_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
 
 // vit_ops.hip
 int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
