@@ -113,12 +113,20 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    # EFFOCR_BENCH_BACKEND=gloo: debugging aid only — lets the N>1 control flow run on a box with fewer GPUs than
+    # ranks (ranks share devices; RCCL refuses duplicate devices).  The driver's runs use the default, "nccl" = RCCL.
+    backend = os.environ.get("EFFOCR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from effocr_amd.encoders import HipEncoder
     from effocr_amd.knn import FaissKNN, IndexFlatIP

@@ -42,10 +42,15 @@ def all_gather_rows(local, n_total, group=None):
 
 def _has_into_tensor(t):
     # gloo (CPU tests) lacks all_gather_into_tensor on some builds; nccl/RCCL has it
-    return t.is_cuda
+    return t.is_cuda and dist.get_backend() == "nccl"
 
 
 def _all_gather_list(out, pad, world, mx, group):
+    if out.is_cuda:                                   # gloo with device tensors (debugging on a shared GPU): stage through the host
+        host = [torch.empty((mx,) + tuple(pad.shape[1:]), dtype=pad.dtype) for _ in range(world)]
+        dist.all_gather(host, pad.cpu().contiguous(), group=group)
+        out.copy_(torch.cat(host, dim=0))
+        return
     chunks = [out[r * mx:(r + 1) * mx] for r in range(world)]
     dist.all_gather(chunks, pad.contiguous(), group=group)
 
