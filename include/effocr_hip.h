@@ -86,8 +86,17 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
  * that the activations between consecutive kernels stay in the 256 MiB Infinity Cache.  Results
  * are identical for every setting; it only changes the workspace size and the launch count. */
 int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
-/* tuning / A-B switches: "use_panel" (1 = row-panel GEMMs with fused LayerNorm [default], 0 = K-streaming
- * GEMM + standalone LayerNorm), "chunk" (= set_chunk).  Results agree to fp32 rounding of the LN. */
+/* tuning / A-B switches (ViT, 16-bit precisions; every combination is parity-tested against the oracle,
+ * results differ only by operand-rounding noise of the precision mode).  [default]
+ *   "use_panel"   [1] row-panel GEMMs with the LayerNorm fused into the panel load; 0: K-streaming GEMMs + LayerNorm kernel
+ *   "use_blocked" [1] fragment-blocked activation layout; 0: row-major activations
+ *   "use_mlp"     [1] LN2+fc1+GELU+fc2+residual as one kernel; 0: row-panel fc1 + K-streaming fc2
+ *   "use_gemm3"   [1] 128-row wave-tile GEMM over blocked operands (fc2; every ViT-B linear); 0: gemm2 / gemm
+ *   "use_gemm2"   [1] DMA-ring GEMM for the patch embedding (and fc2 when use_gemm3 = 0)
+ *   "tail_split"  [1] split the panels / tiles of the last, partially filled round of CUs
+ *   "use_projf"   [0] attn.proj + residual fused in front of the fused MLP kernel
+ *   "use_rowlin"  [0] register-resident-input kernels for LN1+qkv and proj+residual
+ *   "panel_rows"  [128] row-panel height, 64 or 128;  "chunk" (= set_chunk);  "debug" (experiment hooks) */
 int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value);
 
 /* HIP-event profiler for bench.py's roofline object: while armed, every launch of the selected
