@@ -728,6 +728,20 @@ int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void
   return l2_normalize_rows(x_dev, n, d, y_dev, S(stream));
 }
 
+size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k) { return knn_screen_workspace_bytes(nq, ntotal, d, k); }
+
+int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, int64_t ntotal, int d, int k,
+                                float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (nq > 0 && (!q_dev || !xb_dev || !xb_bf16_dev || !dist_dev || !idx_dev || !workspace_dev)) return fail(EFFOCR_EINVAL, "knn(screened): NULL device pointer");
+  return knn_ip_topk_screened(q_dev, nq, xb_dev, xb_bf16_dev, ntotal, d, k, xnorm_max, dist_dev, idx_dev, workspace_dev, workspace_bytes, S(stream));
+}
+
+int effocr_convert_bf16(const float* src_dev, int64_t n, void* dst_dev, void* stream) {
+  if (n > 0 && (!src_dev || !dst_dev)) return fail(EFFOCR_EINVAL, "convert_bf16: NULL device pointer");
+  if (n < 0) return fail(EFFOCR_EINVAL, "convert_bf16: n < 0");
+  return convert_bf16(src_dev, n, dst_dev, S(stream));
+}
+
 int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64_t row_stride, const int32_t* boxes_dev,
                           int n, int size, int antialias, const float* mean, const float* stdv, const float* fill,
                           float* out_dev, void* stream) {

@@ -106,6 +106,12 @@ int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, cons
 size_t knn_workspace_bytes(int64_t B, int64_t N, int D, int k);
 int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, int k, float* dist, int64_t* idx,
                 void* ws, size_t ws_bytes, hipStream_t s);
+// screened search for large indexes: bf16-MFMA screening with a rigorous error bound + exact re-rank; results are
+// bit-identical to knn_ip_topk.  xb16 = bf16 copy of xb (convert_bf16), xnorm_max >= every row's L2 norm.
+size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k);
+int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, int64_t N, int D, int k, float xnorm_max,
+                         float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s);
+int convert_bf16(const float* src, int64_t n, void* dst, hipStream_t s);
 int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s);
 int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);
 

@@ -55,18 +55,26 @@ __device__ __forceinline__ void topk_insert(float (&ls)[KMAX], int (&li)[KMAX], 
 }
 
 struct KnnArgs {
-  const float* q; int B;
-  const float* xb; int N; int D;
+  const void* q; int B;             // queries / index rows in the kernel's element type (fp32 exact, bf16 screening)
+  const void* xb; int N; int D;
   int k;
   int nqt;                // query tiles
   int tiles_per_chunk;    // 128-row index tiles per chunk
   int nchunks;
   float* pdist; int* pidx;          // partial lists [nchunks][B][KMAX]   (nchunks > 1)
   float* dist; int64_t* idx;        // final [B][k]                        (nchunks == 1)
+  // screening (knn_ip_topk_screened): candidate collection and the gated fallback
+  const float* adist; const float* qnorm; float eps_scale;   // tau[q] = adist[q][k-1] - eps_scale * qnorm[q]
+  int* cand; int* cnt; int cap;     // candidate ids [B][cap], counters [B]
+  const int* run_flag;              // non-NULL: the launch is a no-op unless *run_flag != 0 (fallback after an overflow)
 };
 
-template <int KMAX>
+// E = float: exact scores (the product's definition).  E = __bf16: screening scores s^ from bf16-rounded operands
+// (fp32 accumulation).  COLLECT: instead of keeping a top-k, append every row with s^ >= tau[q] to the query's
+// candidate list — same MFMA path as the top-k pass, so s^ is bit-identical between the two passes.
+template <int KMAX, typename E, bool COLLECT>
 __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
+  if (a.run_flag != nullptr && *a.run_flag == 0) return;
   constexpr int MERGEB = 128 * 4 * KMAX * 8;
   constexpr int LDSB = GEMM_LDS > MERGEB ? GEMM_LDS : MERGEB;
   __shared__ __attribute__((aligned(16))) char smem[LDSB];
@@ -78,8 +86,10 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
   const int ntiles = (a.N + 127) / 128;
   const int t0 = chunk * a.tiles_per_chunk;
   const int t1 = min(t0 + a.tiles_per_chunk, ntiles);
-  const int nks = a.D / 32;
+  const int nks = a.D * (int)sizeof(E) / ROWB;           // K-stages of 128 bytes per row
   const int nstage = (t1 - t0) * nks;
+  const E* Q = static_cast<const E*>(a.q);
+  const E* X = static_cast<const E*>(a.xb);
 
   float ls[2][KMAX];
   int li[2][KMAX];
@@ -98,10 +108,10 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
 
   u32x4 rx[4], rq[4];
   if (nstage > 0) {
-    stage_load<float>(rx, a.xb, a.D, t0 * 128, a.N, 0, tid);
-    stage_load<float>(rq, a.q, a.D, q0, a.B, 0, tid);
-    stage_store<float>(rx, smem, tid);
-    stage_store<float>(rq, smem + TILEB, tid);
+    stage_load<E>(rx, X, a.D, t0 * 128, a.N, 0, tid);
+    stage_load<E>(rq, Q, a.D, q0, a.B, 0, tid);
+    stage_store<E>(rx, smem, tid);
+    stage_store<E>(rq, smem + TILEB, tid);
   }
   __syncthreads();
 
@@ -113,16 +123,36 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
     int ntile = tile, nksn = ks + 1;
     if (nksn == nks) { nksn = 0; ntile = tile + 1; }
     if (more) {
-      stage_load<float>(rx, a.xb, a.D, ntile * 128, a.N, nksn * ROWB, tid);
-      stage_load<float>(rq, a.q, a.D, q0, a.B, nksn * ROWB, tid);
+      stage_load<E>(rx, X, a.D, ntile * 128, a.N, nksn * ROWB, tid);
+      stage_load<E>(rq, Q, a.D, q0, a.B, nksn * ROWB, tid);
     }
-    stage_mma<float>(acc, cur, cur + TILEB, wn, wm, lane);
+    stage_mma<E>(acc, cur, cur + TILEB, wn, wm, lane);
     if (ks == nks - 1) {
       // scores of index tile `tile` are complete: feed the per-lane top-k lists, reset.
       // Per query column j a lane holds 32 candidates (i, r) with ascending index id; a bitmask of
       // those beating the current k-th score is drained lowest-bit-first through ONE insertion site
       // (keeps everything statically indexed / register resident and the code small).
       const int nbase = tile * 128 + wn * 64 + 4 * half;
+      if constexpr (COLLECT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int qg = q0 + wm * 64 + j * 32 + r31;
+          const bool qok = qg < a.B;
+          const int qc = qok ? qg : a.B - 1;
+          const float tau = a.adist[(int64_t)qc * a.k + (a.k - 1)] - a.eps_scale * a.qnorm[qc];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
+              if (qok && n < a.N && acc[i][j][r] >= tau) {
+                const int pos = atomicAdd(a.cnt + qg, 1);
+                if (pos < a.cap) a.cand[(int64_t)qg * a.cap + pos] = n;
+              }
+              acc[i][j][r] = 0.f;
+            }
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         uint32_t hits = 0;
@@ -158,13 +188,14 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
       }
     }
     if (more) {
-      stage_store<float>(rx, nxt, tid);
-      stage_store<float>(rq, nxt + TILEB, tid);
+      stage_store<E>(rx, nxt, tid);
+      stage_store<E>(rq, nxt + TILEB, tid);
     }
     __syncthreads();
     tile = ntile; ks = nksn;
   }
 
+  if constexpr (COLLECT) return;
   // ---- merge the 4 partial lists of every query through LDS (staging buffers are dead now)
   float* mS = reinterpret_cast<float*>(smem);                       // [128][4][KMAX]
   int* mI = reinterpret_cast<int*>(smem + 128 * 4 * KMAX * 4);
@@ -212,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
 template <int KMAX>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
                                                         int B, int nchunks, int k, float* __restrict__ dist,
-                                                        int64_t* __restrict__ idx) {
+                                                        int64_t* __restrict__ idx, const int* __restrict__ run_flag) {
+  if (run_flag != nullptr && *run_flag == 0) return;
   constexpr int LPL = MAX_CHUNKS / 64;
   const int lane = threadIdx.x & 63;
   const int qg = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -297,14 +329,104 @@ Plan make_plan(int64_t B, int64_t N, int k) {
   return p;
 }
 
-template <int KMAX>
+template <int KMAX, typename E>
 int launch_knn(const KnnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((knn_partial_kernel<KMAX>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((knn_partial_kernel<KMAX, E, false>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a);
   int rc = check_launch("knn_partial");
   if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
   hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
-                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx);
+                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag);
   return check_launch("knn_merge");
+}
+template <typename E>
+int launch_knn_k(int kmax, const KnnArgs& a, hipStream_t s) {
+  switch (kmax) {
+    case 1: return launch_knn<1, E>(a, s);
+    case 16: return launch_knn<16, E>(a, s);
+    case 32: return launch_knn<32, E>(a, s);
+  }
+  return fail(EFFOCR_EINVAL, "knn: internal");
+}
+
+// ---- screening helpers --------------------------------------------------------------------------------------------
+// queries -> bf16 copy + fp32 L2 norms; zero the candidate counters and the overflow flag.  One wave per query.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ q, int B, int D, __bf16* __restrict__ qb,
+                                                       float* __restrict__ qnorm, int* __restrict__ cnt, int* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
+  if (row >= B) return;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = q[(int64_t)row * D + d]; ss += v * v; qb[(int64_t)row * D + d] = (__bf16)v; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if (lane == 0) { qnorm[row] = sqrtf(ss); cnt[row] = 0; }
+}
+
+__global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restrict__ src, int64_t n, __bf16* __restrict__ dst) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+    *reinterpret_cast<u32x2*>(dst + i) = pack4<__bf16>(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int64_t j = i; j < n; ++j) dst[j] = (__bf16)src[j];
+  }
+}
+
+// Exact re-rank of one query's candidates: score = the ascending-k fp32 fmaf chain (the product's definition, what the
+// fp32 MFMA kernel and oracle/flat_ip.c compute), order = (score desc, id asc).  One workgroup per query.
+constexpr int RR_CAP = 512;
+__global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict__ q, const float* __restrict__ xb, int D, int k,
+                                                         const int* __restrict__ cand, const int* __restrict__ cnt, int cap,
+                                                         float* __restrict__ dist, int64_t* __restrict__ idx, int* __restrict__ flag) {
+  __shared__ float sS[RR_CAP];
+  __shared__ int sI[RR_CAP];
+  const int qg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int n = cnt[qg];
+  if (n > cap) { if (tid == 0) atomicOr(flag, 1); return; }   // overflow: the gated exact pass recomputes everything
+  const float* qr = q + (int64_t)qg * D;
+  for (int j = tid; j < RR_CAP; j += 256) {
+    float sc = -FLT_MAX; int id = ID_NONE;
+    if (j < n) {
+      id = cand[(int64_t)qg * cap + j];
+      const float* xr = xb + (int64_t)id * D;
+      sc = 0.f;
+      for (int d = 0; d < D; d += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(qr + d);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xr + d);
+        sc = fmaf(a[0], b[0], sc); sc = fmaf(a[1], b[1], sc); sc = fmaf(a[2], b[2], sc); sc = fmaf(a[3], b[3], sc);
+      }
+    }
+    sS[j] = sc; sI[j] = id;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  constexpr int PER = RR_CAP / 64;
+  float ls[PER]; int li[PER];
+#pragma unroll
+  for (int t = 0; t < PER; ++t) { ls[t] = sS[lane + 64 * t]; li[t] = sI[lane + 64 * t]; }
+  for (int o = 0; o < k; ++o) {
+    float bs = -FLT_MAX; int bi = ID_NONE;
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+      if (before(ls[t], li[t], bs, bi)) { bs = ls[t]; bi = li[t]; }
+    float ws = bs; int wi = bi;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(ws, off, 64);
+      const int oi = __shfl_xor(wi, off, 64);
+      if (before(os, oi, ws, wi)) { ws = os; wi = oi; }
+    }
+    if (wi != ID_NONE) {
+#pragma unroll
+      for (int t = 0; t < PER; ++t)
+        if (li[t] == wi) { ls[t] = -FLT_MAX; li[t] = ID_NONE; }   // ids are unique: exactly one owner
+    }
+    if (lane == 0) {
+      dist[(int64_t)qg * k + o] = ws;
+      idx[(int64_t)qg * k + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
+    }
+  }
 }
 
 }  // namespace
@@ -326,19 +448,94 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
   const Plan p = make_plan(B, N, k);
   if (p.kmax == 0) return fail(EFFOCR_EUNSUPPORTED, "knn: k > 32 is not supported by the fused top-k kernel");
   if (ws_bytes < knn_workspace_bytes(B, N, D, k)) return fail(EFFOCR_EWORKSPACE, "knn: workspace too small");
-  KnnArgs a;
+  KnnArgs a{};
   a.q = q; a.B = (int)B; a.xb = (N > 0) ? xb : q; a.N = (int)N; a.D = D; a.k = k;
   a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
   a.pdist = static_cast<float*>(ws);
   a.pidx = reinterpret_cast<int*>(static_cast<char*>(ws) + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
   a.dist = dist; a.idx = idx;
   if (N == 0) { a.tiles_per_chunk = 0; a.nchunks = 1; }
+  return launch_knn_k<float>(p.kmax, a, s);
+}
+
+// ---- screened search: bit-identical results to knn_ip_topk, for large indexes ------------------------------------------
+// Workspace layout: [exact-pass partial lists | qb bf16 | qnorm | adist | aidx | cnt | flag | cand]
+struct ScreenWs { size_t part, qb, qnorm, adist, aidx, cnt, flag, cand, total; };
+ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
+  ScreenWs w; size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off = align_up(off + n, 256); return o; };
+  w.part = take(knn_workspace_bytes(B, N, D, k));
+  w.qb = take((size_t)B * D * 2);
+  w.qnorm = take((size_t)B * 4);
+  w.adist = take((size_t)B * k * 4);
+  w.aidx = take((size_t)B * k * 8);
+  w.cnt = take((size_t)B * 4);
+  w.flag = take(256);
+  w.cand = take((size_t)B * RR_CAP * 4);
+  w.total = off;
+  return w;
+}
+size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k) {
+  if (B <= 0 || k <= 0) return 0;
+  return screen_ws(B, N, D, k).total;
+}
+
+int convert_bf16(const float* src, int64_t n, void* dst, hipStream_t s) {
+  if (n <= 0) return EFFOCR_OK;
+  hipLaunchKernelGGL(convert_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, src, n, static_cast<__bf16*>(dst));
+  return check_launch("convert_bf16");
+}
+
+int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, int64_t N, int D, int k, float xnorm_max,
+                         float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (B < 0 || N < 0 || D <= 0 || k <= 0 || !(xnorm_max >= 0.f)) return fail(EFFOCR_EINVAL, "knn(screened): bad sizes");
+  if (B == 0) return EFFOCR_OK;
+  if (D % 64 != 0) return fail(EFFOCR_EUNSUPPORTED, "knn(screened): embedding dim must be a multiple of 64");
+  if (N < k) return fail(EFFOCR_EUNSUPPORTED, "knn(screened): needs at least k index rows (use the exact entry point)");
+  if (N >= (int64_t)INT_MAX - 256 || B >= (int64_t)INT_MAX - 256) return fail(EFFOCR_EUNSUPPORTED, "knn: index or batch too large");
+  const Plan p = make_plan(B, N, k);
+  if (p.kmax == 0) return fail(EFFOCR_EUNSUPPORTED, "knn: k > 32 is not supported by the fused top-k kernel");
+  const ScreenWs w = screen_ws(B, N, D, k);
+  if (ws_bytes < w.total) return fail(EFFOCR_EWORKSPACE, "knn(screened): workspace too small");
+  char* W = static_cast<char*>(ws);
+  __bf16* qb = reinterpret_cast<__bf16*>(W + w.qb);
+  float* qnorm = reinterpret_cast<float*>(W + w.qnorm);
+  float* adist = reinterpret_cast<float*>(W + w.adist);
+  int64_t* aidx = reinterpret_cast<int64_t*>(W + w.aidx);
+  int* cnt = reinterpret_cast<int*>(W + w.cnt);
+  int* flag = reinterpret_cast<int*>(W + w.flag);
+  int* cand = reinterpret_cast<int*>(W + w.cand);
+  hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, q, (int)B, D, qb, qnorm, cnt, flag);
+  int rc = check_launch("knn_prep");
+  if (rc) return rc;
+  KnnArgs a{};
+  a.B = (int)B; a.N = (int)N; a.D = D; a.k = k;
+  a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
+  a.pdist = reinterpret_cast<float*>(W + w.part);
+  a.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
+  // pass 1: approximate top-k (only the k-th score is used)
+  a.q = qb; a.xb = xb16; a.dist = adist; a.idx = aidx;
+  if ((rc = launch_knn_k<__bf16>(p.kmax, a, s))) return rc;
+  // pass 2: every row whose approximate score is within 2*eps of the k-th approximate score.
+  // |s^ - s| <= eps = c * |q| * |x|: operand rounding (2^-8 + 2^-16) plus fp32 accumulation of both chains (4 d 2^-24),
+  // 1e-4 relative slack for the fp32 norms.  A true top-k row has s >= s_(k), hence s^ >= s_(k) - eps >= s^_(k) - 2 eps.
+  const float c = (0.00390625f + 0.0000152587890625f + 4.0f * (float)D * 5.9604645e-8f) * 1.0001f;
+  a.adist = adist; a.qnorm = qnorm; a.eps_scale = 2.0f * c * xnorm_max; a.cand = cand; a.cnt = cnt; a.cap = RR_CAP;
   switch (p.kmax) {
-    case 1: return launch_knn<1>(a, s);
-    case 16: return launch_knn<16>(a, s);
-    case 32: return launch_knn<32>(a, s);
+    case 1: hipLaunchKernelGGL((knn_partial_kernel<1, __bf16, true>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((knn_partial_kernel<16, __bf16, true>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((knn_partial_kernel<32, __bf16, true>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a); break;
   }
-  return fail(EFFOCR_EINVAL, "knn: internal");
+  if ((rc = check_launch("knn_collect"))) return rc;
+  // pass 3: exact re-rank
+  hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)B), dim3(256), 0, s, q, xb, D, k, cand, cnt, RR_CAP, dist, idx, flag);
+  if ((rc = check_launch("knn_rerank"))) return rc;
+  // fallback, gated on the device: the exact search over everything if any query overflowed its candidate list
+  KnnArgs e{};
+  e.q = q; e.B = (int)B; e.xb = xb; e.N = (int)N; e.D = D; e.k = k;
+  e.nqt = p.nqt; e.tiles_per_chunk = p.tpc; e.nchunks = p.nchunks;
+  e.pdist = a.pdist; e.pidx = a.pidx; e.dist = dist; e.idx = idx; e.run_flag = flag;
+  return launch_knn_k<float>(p.kmax, e, s);
 }
 
 int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s) {

@@ -32,12 +32,17 @@ class IndexFlatIP:
     metric_type = 0          # faiss.METRIC_INNER_PRODUCT
     is_trained = True
 
-    def __init__(self, d, device="cuda:0"):
+    SCREEN_MIN_ROWS = 65536   # from this size on `search` uses the screened entry point (bit-identical results, ~4x faster at 1M rows)
+
+    def __init__(self, d, device="cuda:0", screen="auto"):
         self.d = int(d)
         self.device = _lib.require_gpu(device)
         self._L = _lib.lib()
         self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
         self._ws = None
+        self.screen = screen                     # "auto" | True | False
+        self._xb16 = None                        # bf16 copy of the rows + max row norm, built lazily for the screening pass
+        self._xnorm_max = 0.0
 
     @property
     def ntotal(self):
@@ -55,9 +60,26 @@ class IndexFlatIP:
     def add(self, x):
         x = self._as_dev(x)
         self._xb = x.clone() if self.ntotal == 0 else torch.cat([self._xb, x], dim=0)
+        self._xb16 = None
 
     def reset(self):
         self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+        self._xb16 = None
+
+    def _use_screen(self, k):
+        if self.screen is False or self.d % 64 != 0 or k > 32 or self.ntotal < max(k, 1):
+            return False
+        return True if self.screen is True else self.ntotal >= self.SCREEN_MIN_ROWS
+
+    def _screen_copy(self):
+        if self._xb16 is None:
+            self._xb16 = torch.empty((self.ntotal, self.d), dtype=torch.bfloat16, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.effocr_convert_bf16(_lib.ptr(self._xb), self.ntotal * self.d, _lib.ptr(self._xb16),
+                                                       _lib.current_stream(self.device)), "effocr_convert_bf16")
+            # an upper bound of every row norm (fp32 rounding slack included); one host read per index change
+            self._xnorm_max = float(torch.linalg.vector_norm(self._xb, dim=1).max().item()) * (1.0 + 1e-5)
+        return self._xb16
 
     def reconstruct_n(self, i0=0, n=None):
         n = self.ntotal - i0 if n is None else n
@@ -77,6 +99,7 @@ class IndexFlatIP:
             _lib.check(self._L.effocr_gather_rows(_lib.ptr(self._xb), _lib.ptr(rows), rows.numel(), self.d,
                                                   _lib.ptr(dst), _lib.current_stream(self.device)), "effocr_gather_rows")
         self._xb = dst
+        self._xb16 = None
         return int(ids.size)
 
     def search_device(self, q, k):
@@ -89,6 +112,16 @@ class IndexFlatIP:
         D = torch.empty((n, k), dtype=torch.float32, device=self.device)
         I = torch.empty((n, k), dtype=torch.int64, device=self.device)
         if n == 0:
+            return D, I
+        if self._use_screen(k):
+            xb16 = self._screen_copy()
+            need = int(self._L.effocr_knn_screen_workspace_bytes(n, self.ntotal, self.d, k))
+            with torch.cuda.device(self.device):
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+                _lib.check(self._L.effocr_knn_ip_topk_screened(_lib.ptr(q), n, _lib.ptr(self._xb), _lib.ptr(xb16), self.ntotal, self.d, k,
+                                                               self._xnorm_max, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws),
+                                                               self._ws.numel(), _lib.current_stream(self.device)), "effocr_knn_ip_topk_screened")
             return D, I
         need = int(self._L.effocr_knn_workspace_bytes(n, self.ntotal, self.d, k))
         with torch.cuda.device(self.device):

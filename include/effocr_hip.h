@@ -121,6 +121,18 @@ size_t effocr_knn_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k);
 int effocr_knn_ip_topk(const float* q_dev, int64_t nq, const float* xb_dev, int64_t ntotal, int d, int k,
                        float* dist_dev, int64_t* idx_dev, void* workspace_dev, size_t workspace_bytes,
                        void* stream);
+/* The same search for LARGE indexes (e.g. BASELINE configs[3], 1M x 768): a bf16-MFMA screening pass finds every row
+ * whose approximate score s^ lies within 2*eps of the k-th largest s^ (eps = c*|q|*xnorm_max bounds |s^ - s| rigorously:
+ * operand rounding 2^-8 + 2^-16, fp32 accumulation 4*d*2^-24), the candidates are re-ranked with the exact ascending-k
+ * fmaf chain, and — gated on the device — the exact search runs over everything if a query had more than 512
+ * candidates.  dist / idx are BIT-IDENTICAL to effocr_knn_ip_topk for every input.
+ *   xb_bf16_dev  bf16 copy of xb_dev made with effocr_convert_bf16;  xnorm_max >= the L2 norm of every index row
+ *   d % 64 == 0, k <= 32, ntotal >= k. */
+size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k);
+int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, int64_t ntotal, int d,
+                                int k, float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev,
+                                size_t workspace_bytes, void* stream);
+int effocr_convert_bf16(const float* src_dev, int64_t n, void* dst_dev, void* stream);
 /* torch.nn.functional.normalize(x, p=2, dim=1) (infer_effocr.py:316; PML InferenceModel default) */
 int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void* stream);
 /* IndexFlat.remove_ids compaction (infer_effocr.py:211): dst[i] = src[keep_rows[i]] */

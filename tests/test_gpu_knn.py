@@ -123,3 +123,58 @@ def test_l2_normalize_matches_oracle(dev):
     ref = knn_ref.l2_normalize(x)
     np.testing.assert_allclose(y, ref, rtol=2e-6, atol=1e-7)
     assert (y[3] == 0).all()
+
+
+# ---------------------------------------------------------------- screened search (large indexes): bit-identical to the exact kernel
+def _both(dev, X, Q, k):
+    from effocr_amd.knn import IndexFlatIP
+    ex = IndexFlatIP(X.shape[1], device=dev, screen=False)
+    sc = IndexFlatIP(X.shape[1], device=dev, screen=True)
+    ex.add(X); sc.add(X)
+    De, Ie = ex.search_device(Q, k)
+    Ds, Is = sc.search_device(Q, k)
+    torch.cuda.synchronize()
+    return De, Ie, Ds, Is
+
+
+@pytest.mark.parametrize("N,D,B,k", [(200_000, 128, 300, 10), (100_000, 768, 64, 1), (70_000, 384, 1024, 32), (3000, 64, 5, 16)])
+def test_screened_search_is_bit_identical(dev, N, D, B, k):
+    g = torch.Generator(device=dev).manual_seed(N + D)
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    pick = torch.randint(0, N, (B,), generator=g, device=dev)
+    Q = torch.nn.functional.normalize(X[pick] + 0.05 * torch.randn(B, D, generator=g, device=dev), dim=1)
+    De, Ie, Ds, Is = _both(dev, X, Q, k)
+    assert torch.equal(Ie, Is)
+    assert torch.equal(De.view(torch.int32), Ds.view(torch.int32))
+    assert (Ie[:, 0] == pick).all()
+
+
+def test_screened_search_non_unit_rows_ties_and_overflow(dev):
+    """Rows of very different norms (the bound uses the max norm), exact duplicates (tie rule: lower id first) and
+    a cluster of > 512 near-identical rows around some queries (candidate overflow -> gated exact fallback)."""
+    g = torch.Generator(device=dev).manual_seed(7)
+    N, D = 90_000, 256
+    X = torch.randn(N, D, generator=g, device=dev) * torch.rand(N, 1, generator=g, device=dev) * 3
+    X[5000:5004] = X[100]                                   # exact duplicates of row 100
+    centre = torch.nn.functional.normalize(torch.randn(1, D, generator=g, device=dev), dim=1) * 2.5
+    X[20000:21500] = centre + 1e-4 * torch.randn(1500, D, generator=g, device=dev)     # 1500 near-identical rows
+    Q = torch.cat([X[[100, 7, 5001]], centre, torch.randn(60, D, generator=g, device=dev)])
+    for k in (1, 10):
+        De, Ie, Ds, Is = _both(dev, X, Q, k)
+        assert torch.equal(Ie, Is) and torch.equal(De.view(torch.int32), Ds.view(torch.int32))
+    assert Is[0, 0].item() == 100 and Is[2, 0].item() == 100 and Is[0, 1].item() == 5000      # duplicates: ascending id
+
+
+def test_screened_auto_threshold_and_invalidation(dev):
+    from effocr_amd.knn import IndexFlatIP
+    idx = IndexFlatIP(128, device=dev)
+    assert not idx._use_screen(10)
+    idx.add(torch.nn.functional.normalize(torch.randn(70_000, 128, device=dev), dim=1))
+    assert idx._use_screen(10) and not idx._use_screen(33)
+    q = idx._xb[:4].clone()
+    D1, I1 = idx.search_device(q, 5)
+    assert idx._xb16 is not None and (I1[:, 0].cpu() == torch.arange(4)).all()
+    idx.remove_ids(np.array([0]))
+    assert idx._xb16 is None
+    D2, I2 = idx.search_device(q[1:], 5)
+    assert (I2[:, 0].cpu() == torch.arange(3)).all()        # rows shifted down by one
