@@ -118,3 +118,21 @@ def test_fast_path_operator_argument_checks(hip_lib):
     assert L.effocr_op_rowlin_blocked(0, 0, p, None, p, p, 1e-6, p, p, p, 32, 384, 1152, 96, None) == -1   # rows_alloc % 128
     assert L.effocr_op_rowlin_blocked(0, 0, p, None, p, p, 1e-6, p, p, p, 32, 256, 768, 128, None) == -2
     assert b"rowlin" in L.effocr_last_error()
+
+
+def test_screened_knn_argument_checks(hip_lib):
+    L = hip_lib
+    p = ctypes.c_void_p(4096)
+    assert L.effocr_knn_screen_workspace_bytes(1024, 1_000_000, 768, 10) >= 1024 * 512 * 4 + 1024 * 768 * 2
+    assert L.effocr_knn_screen_workspace_bytes(0, 100, 64, 1) == 0
+    call = lambda nq, n, d, k, ws: L.effocr_knn_ip_topk_screened(p, nq, p, p, n, d, k, 1.0, p, p, p, ws, None)
+    assert call(4, 1000, 96, 5, 1 << 30) == -2          # d % 64
+    assert call(4, 3, 128, 5, 1 << 30) == -2            # fewer rows than k
+    assert call(4, 1000, 128, 33, 1 << 30) == -2        # k > 32
+    assert call(4, 1000, 128, 5, 16) == -3              # workspace too small
+    assert call(0, 1000, 128, 5, 0) == 0
+    assert L.effocr_knn_ip_topk_screened(p, 4, p, None, 1000, 128, 5, 1.0, p, p, p, 1 << 30, None) == -1
+    assert L.effocr_knn_ip_topk_screened(p, 4, p, p, 1000, 128, 5, float("nan"), p, p, p, 1 << 30, None) == -1
+    assert L.effocr_convert_bf16(p, -1, p, None) == -1
+    assert L.effocr_convert_bf16(None, 8, p, None) == -1
+    assert L.effocr_convert_bf16(p, 0, p, None) == 0
