@@ -100,14 +100,15 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
   const int wv = wave_id();
   const int wn = (BMT == 128) ? (wv >> 1) : wv, wm = (BMT == 128) ? (wv & 1) : 0;
   // Tail split: 1 workgroup/CU and ceil(M/PBM) panels rarely fill the last round of CUs, so the panels of
-  // that round (index >= tail_first) are cut along N into tail_split workgroups of niter/tail_split sweep
+  // that round (index >= tail_first) are cut along N into tail_split workgroups of ~niter/tail_split sweep
   // steps each (each repeats the cheap prologue); they have the highest block ids = dispatched last.
   int panel = blockIdx.x, niter = a.N / PNT, it_lo = 0;
   if (a.tail_split > 1 && panel >= a.tail_first) {
     const int t = panel - a.tail_first;
     panel = a.tail_first + t / a.tail_split;
-    niter /= a.tail_split;
-    it_lo = (t - (t / a.tail_split) * a.tail_split) * niter;
+    const int part = t - (t / a.tail_split) * a.tail_split;
+    it_lo = part * niter / a.tail_split;                // uneven parts are fine: [part*niter/split, (part+1)*niter/split)
+    niter = (part + 1) * niter / a.tail_split - it_lo;
   }
   const int m0 = panel * PBM;
   const int nlo = it_lo * PNT;                           // first output column of this workgroup
@@ -507,9 +508,9 @@ int launch_panel(int pro, int epi, const PanelArgs& a_in, hipStream_t s) {
   a.tail_first = npanels;
   a.tail_split = 1;
   if (!a.no_tail_split && tail > 0) {
-    int split = 1;
-    for (int d = 2; d <= niter && d * tail <= slots; ++d)
-      if (niter % d == 0) split = d;
+    int split = slots / tail;                            // as many parts as fit into one round of CUs (>= 1 sweep step each)
+    if (split > niter) split = niter;
+    if (split < 1) split = 1;
     a.tail_first = npanels - tail;
     a.tail_split = split;
   }
