@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 rocpd databases (gpurun_out/prof_<tag>/) into text files under profiles/.
 
-usage: python tools_rocpd.py <tag>        e.g. r01  -> profiles/r01_kernel_stats.txt, r01_pmc.txt, r01_traffic.json
+usage: python tools/rocpd.py <tag>        e.g. r01  -> profiles/r01_kernel_stats.txt, r01_pmc.txt, r01_traffic.json
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced read stream
 (MI355X_MICROARCH.md, HBM section), so reads = 2 * FETCH_SIZE * 1024 bytes.
 """
