@@ -58,6 +58,7 @@ struct effocr_encoder {
   int debug = 0;
   int use_rowlin = 0;               // 1: register-resident-input kernels (rowlin.hip) for LN1+qkv and proj+residual instead of the row-panel ones (measured 7 % slower: A/B switch)
   int use_projf = 0;                // 1: attn.proj + residual fused in front of the fused MLP kernel (correct and tested; measured 0.5 ms slower than the separate row-panel launch: A/B switch)
+  int use_qkvattn = 1;              // fused norm1 + attn.qkv + attention kernel (qkvattn.hip): no qkv tensor in HBM (0: A/B switch)
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
@@ -380,6 +381,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
   const bool projf = mlpf && !rl && e->use_projf;
+  const bool qaf = blk && panel && !rl && e->use_qkvattn && qkv_attn_supported(prec, D, T);
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
@@ -402,11 +404,18 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         if ((rc = timed(e, "rowlin_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return rowlin(prec, ROWLIN_RESID, q, s); }))) return rc;
       } else {
       PanelArgs p{};
+      if (qaf) {                                         // norm1 + qkv + attention in one kernel, one workgroup per image
+        QkvAttnArgs q{};
+        q.x = xs; q.gamma = F(L.ln1w); q.beta = F(L.ln1b); q.eps = 1e-6f; q.Wb = wb + L.qkvw_b; q.bias = F(L.qkvb); q.out = att;
+        q.B = B; q.T = T; q.D = D; q.rows_alloc = (int64_t)w.rows;
+        if ((rc = timed(e, "qkv_attn_fused", 2.0 * Md * 3.0 * Dd * Dd + 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return qkv_attn_fused(prec, q, s); }))) return rc;
+      } else {
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
       p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;
       p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS, p, s); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
+      }
       if (!projf) {
       p = PanelArgs{};
       p.A = att; p.lda = D; p.W = wb + L.projw; p.bias = F(L.projb); p.out = xs; p.ldo = D; p.resid = xs; p.ldr = D;
@@ -640,6 +649,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
+  if (n == "use_qkvattn") { enc->use_qkvattn = value; return EFFOCR_OK; }
   if (n == "use_projf") { enc->use_projf = value; return EFFOCR_OK; }
   if (n == "use_rowlin") { enc->use_rowlin = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
@@ -838,6 +848,18 @@ int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const vo
   q.x = x_blk_dev; q.A = a_blk_dev; q.gamma = gamma_dev; q.beta = beta_dev; q.eps = eps; q.Wb = w_blk_dev; q.bias = bias_dev; q.out = out_blk_dev;
   q.M = m; q.D = d; q.N = n; q.rows_alloc = rows_alloc;
   return rowlin(precision, mode, q, S(stream));
+}
+
+int effocr_op_qkv_attn_blocked(int precision, const float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                               const void* wqkv_blk_dev, const float* bias_dev, void* out_blk_dev, int batch, int tokens, int d,
+                               int rows_alloc, void* stream) {
+  if (batch > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !wqkv_blk_dev || !bias_dev || !out_blk_dev))
+    return fail(EFFOCR_EINVAL, "op_qkv_attn_blocked: NULL device pointer");
+  if (batch < 0 || tokens < 1) return fail(EFFOCR_EINVAL, "op_qkv_attn_blocked: bad batch / tokens");
+  QkvAttnArgs q{};
+  q.x = x_blk_dev; q.gamma = gamma_dev; q.beta = beta_dev; q.eps = eps; q.Wb = wqkv_blk_dev; q.bias = bias_dev; q.out = out_blk_dev;
+  q.B = batch; q.T = tokens; q.D = d; q.rows_alloc = rows_alloc;
+  return qkv_attn_fused(precision, q, S(stream));
 }
 
 int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,

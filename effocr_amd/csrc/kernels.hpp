@@ -55,6 +55,18 @@ struct MlpArgs {
 bool mlp_fused_supported(int prec, int D, int H);
 int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);
 
+// qkvattn.hip — fused norm1 + attn.qkv + softmax(q k^T / 8) v per image (the qkv tensor never exists in HBM)
+struct QkvAttnArgs {
+  const float* x;                   // fp32 residual stream, fragment-blocked [rows_alloc, D]
+  const float* gamma; const float* beta; float eps;   // norm1
+  const void* Wb; const float* bias;   // attn.qkv weight [3D, D] fragment-blocked, bias [3D]
+  void* out;                        // attention output, 16-bit fragment-blocked [rows_alloc, D] (feature = head * 64 + dim)
+  int B, T, D;                      // images, tokens per image, embed dim (heads = D / 64)
+  int64_t rows_alloc;               // rows addressable in x / out (multiple of 32, >= B * T)
+};
+bool qkv_attn_supported(int prec, int D, int T);
+int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s);
+
 // rowlin.hip — LN + linear (16-bit out) / linear + residual over the blocked layout, input fragments in registers
 enum { ROWLIN_LN = 0, ROWLIN_RESID = 1 };
 struct RowLinArgs {

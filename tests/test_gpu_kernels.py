@@ -360,3 +360,47 @@ def test_proj_mlp_fused_blocked(hip_lib, dev, prec, shape, scratch):
     tol = {"bf16": 1e-2, "fp16": 1.5e-3}[prec]
     err, scale = (got - ref).abs().max().item(), delta.abs().max().item()
     assert err <= tol * scale, f"{prec} {shape}: err {err:.3e} vs delta scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T,D", [(3, 197, 384), (1, 197, 384), (5, 50, 128), (2, 17, 128), (2, 224, 128), (4, 64, 384), (2, 193, 384), (1, 1, 128), (300, 197, 384)])
+def test_qkv_attn_fused_blocked(hip_lib, dev, prec, B, T, D):
+    """qkvattn.hip: norm1 + attn.qkv + softmax(q k^T / 8) v in one kernel (one workgroup per image) vs an fp64
+    restatement with the same operand rounding points (LN output, q / k / v and P rounded to the operand type)."""
+    heads = D // 64
+    M = B * T
+    g = torch.Generator().manual_seed(B * 1000 + T + D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.3 * torch.randn(M, 1, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(TDT[prec])
+    bias = 0.5 * torch.randn(3 * D, generator=g)
+    ra = (M + 127) // 128 * 128
+    xd, wd = to_blocked(x, ra).to(dev), to_blocked(w, 3 * D).to(dev)
+    gd, btd, bd = gamma.to(dev), beta.to(dev), bias.to(dev)
+    out = torch.zeros(ra * D, dtype=TDT[prec], device=dev)
+    _lib.check(hip_lib.effocr_op_qkv_attn_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(btd), 1e-6, _lib.ptr(wd),
+                                                  _lib.ptr(bd), _lib.ptr(out), B, T, D, ra, _stream(dev)), "op_qkv_attn_blocked")
+    torch.cuda.synchronize()
+    got = from_blocked(out.cpu(), M, D, ra).double()
+    xn = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6).to(TDT[prec]).double()
+    qkv = (xn @ w.double().T + bias.double()).to(TDT[prec])
+    ref = attention_ref(qkv, B, T, heads)
+    assert torch.isfinite(got).all()
+    tol = {"bf16": 2e-2, "fp16": 3e-3}[prec]      # q, k, v and P are rounded to the operand type; an LN rounding flip moves a logit
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+    assert err <= tol * scale, f"{prec} {(B, T, D)}: err {err:.3e} vs scale {scale:.3e}"
+    if ra > M:                                             # padding rows untouched
+        assert not from_blocked(out.cpu(), ra, D, ra)[M:].any()
+
+
+def test_qkv_attn_fused_argument_checks(hip_lib, dev):
+    z = torch.zeros(1 << 16, dtype=torch.bfloat16, device=dev)
+    f = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
+    call = lambda prec, b, t, d, ra: hip_lib.effocr_op_qkv_attn_blocked(prec, _lib.ptr(f), _lib.ptr(f), _lib.ptr(f), 1e-6, _lib.ptr(z), _lib.ptr(f),
+                                                                        _lib.ptr(z), b, t, d, ra, _stream(dev))
+    assert call(0, 1, 100, 128, 128) == -2        # 65..192 tokens: no kernel
+    assert call(0, 1, 50, 256, 128) == -2         # embed dim
+    assert call(2, 1, 50, 128, 128) == -2         # fp32
+    assert call(0, 2, 50, 128, 64) == -1          # rows_alloc < batch * tokens
+    assert call(0, 0, 50, 128, 0) == 0
+    assert hip_lib.effocr_op_qkv_attn_blocked(0, None, _lib.ptr(f), _lib.ptr(f), 1e-6, _lib.ptr(z), _lib.ptr(f), _lib.ptr(z), 1, 50, 128, 128, None) == -1
