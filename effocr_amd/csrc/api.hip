@@ -381,7 +381,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
   const bool projf = mlpf && !rl && e->use_projf;
-  const bool qaf = blk && panel && !rl && e->use_qkvattn && qkv_attn_supported(prec, D, T);
+  const bool qaf = blk && panel && !rl && mlpf && e->use_qkvattn && qkv_attn_supported(prec, D, T);
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
@@ -389,6 +389,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
   g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn; g.blk_out = blk;
   if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return g2p ? gemm2_nt(prec, EPI_PATCH, g, s) : gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
+  bool xn_ready = false;                               // xn holds norm1(x) of the coming block (written by the previous block's MLP epilogue)
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
     if (panel) {
@@ -404,9 +405,11 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         if ((rc = timed(e, "rowlin_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return rowlin(prec, ROWLIN_RESID, q, s); }))) return rc;
       } else {
       PanelArgs p{};
-      if (qaf) {                                         // norm1 + qkv + attention in one kernel, one workgroup per image
+      if (qaf) {                                         // qkv + attention in one kernel, one image per workgroup at a time
+        if (!xn_ready && (rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
+        xn_ready = false;
         QkvAttnArgs q{};
-        q.x = xs; q.gamma = F(L.ln1w); q.beta = F(L.ln1b); q.eps = 1e-6f; q.Wb = wb + L.qkvw_b; q.bias = F(L.qkvb); q.out = att;
+        q.xn = xn; q.Wb = wb + L.qkvw_b; q.bias = F(L.qkvb); q.out = att;
         q.B = B; q.T = T; q.D = D; q.rows_alloc = (int64_t)w.rows;
         if ((rc = timed(e, "qkv_attn_fused", 2.0 * Md * 3.0 * Dd * Dd + 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return qkv_attn_fused(prec, q, s); }))) return rc;
       } else {
@@ -430,8 +433,16 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split;   // the hidden buffer is free on this path
         if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
           m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p); m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b);
+          if (qaf && i + 1 < e->vit.depth) {
+            m.xn_out = xn; m.gamma_n = F(e->layers[i + 1].ln1w); m.beta_n = F(e->layers[i + 1].ln1b);
+            xn_ready = true;
+          }
           if ((rc = timed(e, "proj_mlp_fused", 4.0 * Md * Hd * Dd + 2.0 * Md * Dd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
           continue;
+        }
+        if (qaf && i + 1 < e->vit.depth) {               // second output: the next block's norm1(x), consumed by its qkv+attention kernel
+          m.xn_out = xn; m.gamma_n = F(e->layers[i + 1].ln1w); m.beta_n = F(e->layers[i + 1].ln1b);
+          xn_ready = true;
         }
         if ((rc = timed(e, "mlp_fused", 4.0 * Md * Hd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
         continue;
@@ -825,6 +836,19 @@ int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_de
   return mlp_fused(precision, a, S(stream));
 }
 
+int effocr_op_mlp_ln_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                             const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                             const float* gamma_next_dev, const float* beta_next_dev, void* xn_blk_dev,
+                             int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream) {
+  if (m > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_dev || !gamma_next_dev || !beta_next_dev || !xn_blk_dev))
+    return fail(EFFOCR_EINVAL, "op_mlp_ln_blocked: NULL device pointer");
+  MlpArgs a{};
+  a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_dev;
+  a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
+  a.xn_out = xn_blk_dev; a.gamma_n = gamma_next_dev; a.beta_n = beta_next_dev;
+  return mlp_fused(precision, a, S(stream));
+}
+
 int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_blk_dev, const void* wp_perm_dev, const float* bp_perm_dev,
                                const float* gamma_dev, const float* beta_dev, float eps, const void* w1_blk_dev, const float* b1_dev,
                                const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev, int m, int d, int h, int rows_alloc,
@@ -850,14 +874,13 @@ int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const vo
   return rowlin(precision, mode, q, S(stream));
 }
 
-int effocr_op_qkv_attn_blocked(int precision, const float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                               const void* wqkv_blk_dev, const float* bias_dev, void* out_blk_dev, int batch, int tokens, int d,
-                               int rows_alloc, void* stream) {
-  if (batch > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !wqkv_blk_dev || !bias_dev || !out_blk_dev))
+int effocr_op_qkv_attn_blocked(int precision, const void* xn_blk_dev, const void* wqkv_blk_dev, const float* bias_dev,
+                               void* out_blk_dev, int batch, int tokens, int d, int rows_alloc, void* stream) {
+  if (batch > 0 && (!xn_blk_dev || !wqkv_blk_dev || !bias_dev || !out_blk_dev))
     return fail(EFFOCR_EINVAL, "op_qkv_attn_blocked: NULL device pointer");
   if (batch < 0 || tokens < 1) return fail(EFFOCR_EINVAL, "op_qkv_attn_blocked: bad batch / tokens");
   QkvAttnArgs q{};
-  q.x = x_blk_dev; q.gamma = gamma_dev; q.beta = beta_dev; q.eps = eps; q.Wb = wqkv_blk_dev; q.bias = bias_dev; q.out = out_blk_dev;
+  q.xn = xn_blk_dev; q.Wb = wqkv_blk_dev; q.bias = bias_dev; q.out = out_blk_dev;
   q.B = batch; q.T = tokens; q.D = d; q.rows_alloc = rows_alloc;
   return qkv_attn_fused(precision, q, S(stream));
 }

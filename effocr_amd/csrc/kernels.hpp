@@ -51,18 +51,20 @@ struct MlpArgs {
   // Wp fragment-blocked with the rows of every 32-row block permuted, bp / b2 permuted alike, W2p additionally row-
   // permuted (put_op_blocked rowperm), and b2_logical is the unpermuted fc2 bias (tail reduction)
   const void* A; const void* Wpp; const float* bp; const float* b2_logical;
+  // optional second output: xn_out (16-bit, fragment-blocked) = LayerNorm(x_new; gamma_n, beta_n) — the NEXT block's
+  // norm1, computed in the epilogue where a lane pair holds the whole new row (feeds qkvattn.hip)
+  void* xn_out; const float* gamma_n; const float* beta_n;
 };
 bool mlp_fused_supported(int prec, int D, int H);
 int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);
 
 // qkvattn.hip — fused norm1 + attn.qkv + softmax(q k^T / 8) v per image (the qkv tensor never exists in HBM)
 struct QkvAttnArgs {
-  const float* x;                   // fp32 residual stream, fragment-blocked [rows_alloc, D]
-  const float* gamma; const float* beta; float eps;   // norm1
+  const void* xn;                   // norm1(x), 16-bit fragment-blocked [rows_alloc, D]
   const void* Wb; const float* bias;   // attn.qkv weight [3D, D] fragment-blocked, bias [3D]
   void* out;                        // attention output, 16-bit fragment-blocked [rows_alloc, D] (feature = head * 64 + dim)
   int B, T, D;                      // images, tokens per image, embed dim (heads = D / 64)
-  int64_t rows_alloc;               // rows addressable in x / out (multiple of 32, >= B * T)
+  int64_t rows_alloc;               // rows addressable in xn / out (multiple of 32, >= B * T)
 };
 bool qkv_attn_supported(int prec, int D, int T);
 int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s);

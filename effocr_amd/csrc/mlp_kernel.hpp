@@ -76,13 +76,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   static_assert(D % 128 == 0 && H % 128 == 0 && (H / 128) % NCW == 0, "mlp: D and H must be multiples of 128");
   constexpr int NXF = D / 16;                            // xn B-operand fragments per lane (one per k16 step)
   constexpr int R = MLP_RING;
-  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 4 * D) * 4];
+  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 6 * D) * 4];
   char* sW = smem;
   float* sB1 = reinterpret_cast<float*>(smem + R * MLP_STAGE);
   float* sB2 = sB1 + H;
   float* sG = sB2 + D;                                   // norm2 weight / bias: LDS reads do not queue behind the ring's DMAs
   float* sBt = sG + D;
   float* sBp = sBt + D;                                  // proj bias (row-permuted like its weight)
+  float* sGn = sBp + D;                                  // next block's norm1 weight / bias (second output)
+  float* sBn = sGn + D;
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
@@ -119,6 +121,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   }
   for (int n = tid; n < H; n += 256) sB1[n] = a.b1[n];
   for (int n = tid; n < D; n += 256) { sB2[n] = a.b2[n]; sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; if constexpr (PROJ) sBp[n] = a.bp[n]; }
+  if constexpr (!PARTIAL) {
+    if (a.xn_out) for (int n = tid; n < D; n += 256) { sGn[n] = a.gamma_n[n]; sBn[n] = a.beta_n[n]; }
+  }
   __syncthreads();                                       // parameters visible (and x has landed) before the ring starts filling
 
   // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
@@ -437,6 +442,50 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
+  } else if (a.xn_out && rb * 32 + r31 < a.M) {
+    // ---- epilogue with the second output.  The lane pair (r31, half 0 / 1) holds the whole new row: pass 1 stores it
+    // and parks it in the accumulators, then two-pass statistics (one cross-half exchange each) and the next
+    // block's norm1 applied on the way out, rounded to the operand type (same arithmetic as layernorm_blocked_kernel)
+    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
+    float sm = 0.f;
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      f32x4 rv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)cq(t, q) * 512);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + t * 32 + 8 * q + 4 * half);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = acc2[t][4 * q + e] + bv[e] + rv[q][e]; acc2[t][4 * q + e] = o[e]; }
+        sm += (o[0] + o[1]) + (o[2] + o[3]);
+        *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
+      }
+    });
+    sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm * (1.0f / D);
+    float ss = 0.f;
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = acc2[t][r] - mean; ss += d * d; }
+    });
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+    char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = cq(t, q);                          // fp32 chunk of the row = features 4c..4c+3 = half (c & 1) of 16-bit chunk c >> 1
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+        *reinterpret_cast<u32x2*>(nr + (size_t)(c >> 1) * 512 + (c & 1) * 8) =
+            pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
+                     (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
+      }
+    });
   } else if (rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
     sfor<0, OT>([&](auto T_) {
@@ -526,7 +575,13 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
     const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical ? a.b2_logical : a.b2,
                        (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M);
-    return check_launch("mlp_reduce");
+    rc = check_launch("mlp_reduce");
+    if (rc || !a.xn_out) return rc;
+    // second output for the split panels: the blocked LayerNorm kernel over their rows (a few thousand)
+    const int64_t rb0 = (int64_t)main_panels * 4;
+    return layernorm_rows_blocked(sizeof(E) == 2 && std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16,
+                                  reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + rb0 * (a.D / 4) * 512), (int64_t)a.M - rb0 * 32, a.D,
+                                  a.gamma_n, a.beta_n, a.eps, static_cast<char*>(a.xn_out) + rb0 * (a.D / 8) * 512, s);
   }
   return EFFOCR_OK;
 }

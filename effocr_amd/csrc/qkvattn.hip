@@ -1,17 +1,16 @@
-// Fused norm1 + attn.qkv + multi-head self-attention of one timm ViT block (bf16 / f16 operands, gfx950):
-//     att = softmax(q k^T / 8) v   with   [q | k | v] = LayerNorm(x) . Wqkv^T + b          (head_dim 64)
+// Fused attn.qkv + multi-head self-attention of one timm ViT block (bf16 / f16 operands, gfx950):
+//     att = softmax(q k^T / 8) v   with   [q | k | v] = xn . Wqkv^T + b,   xn = norm1(x) (16-bit)     (head_dim 64)
 // (timm Block: attn(norm1(x)) up to, not including, attn.proj; call site models/encoders.py:58,63 via
 // infer_effocr.py:314).  The qkv tensor [tokens, 3*D] never exists in HBM: per ViT-S block and 1024 crops that
 // removes 465 MB written + 482 MB read, and the separate LN1+qkv and attention launches (round 1: 3.48 + 1.91 ms
-// of a 15.4 ms forward) become one kernel that reads x once (fp32, 310 MB) and writes the attention output
-// (16-bit, 155 MB).
+// of a 15.4 ms forward) become one kernel that reads the normalised rows once (16-bit, 155 MB; written by the
+// previous block's fused MLP kernel in its epilogue, mlp_kernel.hpp) and writes the attention output (155 MB).
 //
-// One workgroup = ONE IMAGE (T <= 224 tokens) = 4 waves, one per SIMD (512-register regime of mlp_kernel.hpp /
-// gemm3.hip); wave w owns token tiles 2w and 2w+1 (32 tokens each; tile 7 of a 197-token image does not exist,
-// wave 3 runs one tile).  Everything a wave needs of its own tokens stays in its registers for the whole kernel:
-//   prologue   LayerNorm of the wave's rows, two lanes per row; lane (row, half) loads exactly the fp32 chunks that
-//              make up ITS MFMA operand fragments (k chunks 2t+half): the normalised rows exist only as D/16
-//              fragments per tile (96 VGPRs per tile at D = 384), no LDS panel.
+// One workgroup = ONE IMAGE (T <= 224 tokens) at a time = 4 waves, one per SIMD (512-register regime of
+// mlp_kernel.hpp / gemm3.hip); wave w owns token tiles 2w and 2w+1 (32 tokens each; tile 7 of a 197-token image is
+// a dummy).  Everything a wave needs of its own tokens stays in its registers for the whole image:
+//   prologue   lane (row, half) loads exactly the 16-byte chunks 2t+half of its row = ITS MFMA operand fragments:
+//              the rows exist only as D/16 fragments per tile (96 registers per tile at D = 384), no LDS panel.
 //   per head h (loop, rolled):
 //     projection  q^T, k^T (SWAPPED: rows = features, cols = tokens) and v (NOT swapped: rows = tokens, cols =
 //                 features) of the wave's tiles for head h: 6 feature tiles x D/16 k-steps x tiles MFMAs.  The
@@ -32,10 +31,23 @@
 //     attention   per query tile: S^T tiles (keys x queries) so that a lane holds one query's whole score row
 //                 (<= 112 registers): row max / sum lane-local + one cross-half exchange, no online rescale;
 //                 P tile by tile into O^T = V^T P^T; 16-bit output rows stored fragment-blocked.
+// Workgroups are persistent (grid = min(images, CUs)); the rows of the NEXT image are requested right after the
+// last head's projection (the fragments are dead from there on), so they land under that head's attention.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <math.h>
 #include <type_traits>
+
+#ifndef EFFOCR_EXP
+#define EFFOCR_EXP 0
+#endif
+// timing experiments (never shipped): -DEFFOCR_EXP=3000+bits; 1 no attention, 2 no projection MFMAs, 4 no x loads,
+// 8 no stage barrier, 16 no output stores, 32 no accumulator -> fragment conversion
+#if EFFOCR_EXP >= 3000 && EFFOCR_EXP < 4000
+#define QAX (EFFOCR_EXP - 3000)
+#else
+#define QAX 0
+#endif
 
 namespace effocr {
 namespace {
@@ -46,6 +58,13 @@ template <int I, int N, typename F> __device__ __forceinline__ void qa_for(F&& f
     qa_for<I + 1, N>(f);
   }
 }
+
+#if (QAX & 64)
+__device__ unsigned long long qa_timeline[1024 * 32];    // [workgroup][stamp]: s_memtime of wave 0 (experiments only)
+#define QA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) qa_timeline[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QA_STAMP(i) do {} while (0)
+#endif
 
 constexpr int QA_STAGE = 16384;                          // bytes per ring stage: 2 row blocks x 16 k-chunks x 512 B
 constexpr int QA_RING = 6;
@@ -62,27 +81,38 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   constexpr int R = QA_RING;
   constexpr bool SMALL = NSH < R - 1;                    // miniature test width: a head is shorter than the prefetch distance
   static_assert(D % 128 == 0 && NS >= R - 1, "qkvattn: embed dim must be a multiple of 128");
-  __shared__ __attribute__((aligned(16))) char smem[R * QA_STAGE + NTT * 8192 + 5 * D * 4];
+  __shared__ __attribute__((aligned(16))) char smem[R * QA_STAGE + NTT * 8192 + 3 * D * 4];
   // K / V and the parameters sit in the first 64 KB so that every access is one base register + a 16-bit immediate
   char* sK = smem;                                       // [key tile][k-step 0..3][lane] 16 B
   char* sV = sK + NTT * 4096;                            // [key tile][m 0..1][dim tile 0..1][lane] 16 B
-  float* sG = reinterpret_cast<float*>(sV + NTT * 4096);
-  float* sBt = sG + D;
-  float* sBias = sBt + D;                                // qkv bias [3*D]
-  char* sW = smem + NTT * 8192 + 5 * D * 4;              // weight ring
+  float* sBias = reinterpret_cast<float*>(sV + NTT * 4096);   // qkv bias [3*D]
+  char* sW = smem + NTT * 8192 + 3 * D * 4;              // weight ring
 
-  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x;
+  // lane-derived values are re-derived behind an opaque asm at the top of every image and every head: otherwise LICM
+  // hoists ~100 registers of loop-invariant per-lane addresses (x chunks, LDS slots, output cells) out of the image /
+  // head loops and the allocator spills the operand fragments instead (1100 dwords of scratch measured)
+  int lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  auto refresh_lane = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane));
+    r31 = lane & 31;
+    half = lane >> 5;
+  };
   const int w = wave_id();
   const int T = a.T;
-  const int64_t tok0 = (int64_t)blockIdx.x * T;          // first token of this image
+  int64_t tok0 = 0;                                      // first token of the current image
+  // Workgroups are persistent (grid = min(images, CUs)): image blockIdx.x, + gridDim.x, ...  The weight stream of an
+  // image is cyclic over the heads, and workgroup b starts its cycle at head h0(b): co-resident workgroups then read
+  // DIFFERENT parts of Wqkv at any moment (all of them starting at head 0 in lock step serialised on the same L2
+  // channels: the first head's projection took 8x as long as the others), and the ring never drains between images.
+  const int h0 = ((int)blockIdx.x >> 3) % HEADS;         // blocks b, b+8, ... share an XCD (and its L2)
   const char* Wb = static_cast<const char*>(a.Wb);
 
-  for (int n = tid; n < D; n += 256) { sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; }
   for (int n = tid; n < 3 * D; n += 256) sBias[n] = a.bias[n];
 
   // ---- ring: global stage g = (head, q|k|v, k slice).  Wave w copies row block w>>1, k chunks (w&1)*8..+8 of the
   // stage: 4 pieces of 1 KB (two adjacent 512-byte cells each).  (ih, isec, ikt) = the next stage to be issued.
-  int ih = 0, isec = 0, ikt = 0, islot = 0;
+  int ih = h0, isec = 0, ikt = 0, islot = 0;
   auto issue_piece = [&](int p) __attribute__((always_inline)) {
     const int rb = (isec * D + ih * 64) / 32 + (w >> 1);
     const char* src = Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8 + 2 * p) * 512 + lane * 16;
@@ -92,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   };
   auto issue_advance = [&]() __attribute__((always_inline)) {
     islot = islot + 1 == R ? 0 : islot + 1;
-    if (++ikt == KT) { ikt = 0; if (++isec == 3) { isec = 0; ++ih; } }
+    if (++ikt == KT) { ikt = 0; if (++isec == 3) { isec = 0; ih = ih + 1 == HEADS ? 0 : ih + 1; } }
   };
 
   auto run = [&](auto NT_) __attribute__((always_inline)) {
@@ -100,78 +130,38 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     constexpr int NA = NT > 0 ? NT : 1;
     V8 xf[NA][NXF];                                      // LayerNorm(x) operand fragments, resident for the whole kernel
 
-    // ---- input rows first (oldest in the in-order VM queue).  lane = (row r31, half): 16-bit k chunk 2t+half of
-    // its row = fp32 chunks 4t+2half, 4t+2half+1.  Rows past the image's last token re-read the last token
-    // (their keys are masked, their query rows never stored).
-    auto load_rows = [&](int tt, f32x4 (&xv)[2 * NXF]) __attribute__((always_inline)) {
-      int t = (2 * w + tt) * 32 + r31;
-      t = t < T ? t : T - 1;
-      const int64_t tok = tok0 + t;
-      const char* xb = reinterpret_cast<const char*>(a.x) + (tok >> 5) * (int64_t)(D / 4) * 512 + (tok & 31) * 16;
+    // lane = (row r31, half): operand fragment t of its row = 16-byte chunk 2t+half.  Rows past the image's last token
+    // re-read the last token (their keys are masked, their query rows never stored).
+    auto load_frags = [&](int img) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < NXF; ++i) {
-        xv[2 * i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * i + 2 * half) * 512);
-        xv[2 * i + 1] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * i + 2 * half + 1) * 512);
-      }
-    };
-    // LayerNorm in registers: xv (this lane's half of the row, fp32) -> xf[tt][t] = operand fragment of k16 step t
-    auto layernorm_to_xf = [&](int tt, const f32x4 (&xv)[2 * NXF]) __attribute__((always_inline)) {
-      float sm = 0.f;
+      for (int tt = 0; tt < NT; ++tt) {
+        int t = (2 * w + tt) * 32 + r31;
+        t = t < T ? t : T - 1;
+        const int64_t tok = (int64_t)img * T + t;
+        const char* xb = static_cast<const char*>(a.xn) + (tok >> 5) * (int64_t)KC * 512 + (tok & 31) * 16 + half * 512;   // + compile-time offsets only
 #pragma unroll
-      for (int i = 0; i < 2 * NXF; ++i) sm += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
-      sm += __shfl_xor(sm, 32, 64);
-      const float mean = sm * (1.0f / D);
-      float ss = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2 * NXF; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
-      ss += __shfl_xor(ss, 32, 64);
-      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
-#pragma unroll
-      for (int t = 0; t < NXF; ++t) {
-        u32x2 pk[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int c = 4 * t + 2 * half + j;
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(sG + c * 4);
-          const f32x4 bt = *reinterpret_cast<const f32x4*>(sBt + c * 4);
-          const f32x4 v = xv[2 * t + j];
-          pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
-                           (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
+        for (int i = 0; i < NXF; ++i) {
+#if (QAX & 4)
+          xf[tt][i] = V8{(E)(1.f + i), (E)2.f, (E)(3.f * half), (E)4.f, (E)0.f, (E)1.f, (E)0.5f, (E)0.25f};
+          if (a.T < 0)
+#endif
+          xf[tt][i] = *reinterpret_cast<const V8*>(xb + i * 1024);
         }
-        const u32x4 q = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
-        xf[tt][t] = __builtin_bit_cast(V8, q);
       }
     };
-    f32x4 xv0[2 * NXF];
-    if constexpr (NT > 0) load_rows(0, xv0);
-    __syncthreads();                                     // parameters visible before the ring starts filling
-#pragma unroll
-    for (int s0 = 0; s0 < R - 1; ++s0) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) issue_piece(p);
-      issue_advance();
-    }
-    if constexpr (NT > 0) layernorm_to_xf(0, xv0);
-    if constexpr (NT > 1) {                              // (both tiles' raw rows at once would need 384 VGPRs)
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 xv1[2 * NXF];
-      load_rows(1, xv1);
-      layernorm_to_xf(1, xv1);
-    }
-
+    const int nimg = (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // images of this workgroup (>= 1)
+    const int gtotal = nimg * NS;                        // ring stages of this workgroup
     int slot = 0;                                        // ring slot of the stage being consumed
-    int g = 0;                                           // its global index (used by the SMALL path only)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
-    __builtin_amdgcn_s_barrier();                        // ... and everybody's
-    asm volatile("" ::: "memory");
+    int g = 0;                                           // its index in the workgroup's stream (used by the SMALL path only)
 
     const float cexp = 0.125f * 1.44269504088896340736f; // head_dim^-0.5 * log2(e)
 
-    auto head = [&](auto LAST_, int h) __attribute__((always_inline)) {
-      constexpr bool LAST = decltype(LAST_)::value;
+    auto head = [&](auto LAST_, auto PRE_, int h, int hi, int img_next) __attribute__((always_inline)) {
+      constexpr bool LAST = decltype(LAST_)::value;        // last head of the workgroup's last image: the ring runs dry
+      constexpr bool PRE = decltype(PRE_)::value;          // last head of an image that is not the last: request the next image's rows
+      refresh_lane();
       V8 qf[NA][4];                                      // Q^T operand fragments of the wave's tiles (k-step = 16 head dims)
+      V8 f0, f1;                                         // the k-step's two W fragments (row blocks 0 / 1 of the stage)
       qa_for<0, 3>([&](auto SEC_) {
         constexpr int sec = decltype(SEC_)::value;       // 0 q, 1 k, 2 v
         f32x16 acc[NA][2];
@@ -186,8 +176,12 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           constexpr int sl = sec * KT + kt;              // stage within the head
           constexpr int ft = NSH - 1 - sl;               // LAST: stages that follow in the whole stream
           const char* st = sW + slot * QA_STAGE + half * 512 + r31 * 16;
-          V8 f0 = *reinterpret_cast<const V8*>(st);
-          V8 f1 = *reinterpret_cast<const V8*>(st + 16 * 512);
+          const int nslot = slot + 1 == R ? 0 : slot + 1;
+          const char* stn = sW + nslot * QA_STAGE + half * 512 + r31 * 16;
+          if constexpr (sl == 0) {                       // later stages: requested under the previous stage's last MFMAs
+            f0 = *reinterpret_cast<const V8*>(st);
+            f1 = *reinterpret_cast<const V8*>(st + 16 * 512);
+          }
           qa_for<0, 8>([&](auto KS_) {
             constexpr int ks = decltype(KS_)::value;
             if constexpr (ks == 4) {
@@ -197,14 +191,22 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               else if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
               else if constexpr (ft >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((ft < R - 2 ? ft : R - 2) - 1) * 4) : "memory");
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(QAX & 8)
               __builtin_amdgcn_s_barrier();
+#endif
               asm volatile("" ::: "memory");
             }
             V8 n0, n1;
             if constexpr (ks < 7) {
               n0 = *reinterpret_cast<const V8*>(st + (2 * (ks + 1)) * 512);
               n1 = *reinterpret_cast<const V8*>(st + (16 + 2 * (ks + 1)) * 512);
+            } else if constexpr (sl + 1 < NSH) {         // stage g+1 landed for everybody at this stage's barrier
+              n0 = *reinterpret_cast<const V8*>(stn);
+              n1 = *reinterpret_cast<const V8*>(stn + 16 * 512);
             }
+#if (QAX & 2)
+            if (a.T < 0)
+#endif
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
               if constexpr (sec < 2) {                   // q^T, k^T: rows = features, cols = tokens
@@ -216,12 +218,12 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               }
             }
             if constexpr (ks >= 4) {
-              if constexpr (SMALL) { if (g + R - 1 < NS) issue_piece(ks - 4); }
+              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_piece(ks - 4); }
               else if constexpr (!LAST || ft >= R - 1) issue_piece(ks - 4);
             }
-            if constexpr (ks < 7) { f0 = n0; f1 = n1; }
+            if constexpr (ks < 7 || sl + 1 < NSH) { f0 = n0; f1 = n1; }
           });
-          if constexpr (SMALL) { if (g + R - 1 < NS) issue_advance(); }
+          if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_advance(); }
           else if constexpr (!LAST || ft >= R - 1) issue_advance();
           slot = slot + 1 == R ? 0 : slot + 1;
           ++g;
@@ -249,33 +251,50 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
                 p = u32x4{lo[0], lo[1], hi[0], hi[1]};
               }
               if constexpr (sec == 0) qf[tt][2 * i + m] = __builtin_bit_cast(V8, p);
-              else if constexpr (sec == 1) *reinterpret_cast<u32x4*>(sK + ((tile * 4 + 2 * i + m) * 64 + lane) * 16) = p;
-              else *reinterpret_cast<u32x4*>(sV + (((tile * 2 + m) * 2 + i) * 64 + lane) * 16) = p;
+              else if (tile < NTT) {
+                if constexpr (sec == 1) *reinterpret_cast<u32x4*>(sK + ((tile * 4 + 2 * i + m) * 64 + lane) * 16) = p;
+                else *reinterpret_cast<u32x4*>(sV + (((tile * 2 + m) * 2 + i) * 64 + lane) * 16) = p;
+              }
             }
           }
         }
       });
+      if constexpr (PRE) load_frags(img_next);           // the fragments are dead from here on: the loads land under the attention
+      QA_STAMP(1 + 3 * hi);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // K and V of every tile are in LDS
       asm volatile("" ::: "memory");
+      QA_STAMP(2 + 3 * hi);
 
-      // ---- attention of the wave's query tiles against all keys of the image
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
+      // ---- attention of the wave's query tiles against all keys of the image.  K / V fragments are requested one
+      // step ahead by hand (with one wave per SIMD nothing else hides the LDS latency; left to itself the compiler
+      // either serialises read -> wait -> MFMA or hoists every read and spills)
+      const char* kb = sK + lane * 16;
+      const char* vb = sV + lane * 16;
+#if !(QAX & 1)
+      qa_for<0, NT>([&](auto TT_) {
+        constexpr int tt = decltype(TT_)::value;
         __builtin_amdgcn_sched_barrier(0);               // one query tile at a time (two score rows do not fit)
         const int tq = (2 * w + tt) * 32 + r31;
         f32x16 s[NTT];
+        V8 kf[2][4];
 #pragma unroll
-        for (int kt = 0; kt < NTT; ++kt) {
+        for (int ks = 0; ks < 4; ++ks) kf[0][ks] = *reinterpret_cast<const V8*>(kb + ks * 1024);
+        qa_for<0, NTT>([&](auto KT_) {
+          constexpr int kt = decltype(KT_)::value, cur = kt & 1, nxt = cur ^ 1;
+          if constexpr (kt + 1 < NTT) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[nxt][ks] = *reinterpret_cast<const V8*>(kb + ((kt + 1) * 4 + ks) * 1024);
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const V8 kf = *reinterpret_cast<const V8*>(sK + ((kt * 4 + ks) * 64 + lane) * 16);
-            s[kt] = Op16<E>::mfma(kf, qf[tt][ks], s[kt]);
-          }
-          __builtin_amdgcn_sched_barrier(0);             // (all 28 K fragment reads hoisted to the top would cost 112 registers)
-        }
+          for (int ks = 0; ks < 4; ++ks) s[kt] = Op16<E>::mfma(kf[cur][ks], qf[tt][ks], s[kt]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        V8 vf[2][2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) vf[0][db] = *reinterpret_cast<const V8*>(vb + db * 1024);
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NTT; ++kt) {
@@ -296,26 +315,27 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
         float l = 0.f;
         const float mxc = mx * cexp;
+        __builtin_amdgcn_sched_barrier(0);
+        // P = exp2((S - max) * c), 8 keys (one operand fragment) at a time, fed straight into O^T = V^T P^T
+        qa_for<0, 2 * NTT>([&](auto ST_) {
+          constexpr int st = decltype(ST_)::value, kt = st >> 1, m = st & 1, cur = st & 1, nxt = cur ^ 1;
+          if constexpr (st + 1 < 2 * NTT) {
 #pragma unroll
-        for (int kt = 0; kt < NTT; ++kt) {
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            V8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * m + j], cexp, -mxc));
-              l += p;
-              pf[j] = (E)p;
-            }
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-              const V8 vf = *reinterpret_cast<const V8*>(sV + (((kt * 2 + m) * 2 + db) * 64 + lane) * 16);
-              o[db] = Op16<E>::mfma(vf, pf, o[db]);
-            }
+            for (int db = 0; db < 2; ++db) vf[nxt][db] = *reinterpret_cast<const V8*>(vb + ((st + 1) * 2 + db) * 1024);
           }
-          __builtin_amdgcn_sched_barrier(0);             // keep every tile's exp / V reads next to its MFMAs
-        }
+          V8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * m + j], cexp, -mxc));
+            l += p;
+            pf[j] = (E)p;
+          }
+#pragma unroll
+          for (int db = 0; db < 2; ++db) o[db] = Op16<E>::mfma(vf[cur][db], pf, o[db]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
         l += __shfl_xor(l, 32, 64);
+#if !(QAX & 16)
         if (tq < T) {
           const float inv = 1.0f / l;
           char* ob = static_cast<char*>(a.out) + half * 8;
@@ -326,24 +346,60 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               *reinterpret_cast<u32x2*>(ob + blk_off(tok0 + tq, (h * 64 + db * 32 + 8 * q4) / 8, D / 8)) =
                   pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
         }
-      }
+#else
+        if (l == 12345.f && o[0][0] == 1.f && o[1][3] == 2.f) *reinterpret_cast<float*>(a.out) = l;
+#endif
+      });
+#else
+      if (qf[0][0][0] == (E)12345.f && qf[NA - 1][3][1] == (E)7.f) *reinterpret_cast<float*>(a.out) = 1.f;
+#endif
+      QA_STAMP(3 + 3 * hi);
     };
 
+    __syncthreads();                                     // parameters visible before the ring starts filling
+    load_frags((int)blockIdx.x);                         // oldest in the in-order VM queue
+#pragma unroll
+    for (int s0 = 0; s0 < R - 1; ++s0) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) issue_piece(p);
+      issue_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
+    __builtin_amdgcn_s_barrier();                        // ... and everybody's
+    asm volatile("" ::: "memory");
 #pragma unroll 1
-    for (int h = 0; h < HEADS - 1; ++h) head(std::false_type{}, h);
-    head(std::true_type{}, HEADS - 1);
+    for (int ii = 0; ii < nimg; ++ii) {
+      const int img = (int)blockIdx.x + ii * (int)gridDim.x;
+      tok0 = (int64_t)img * T;
+      refresh_lane();
+      QA_STAMP(0);
+#pragma unroll 1
+      for (int i = 0; i < HEADS - 1; ++i) {
+        const int h = h0 + i < HEADS ? h0 + i : h0 + i - HEADS;
+        head(std::false_type{}, std::false_type{}, h, i, 0);
+      }
+      const int hl = h0 == 0 ? HEADS - 1 : h0 - 1;
+      if (ii + 1 < nimg) head(std::false_type{}, std::true_type{}, hl, HEADS - 1, img + (int)gridDim.x);
+      else head(std::true_type{}, std::false_type{}, hl, HEADS - 1, 0);
+    }
   };
 
-  const int nt = 2 * w + 1 < NTT ? 2 : (2 * w < NTT ? 1 : 0);
-  if (nt == 2) run(std::integral_constant<int, 2>{});
-  else if (nt == 1) run(std::integral_constant<int, 1>{});
-  else run(std::integral_constant<int, 0>{});
+  // every wave runs the two-tile code; a tile index >= NTT (wave 3's second tile of a 197-token image) is a dummy:
+  // its rows re-read the last token, it writes neither K / V nor output.  (Separate one- and zero-tile code paths
+  // tripled the kernel and made the register allocator spill the fragments.)
+  run(std::integral_constant<int, 2>{});
 }
 
 template <typename E>
 int launch_qkvattn(const QkvAttnArgs& a, hipStream_t s) {
   const int ntt = (a.T + 31) / 32;
-  const dim3 grid((unsigned)a.B), blk(256);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus = v;
+  }
+  const dim3 grid((unsigned)(a.B < cus ? a.B : cus)), blk(256);   // one persistent workgroup per CU (160 KB of LDS each)
   if (a.D == 384 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7>), grid, blk, 0, s, a);
   else if (a.D == 384 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 2>), grid, blk, 0, s, a);
   else if (a.D == 128 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 7>), grid, blk, 0, s, a);
@@ -365,5 +421,11 @@ int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s) {
   if (a.rows_alloc % 32 || a.rows_alloc < (int64_t)a.B * a.T) return fail(EFFOCR_EINVAL, "qkv_attn_fused: rows_alloc must be a multiple of 32 >= batch * tokens");
   return prec == PREC_BF16 ? launch_qkvattn<__bf16>(a, s) : launch_qkvattn<_Float16>(a, s);
 }
+
+#if (QAX & 64)
+extern "C" int effocr_exp_qa_timeline(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qa_timeline), (size_t)n * 8);
+}
+#endif
 
 }  // namespace effocr

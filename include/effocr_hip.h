@@ -90,7 +90,7 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  * results differ only by operand-rounding noise of the precision mode).  [default]
  *   "use_panel"   [1] row-panel GEMMs with the LayerNorm fused into the panel load; 0: K-streaming GEMMs + LayerNorm kernel
  *   "use_blocked" [1] fragment-blocked activation layout; 0: row-major activations
- *   "use_qkvattn" [1] norm1 + attn.qkv + attention as one kernel per image (ViT-S / 128-wide; no qkv tensor in memory);
+ *   "use_qkvattn" [1] attn.qkv + attention as one kernel per image (ViT-S / 128-wide; no qkv tensor in memory);
  *                     0: row-panel LN1+qkv kernel + attention kernel
  *   "use_mlp"     [1] LN2+fc1+GELU+fc2+residual as one kernel; 0: row-panel fc1 + K-streaming fc2
  *   "use_gemm3"   [1] 128-row wave-tile GEMM over blocked operands (fc2; every ViT-B linear); 0: gemm2 / gemm
@@ -199,6 +199,13 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
                           const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
                           int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* The same kernel with its SECOND output: xn_blk (16-bit blocked [m,d]) = LayerNorm(x_new; gamma_next, beta_next, eps), i.e.
+ * the NEXT block's norm1 applied to the updated residual stream, computed in the epilogue where a lane pair holds the
+ * whole new row (input of effocr_op_qkv_attn_blocked).  Other arguments as effocr_op_mlp_blocked. */
+int effocr_op_mlp_ln_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                             const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                             const float* gamma_next_dev, const float* beta_next_dev, void* xn_blk_dev,
+                             int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream);
 /* attn.proj + residual fused in front of the MLP (everything a timm Block does after attention):
  *   x_blk <- y + fc2(gelu(fc1(LN(y)))),  y = x + a . wp^T + bp.
  * a_blk [m,d] 16-bit blocked (attention output).  Row permutation P32 inside every block of 32 rows / entries:
@@ -220,15 +227,15 @@ int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_bl
 int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const void* a_blk_dev, const float* gamma_dev,
                              const float* beta_dev, float eps, const void* w_blk_dev, const float* bias_dev, void* out_blk_dev,
                              int m, int d, int n, int rows_alloc, void* stream);
-/* norm1 + attn.qkv + multi-head self-attention of one timm Block in ONE kernel, one workgroup per image (timm
- * Attention.forward up to, not including, attn.proj, applied to norm1(x); models/encoders.py:58,63):
+/* attn.qkv + multi-head self-attention of one timm Block in ONE kernel, one image per workgroup at a time (timm
+ * Attention.forward up to, not including, attn.proj; models/encoders.py:58,63):
  *   out_blk (16-bit [batch*tokens, d] blocked, feature = head*64 + dim) = softmax(q k^T / 8) v,
- *   [q | k | v] = LayerNorm(x_blk fp32 [batch*tokens, d] blocked) . wqkv^T + bias   (heads = d / 64)
+ *   [q | k | v] = xn_blk . wqkv^T + bias   (heads = d / 64)
+ * xn_blk: norm1(x), 16-bit blocked [batch*tokens, d] (effocr_op_layernorm_blocked, or the fused MLP kernel's second output);
  * wqkv_blk: attn.qkv.weight [3d, d] 16-bit fragment-blocked.  d in {128, 384}; tokens <= 64 or in 193..224.
  * The qkv tensor never exists in device memory. */
-int effocr_op_qkv_attn_blocked(int precision, const float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                               const void* wqkv_blk_dev, const float* bias_dev, void* out_blk_dev, int batch, int tokens, int d,
-                               int rows_alloc, void* stream);
+int effocr_op_qkv_attn_blocked(int precision, const void* xn_blk_dev, const void* wqkv_blk_dev, const float* bias_dev,
+                               void* out_blk_dev, int batch, int tokens, int d, int rows_alloc, void* stream);
 int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,
                                 const float* beta_dev, float eps, void* out_blk_dev, void* stream);
 
