@@ -34,7 +34,8 @@
 #define EFFOCR_EXP 0
 #endif
 // timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
-// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 no residual loads after the projection
+// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 no residual loads after the projection,
+// 256 no stores of the second output, 512 second output skipped altogether
 #if EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000
 #define MLX (EFFOCR_EXP - 2000)
 #else
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
-  } else if (a.xn_out && rb * 32 + r31 < a.M) {
+  } else if (a.xn_out && !(MLX & 512) && rb * 32 + r31 < a.M) {
     // ---- epilogue with the second output.  The lane pair (r31, half 0 / 1) holds the whole new row: pass 1 stores it
     // and parks it in the accumulators, then two-pass statistics (one cross-half exchange each) and the next
     // block's norm1 applied on the way out, rounded to the operand type (same arithmetic as layernorm_blocked_kernel)
@@ -481,6 +482,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         const int c = cq(t, q);                          // fp32 chunk of the row = features 4c..4c+3 = half (c & 1) of 16-bit chunk c >> 1
         const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
         const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+#if (MLX & 256)
+        if (mean == 12345.f)
+#endif
         *reinterpret_cast<u32x2*>(nr + (size_t)(c >> 1) * 512 + (c & 1) * 8) =
             pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
                      (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);

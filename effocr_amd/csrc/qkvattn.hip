@@ -313,28 +313,45 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         for (int db = 0; db < 2; ++db)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-        float l = 0.f;
+        f32x16 lsum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
+        const V8 ones = {(E)1.f, (E)1.f, (E)1.f, (E)1.f, (E)1.f, (E)1.f, (E)1.f, (E)1.f};
         const float mxc = mx * cexp;
         __builtin_amdgcn_sched_barrier(0);
-        // P = exp2((S - max) * c), 8 keys (one operand fragment) at a time, fed straight into O^T = V^T P^T
+        // P = exp2((S - max) * c), 8 keys (one operand fragment) at a time, into O^T = V^T P^T — software-pipelined by one
+        // step: a region holds the exponentials of step st and the MFMAs of step st-1, which are independent, so the
+        // compiler can put the matrix instructions under the VALU work (with the MFMAs of a step behind ITS OWN
+        // exponentials the in-order wave ran them strictly one after the other)
+        V8 pf[2];
+        auto p_frag = [&](auto ST_) __attribute__((always_inline)) {
+          constexpr int st = decltype(ST_)::value, kt = st >> 1, m = st & 1;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {               // exponent arguments two at a time (v_pk_fma_f32)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 sv = {s[kt][8 * m + j], s[kt][8 * m + j + 1]};
+            const f32x2 av = __builtin_elementwise_fma(sv, f32x2{cexp, cexp}, f32x2{-mxc, -mxc});
+            pf[st & 1][j] = (E)__builtin_amdgcn_exp2f(av[0]);
+            pf[st & 1][j + 1] = (E)__builtin_amdgcn_exp2f(av[1]);
+          }
+        };
+        p_frag(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
         qa_for<0, 2 * NTT>([&](auto ST_) {
-          constexpr int st = decltype(ST_)::value, kt = st >> 1, m = st & 1, cur = st & 1, nxt = cur ^ 1;
+          constexpr int st = decltype(ST_)::value, cur = st & 1, nxt = cur ^ 1;
           if constexpr (st + 1 < 2 * NTT) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) vf[nxt][db] = *reinterpret_cast<const V8*>(vb + ((st + 1) * 2 + db) * 1024);
           }
-          V8 pf;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * m + j], cexp, -mxc));
-            l += p;
-            pf[j] = (E)p;
-          }
-#pragma unroll
-          for (int db = 0; db < 2; ++db) o[db] = Op16<E>::mfma(vf[cur][db], pf, o[db]);
+          for (int db = 0; db < 2; ++db) o[db] = Op16<E>::mfma(vf[cur][db], pf[cur], o[db]);
+          // row sums on the (otherwise idle) matrix pipe: an all-ones A operand makes every row of the tile sum_k P[k][query],
+          // i.e. the softmax denominator of exactly the rounded P that enters the numerator; no per-value adds, no exchange
+          lsum = Op16<E>::mfma(ones, pf[cur], lsum);
+          if constexpr (st + 1 < 2 * NTT) p_frag(std::integral_constant<int, st + 1>{});
           __builtin_amdgcn_sched_barrier(0);
         });
-        l += __shfl_xor(l, 32, 64);
+        const float l = lsum[0];
 #if !(QAX & 16)
         if (tq < T) {
           const float inv = 1.0f / l;
