@@ -4,9 +4,12 @@
 Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON
 line on rank 0.  A *step* is one pass of the hot path over one batch of synthetic crops:
 BASELINE.json configs[1] — ViT-S/16 encoder, bf16 MFMA operands, 1024 x 3x224x224 fp32 crops per GPU
-already resident in HBM, 10,000-row fp32 glyph index, k=10.  For N>1 every rank (one process per
-GPU, launched by torch.distributed.run) processes its own 1024 crops (weak scaling; encoder weights
-and index replicated) and one RCCL all_gather assembles the [N*1024, 10] ids on every rank.
+already resident in HBM, 10,000-row fp32 glyph index, k=10.  For N>1 (one process per GPU; launched by
+torch.distributed.run, or by this script itself when WORLD_SIZE is not set) the default is BASELINE
+configs[2]: the SAME 1024 crops sharded over the ranks (``--scaling strong``: rank r encodes rows
+shard_bounds(1024, r, N), weights and index replicated) and one RCCL all_gather assembles the [1024, 10]
+ids on every rank; the weak-scaling figure (1024 crops per rank) is measured right after and reported
+under "weak".  ``--scaling weak`` makes the weak figure the headline instead.
 
 Extra objects on the line:
   roofline      the dominant kernel class, timed live with HIP events recorded on the launch stream
@@ -15,7 +18,11 @@ Extra objects on the line:
                 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline  rank 0, N=1 only: the CPU restatement of the reference path (oracle/: plain-torch
                 fp32 ViT-S + F.normalize + Q@X^T/top-k, i.e. PyTorch-CPU + IndexFlatIP semantics; timm
-                and faiss cannot be installed offline) on a bounded sample of the same workload.
+                and faiss are tried first and their absence is recorded) on a bounded sample of the same workload.
+  small_batch   N=1: the reference drivers' real call sizes — 64-crop batches device-resident, and through
+                EffRecognizer.run(numpy) (pinned staging + per-call streams; PCIe-inclusive, 1 and 4 caller threads),
+                plus the k-NN alone at B in {1, 16, 64} against a 1M-row index where HBM is the roof.
+  c4            N=1: BASELINE configs[3] — ViT-B/16 + 1M x 768 index: crops/s, per-linear TFLOP/s, k-NN time.
 """
 import argparse
 import json
@@ -60,6 +67,9 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="library option (set_option) for A/B runs, e.g. tail_split=0")
     ap.add_argument("--panel-rows", type=int, default=0, help="row-panel height 64|128 (0 = library default)")
     ap.add_argument("--no-panel", action="store_true", help="A/B: K-streaming GEMM + standalone LayerNorm path")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="N>1: strong = --batch crops in total, sharded (BASELINE configs[2]); weak = --batch crops per rank; auto = strong for N>1")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small_batch and c4 objects (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel-class table to stderr")
@@ -69,6 +79,13 @@ def parse():
 def cpu_baseline(arch, sd, index_cpu, k, target_s):
     """PyTorch-CPU fp32 restatement of the reference path on a bounded sample; returns dict."""
     from oracle.encoders_ref import encoder_forward, l2_normalize
+    probe = []
+    for mod in ("timm", "faiss"):                        # BASELINE.md section 3: use the real libraries when the box has them
+        try:
+            __import__(mod)
+            probe.append(f"{mod} importable (not used: the oracle port is the committed baseline)")
+        except Exception as e:
+            probe.append(f"{mod} absent ({type(e).__name__})")
     ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(1234)
 
@@ -99,7 +116,7 @@ def cpu_baseline(arch, sd, index_cpu, k, target_s):
     return {"value": round(n / t, 2), "unit": "glyph-crops/s", "cores": best_n, "host_logical_cpus": ncpu, "kind": "port",
             "sample": f"{n} of the 1024 crops of one step (same shapes, fp32, torch {torch.__version__} CPU with "
                       f"{best_n} intra-op threads = fastest of the probed pool sizes, oracle/encoders_ref.py + normalize "
-                      f"+ Q@X^T top-{k} over the full {index_cpu.shape[0]}-row index), {t:.1f} s"}
+                      f"+ Q@X^T top-{k} over the full {index_cpu.shape[0]}-row index), {t:.1f} s; " + "; ".join(probe)}
 
 
 def main():
@@ -108,8 +125,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # plain ``python bench.py --gpus N``: become the launcher (one rank per GPU over RCCL)
+            import socket
+            import subprocess
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd))
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
@@ -156,22 +181,43 @@ def main():
     index_cpu = torch.nn.functional.normalize(torch.randn(a.index_rows, D, generator=gi), dim=1)
     knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
     knn.train(index_cpu)
+    from effocr_amd.dist import shard_bounds
+    scaling = a.scaling if a.scaling != "auto" else ("strong" if world > 1 else "weak")
     gx = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(a.batch, 3, 224, 224, generator=gx, device=dev)          # resident in HBM
-    n_total = a.batch * world
+    x_full = torch.randn(a.batch, 3, 224, 224, generator=gx, device=dev)     # resident in HBM
+    lo, hi = shard_bounds(a.batch, rank, world)
+    x_shard = x_full[lo:hi]                                                  # strong: this rank's slice of the 1024 crops
 
-    def step():
-        emb = enc.forward(x, normalize=True)
-        d, i = knn(emb, k=a.k)
-        if world > 1:
-            i = all_gather_rows(i, n_total)
-        return i
+    def make_step(x, n_total):
+        def step():
+            emb = enc.forward(x, normalize=True)
+            d, i = knn(emb, k=a.k)
+            if world > 1:
+                i = all_gather_rows(i, n_total)
+            return i
+        return step
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(step, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), out
+
+    if scaling == "strong":
+        step, n_total = make_step(x_shard, a.batch), a.batch
+    else:
+        step, n_total = make_step(x_full, a.batch * world), a.batch * world
     for _ in range(a.warmup):
         step()
     # pick the dominant kernel class with one fully-profiled step (untimed)
@@ -190,33 +236,38 @@ def main():
     # carries event pairs (2 events per launch of that class), everything else runs untouched
     if dom:
         enc.profile_begin(only=dom)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, out = timed(step, a.steps)
     prof = enc.profile_collect() if dom else {}
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
     assert tuple(out.shape) == (n_total, a.k)
+    other = None
+    if world > 1:                                          # the other scaling mode, same run, reported as an extra key
+        if scaling == "strong":
+            ostep, on = make_step(x_full, a.batch * world), a.batch * world
+        else:
+            ostep, on = make_step(x_shard, a.batch), a.batch
+        for _ in range(max(1, a.warmup)):
+            ostep()
+        odt, _ = timed(ostep, a.steps)
+        other = {"scaling": "weak" if scaling == "strong" else "strong", "value": round(on * a.steps / odt, 1), "unit": "glyph-crops/s",
+                 "ms_per_step": round(1e3 * odt / a.steps, 3), "global_batch": on}
 
     if rank == 0:
         value = n_total * a.steps / dt
+        per_rank = f"{hi - lo} of {a.batch} crops per GPU (rows shard_bounds(B, rank, N))" if scaling == "strong" else f"{a.batch} crops per GPU"
         line = {
             "metric": "glyph-crops/sec end-to-end (encode+kNN), 224x224 bs=1024",
             "value": round(value, 1), "unit": "glyph-crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {a.arch} encoder ({a.precision} MFMA operands, fp32 accumulate/"
-                                   f"residual/LN/softmax), {a.batch}x3x224x224 fp32 crops per GPU resident in HBM, "
+            "config": {"workload": f"BASELINE configs[{2 if (world > 1 and scaling == 'strong') else 1}]: {a.arch} encoder ({a.precision} MFMA operands, fp32 accumulate/"
+                                   f"residual/LN/softmax), {a.batch}x3x224x224 fp32 crops {'in total' if scaling == 'strong' else 'per GPU'} resident in HBM, "
                                    f"{a.index_rows}-row fp32 IndexFlatIP, k={a.k}; seeded random-init weights",
-                       "crops_per_gpu": a.batch, "global_batch": n_total, "index_rows": a.index_rows, "k": a.k,
-                       "parallelism": f"crops sharded over {world} GPU(s), weights+index replicated"
+                       "crops_per_gpu": (hi - lo) if scaling == "strong" else a.batch, "global_batch": n_total, "index_rows": a.index_rows, "k": a.k,
+                       "parallelism": f"{per_rank}, weights+index replicated"
                                       + (", all_gather(ids) over RCCL" if world > 1 else "")},
         }
+        if other:
+            line[other["scaling"]] = other
         if dom and dom in prof and prof[dom]["launches"]:
             p = prof[dom]
             sec = p["ms"] * 1e-3 / p["launches"]
@@ -225,15 +276,121 @@ def main():
             line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(fl / sec / 1e12, 2),
                                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(fl / sec / peak, 4),
                                 "flops_per_launch": fl, "avg_launch_us": round(sec * 1e6, 2), "launches": p["launches"],
-                                "traffic": measured_traffic(dom) if (a.arch == "vit_small_patch16_224" and a.batch == 1024) else None}
+                                "traffic": measured_traffic(dom) if (a.arch == "vit_small_patch16_224" and a.batch == 1024 and world == 1) else None}
         if a.arch in FLOP_PER_CROP:
             line["encoder_mfma_frac_end_to_end"] = round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)
+        if world == 1 and not a.no_extras:
+            try:
+                line["small_batch"] = small_batch_extras(a, enc, knn, sd, dev)
+                if a.arch == "vit_small_patch16_224":
+                    del enc, x_full, x_shard
+                    torch.cuda.empty_cache()
+                    line["c4"] = c4_extras(a, dev)
+            except Exception as e:                          # extras never take the headline down
+                line["extras_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch, sd, index_cpu, a.k, a.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _time_gpu(fn, dev, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / iters
+
+
+def small_batch_extras(a, enc, knn, sd, dev):
+    """The reference drivers' own call sizes (infer_effocr.py:313: one text line, tens of crops; infer_effocr_onnx_multi.py:157:
+    literal 64) and the k-NN in the regime where HBM is the roof (B <= 16 against a large index)."""
+    import threading
+    import numpy as np
+    from effocr_amd.knn import IndexFlatIP
+    from effocr_amd.recognizer_engine import EffRecognizer
+    out = {}
+    x64 = torch.randn(64, 3, 224, 224, device=dev)
+    t = _time_gpu(lambda: knn(enc.forward(x64, normalize=True), k=a.k), dev, 30)
+    out["b64_device_resident"] = {"crops_per_s": round(64 / t, 1), "ms_per_call": round(1e3 * t, 3)}
+    eng = EffRecognizer(sd, arch=a.arch, precision=a.precision, device=dev, lanes=2)
+    batch = np.random.default_rng(0).standard_normal((64, 3, 224, 224), dtype=np.float32)
+    eng.run(batch)
+    n_calls = 24
+    t0 = time.perf_counter()
+    for _ in range(n_calls):
+        eng.run(batch)
+    t1 = time.perf_counter() - t0
+
+    def worker(n):
+        for _ in range(n):
+            eng.run(batch)
+    ths = [threading.Thread(target=worker, args=(n_calls // 4,)) for _ in range(4)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    t4 = time.perf_counter() - t0
+    out["b64_effrecognizer_run_numpy"] = {"crops_per_s_1_thread": round(64 * n_calls / t1, 1), "crops_per_s_4_threads": round(64 * n_calls / t4, 1),
+                                          "note": "pageable numpy in / numpy out per call: 38.5 MB host->pinned->device + D2H, PCIe-inclusive; never the headline value"}
+    del eng
+    # k-NN alone, HBM-bound regime: 1M x D fp32 index (1.5 GB at D=384), exact kernel and the screened path
+    D = enc.embed_dim
+    N = 1_000_000
+    idx = IndexFlatIP(D, device=dev, screen=False)
+    g = torch.Generator(device=dev).manual_seed(7)
+    xb = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    idx.add(xb)
+    idx_s = IndexFlatIP(D, device=dev, screen=True)
+    idx_s._xb = idx._xb
+    rows = {}
+    for B in (1, 16, 64, 1024):
+        q = torch.nn.functional.normalize(xb[:B] + 0.1 * torch.randn(B, D, generator=g, device=dev), dim=1)
+        te = _time_gpu(lambda: idx.search_device(q, a.k), dev, 10)
+        ts = _time_gpu(lambda: idx_s.search_device(q, a.k), dev, 10)
+        by = N * D * 4.0
+        rows[f"B{B}"] = {"exact_ms": round(1e3 * te, 3), "exact_hbm_frac": round(by / te / 8.0e12, 4),
+                         "exact_mfma_fp32_frac": round(2.0 * B * N * D / te / 157.3e12, 4),
+                         "screened_ms": round(1e3 * ts, 3), "screened_hbm_frac_bf16_two_passes": round(2 * N * D * 2.0 / ts / 8.0e12, 4)}
+    out["knn_1M_rows"] = {"index": f"{N} x {D} fp32 ({N * D * 4 / 1e9:.2f} GB)", "k": a.k, "hbm_peak_GBps": 8000, **rows}
+    return out
+
+
+def c4_extras(a, dev):
+    """BASELINE configs[3]: ViT-B/16 encoder + 1M x 768 glyph index on one GPU."""
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import FaissKNN, IndexFlatIP
+    from effocr_amd.weights import init_state_dict
+    arch = "vit_base_patch16_224"
+    enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=224), img_size=224, precision=a.precision, device=dev)
+    N, D = 1_000_000, 768
+    g = torch.Generator(device=dev).manual_seed(11)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.index = IndexFlatIP(D, device=dev)
+    for _ in range(4):                                     # 4 x 250k rows: bounded transient memory
+        knn.index.add(torch.nn.functional.normalize(torch.randn(N // 4, D, generator=g, device=dev), dim=1))
+    x = torch.randn(1024, 3, 224, 224, generator=g, device=dev)
+    step = lambda: knn(enc.forward(x, normalize=True), k=a.k)
+    for _ in range(2):
+        step()
+    enc.profile_begin()
+    emb = enc.forward(x, normalize=True)
+    table = enc.profile_collect()
+    t = _time_gpu(step, dev, 5, warm=0)
+    tk = _time_gpu(lambda: knn(emb, k=a.k), dev, 5, warm=1)
+    te = t - tk
+    lin = {n: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for n, v in table.items() if v["flops"] > 0 and v["ms"] > 0}
+    return {"workload": f"BASELINE configs[3]: {arch} ({a.precision}), 1024x3x224x224 crops resident in HBM, {N}x{D} fp32 IndexFlatIP (screened search), k={a.k}",
+            "value": round(1024 / t, 1), "unit": "glyph-crops/s", "ms_per_step": round(1e3 * t, 3),
+            "encoder_ms": round(1e3 * te, 3), "encoder_mfma_frac": round(1024 * FLOP_PER_CROP[arch] / te / MFMA_PEAK[a.precision], 4),
+            "kernel_TFLOPs": lin, "knn_ms": round(1e3 * tk, 3),
+            "knn_hbm_frac_bf16_two_passes": round(2 * N * D * 2.0 / tk / 8.0e12, 4), "knn_mfma_bf16_frac": round(2 * 2.0 * 1024 * N * D / tk / 2.5e15, 4)}
 
 
 if __name__ == "__main__":

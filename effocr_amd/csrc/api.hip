@@ -381,7 +381,9 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
   const bool projf = mlpf && !rl && e->use_projf;
-  const bool qaf = blk && panel && !rl && mlpf && e->use_qkvattn && qkv_attn_supported(prec, D, T);
+  // one image per workgroup at a time: worth it from ~3/4 of a round of CUs on; small batches (the reference's 64-crop calls)
+  // keep the token-panel kernels, which spread 64 x 197 tokens over every CU.  use_qkvattn = 2 forces it (tests).
+  const bool qaf = blk && panel && !rl && mlpf && qkv_attn_supported(prec, D, T) && (e->use_qkvattn == 2 || (e->use_qkvattn == 1 && B >= 192));
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
@@ -750,6 +752,8 @@ int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void
 }
 
 size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k) { return knn_screen_workspace_bytes(nq, ntotal, d, k); }
+
+size_t effocr_knn_screen_flag_offset(int64_t nq, int64_t ntotal, int d, int k) { return knn_screen_flag_offset(nq, ntotal, d, k); }
 
 int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, int64_t ntotal, int d, int k,
                                 float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {

@@ -479,6 +479,10 @@ size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B <= 0 || k <= 0) return 0;
   return screen_ws(B, N, D, k).total;
 }
+size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k) {
+  if (B <= 0 || k <= 0) return 0;
+  return screen_ws(B, N, D, k).flag;
+}
 
 int convert_bf16(const float* src, int64_t n, void* dst, hipStream_t s) {
   if (n <= 0) return EFFOCR_OK;

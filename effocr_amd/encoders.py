@@ -22,7 +22,8 @@ from . import weights as W
 
 
 class HipEncoder:
-    """Device-resident encoder: C-ABI handle + weight blob + grow-only workspace."""
+    """Device-resident encoder: C-ABI handle + weight blob + one grow-only workspace PER HIP STREAM (the Python lock
+    covers only the enqueue; two threads forwarding on different streams must not share activation buffers)."""
 
     def __init__(self, arch, state_dict, img_size=224, precision="bf16", device="cuda:0"):
         if precision not in _lib.PREC:
@@ -46,7 +47,7 @@ class HipEncoder:
         with torch.cuda.device(self.device):
             self._wblob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self._L.effocr_encoder_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_encoder_upload")
-        self._ws = None
+        self._ws = {}
 
     def __del__(self):
         try:
@@ -59,11 +60,11 @@ class HipEncoder:
     def set_chunk(self, crops_per_chunk):
         """Internal sub-batch size of the ViT forward (0 = whole batch); see effocr_encoder_set_chunk."""
         _lib.check(self._L.effocr_encoder_set_chunk(self._h, int(crops_per_chunk)), "effocr_encoder_set_chunk")
-        self._ws = None
+        self._ws = {}
 
     def set_option(self, name, value):
         _lib.check(self._L.effocr_encoder_set_option(self._h, name.encode(), int(value)), "effocr_encoder_set_option")
-        self._ws = None
+        self._ws = {}
 
     def workspace_bytes(self, batch):
         return int(self._L.effocr_encoder_workspace_bytes(self._h, int(batch)))
@@ -85,11 +86,14 @@ class HipEncoder:
             return emb
         need = self.workspace_bytes(B)
         with self._lock, torch.cuda.device(self.device):
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = None
-                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            key = torch.cuda.current_stream(self.device).cuda_stream
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need:
+                self._ws.pop(key, None)
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._ws[key] = ws
             _lib.check(self._L.effocr_encoder_forward(self._h, _lib.ptr(x), B, _lib.ptr(emb), 1 if normalize else 0,
-                                                      _lib.ptr(self._ws), self._ws.numel(),
+                                                      _lib.ptr(ws), ws.numel(),
                                                       _lib.current_stream(self.device)), "effocr_encoder_forward")
         return emb
 

@@ -39,8 +39,10 @@ class IndexFlatIP:
         self.device = _lib.require_gpu(device)
         self._L = _lib.lib()
         self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
-        self._ws = None
+        self._ws = {}                            # scratch per HIP stream: calls on different streams never share partial lists
         self.screen = screen                     # "auto" | True | False
+        self.screen_overflows = 0                # screened searches that had to re-run exactly (candidate cap exceeded)
+        self._flag_pending = None                # (pinned host copy of the device overflow flag, event) of the last screened call
         self._xb16 = None                        # bf16 copy of the rows + max row norm, built lazily for the screening pass
         self._xnorm_max = 0.0
 
@@ -65,6 +67,31 @@ class IndexFlatIP:
     def reset(self):
         self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
         self._xb16 = None
+
+    SCREEN_MAX_OVERFLOWS = 3   # after this many overflowing calls screening is switched off for this index
+
+    def _workspace(self, need):
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _poll_overflow(self):
+        """Non-blocking look at the previous screened call's device flag: an index full of near-duplicate rows (one
+        glyph in many fonts) can exceed the 512-candidate cap, in which case that call ALSO ran the exact pass; after
+        SCREEN_MAX_OVERFLOWS such calls the index stops screening (results are identical either way)."""
+        if self._flag_pending is None:
+            return
+        host, ev = self._flag_pending
+        if not ev.query():
+            return
+        self._flag_pending = None
+        if int(host.item()) != 0:
+            self.screen_overflows += 1
+            if self.screen == "auto" and self.screen_overflows >= self.SCREEN_MAX_OVERFLOWS:
+                self.screen = False
 
     def _use_screen(self, k):
         if self.screen is False or self.d % 64 != 0 or k > 32 or self.ntotal < max(k, 1):
@@ -113,22 +140,28 @@ class IndexFlatIP:
         I = torch.empty((n, k), dtype=torch.int64, device=self.device)
         if n == 0:
             return D, I
+        self._poll_overflow()
         if self._use_screen(k):
             xb16 = self._screen_copy()
             need = int(self._L.effocr_knn_screen_workspace_bytes(n, self.ntotal, self.d, k))
             with torch.cuda.device(self.device):
-                if self._ws is None or self._ws.numel() < need:
-                    self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+                ws = self._workspace(need)
                 _lib.check(self._L.effocr_knn_ip_topk_screened(_lib.ptr(q), n, _lib.ptr(self._xb), _lib.ptr(xb16), self.ntotal, self.d, k,
-                                                               self._xnorm_max, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws),
-                                                               self._ws.numel(), _lib.current_stream(self.device)), "effocr_knn_ip_topk_screened")
+                                                               self._xnorm_max, _lib.ptr(D), _lib.ptr(I), _lib.ptr(ws),
+                                                               ws.numel(), _lib.current_stream(self.device)), "effocr_knn_ip_topk_screened")
+                if self._flag_pending is None:
+                    off = int(self._L.effocr_knn_screen_flag_offset(n, self.ntotal, self.d, k))
+                    host = torch.empty(1, dtype=torch.int32).pin_memory()
+                    host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    self._flag_pending = (host, ev)
             return D, I
         need = int(self._L.effocr_knn_workspace_bytes(n, self.ntotal, self.d, k))
         with torch.cuda.device(self.device):
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            ws = self._workspace(need)
             _lib.check(self._L.effocr_knn_ip_topk(_lib.ptr(q), n, _lib.ptr(self._xb), self.ntotal, self.d, k,
-                                                  _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(),
+                                                  _lib.ptr(D), _lib.ptr(I), _lib.ptr(ws), ws.numel(),
                                                   _lib.current_stream(self.device)), "effocr_knn_ip_topk")
         return D, I
 
@@ -155,17 +188,29 @@ def write_index(index, path):
         f.write(xb.tobytes(order="C"))
 
 
-def read_index(path, device="cuda:0"):
+_OTHER_FOURCC = {b"IxF2": "IndexFlatL2", b"IxFl": "legacy IndexFlat", b"IxF1": "IndexFlat1D", b"IwFl": "IndexIVFFlat",
+                 b"IxPq": "IndexPQ", b"IHNf": "IndexHNSWFlat", b"IxMp": "IndexIDMap", b"IxM2": "IndexIDMap2"}
+
+
+def read_index(path, device=None):
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
     with open(path, "rb") as f:
         buf = f.read()
     if buf[:4] != _FOURCC_IP:
-        raise ValueError(f"{path}: not a faiss IndexFlatIP file (fourcc {buf[:4]!r}); only 'IxFI' is supported")
+        kind = _OTHER_FOURCC.get(bytes(buf[:4]))
+        raise ValueError(f"{path}: not a faiss IndexFlatIP file (fourcc {bytes(buf[:4])!r}" + (f" = {kind}" if kind else "") +
+                         "); the reference writes faiss.IndexFlatIP, 'IxFI' (train_effocr_recognizer.py:27,52)")
+    hdr = struct.calcsize("<iqqqBi")
+    if len(buf) < 4 + hdr + 8:
+        raise ValueError(f"{path}: truncated IndexFlatIP header ({len(buf)} bytes)")
     d, ntotal, _, _, _, metric = struct.unpack_from("<iqqqBi", buf, 4)
-    off = 4 + struct.calcsize("<iqqqBi")
+    off = 4 + hdr
     (nfl,) = struct.unpack_from("<Q", buf, off)
     off += 8
-    if metric != 0 or nfl != ntotal * d or len(buf) < off + 4 * nfl:
-        raise ValueError(f"{path}: inconsistent IndexFlatIP header (d={d}, ntotal={ntotal}, metric={metric}, n={nfl})")
+    if d <= 0 or ntotal < 0 or metric != 0 or nfl != ntotal * d or len(buf) < off + 4 * nfl:
+        raise ValueError(f"{path}: inconsistent IndexFlatIP header (d={d}, ntotal={ntotal}, metric={metric}, n={nfl}, "
+                         f"{len(buf) - off} payload bytes)")
     idx = IndexFlatIP(d, device=device)
     if ntotal:
         idx.add(np.frombuffer(buf, dtype="<f4", count=nfl, offset=off).reshape(ntotal, d).copy())
@@ -176,7 +221,11 @@ def read_index(path, device="cuda:0"):
 class FaissKNN:
     """pytorch_metric_learning.utils.inference.FaissKNN call convention on the HIP index."""
 
-    def __init__(self, reset_before=True, reset_after=True, index_init_fn=None, gpus=None, device="cuda:0"):
+    def __init__(self, reset_before=True, reset_after=True, index_init_fn=None, gpus=None, device=None):
+        # device None = the current HIP device (what PML / faiss-gpu do); one process per GPU sets it with
+        # torch.cuda.set_device(local_rank)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
         self.reset_before = reset_before
         self.reset_after = reset_after
         # the reference passes faiss.IndexFlatIP; any callable taking d works, default = ours
@@ -243,7 +292,11 @@ class InferenceModel:
         self.match_finder = match_finder
         self.normalize_embeddings = normalize_embeddings
         self.knn_func = FaissKNN(reset_before=False, reset_after=False) if knn_func is None else knn_func
-        self.data_device = torch.device("cuda:0") if data_device is None else torch.device(data_device)
+        if data_device is None:                  # PML: the current device; here preferably the trunk's own device
+            data_device = getattr(trunk, "_device", None) or getattr(trunk, "device", None)
+            if data_device is None or isinstance(data_device, str) and data_device == "cuda":
+                data_device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
+        self.data_device = torch.device(data_device)
         self.dtype = dtype
 
     def get_embeddings(self, x):

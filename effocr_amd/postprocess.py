@@ -106,9 +106,10 @@ class LinePostprocessor:
 class LineRecognizer:
     """`EffOCR.infer` from the localizer result on (infer_effocr.py:268-343): boxes -> crops (on the device) ->
     recognizer -> strings.  `recognizer` is an `effocr_amd.pipeline.Recognizer`; `double_clipped` crops span the
-    whole line height (or width when vertical) like the reference's flag (:288-292)."""
+    whole line height (or width when vertical): the reference hard-codes ``self.double_clipped = True``
+    (infer_effocr.py:226, applied at :287-291), so that is the default here."""
 
-    def __init__(self, recognizer, post: LinePostprocessor, double_clipped=False, char_transform=None):
+    def __init__(self, recognizer, post: LinePostprocessor, double_clipped=True, char_transform=None):
         self.recognizer, self.post = recognizer, post
         self.double_clipped, self.char_transform = bool(double_clipped), char_transform
 
@@ -135,6 +136,5 @@ class LineRecognizer:
         if post.lang == "en":
             heights = [float(bb[3] - bb[1]) for bb in char_bboxes]
             bottoms = [float(bb[3]) for bb in char_bboxes]
-            first = "".join(x[0] for x in nearest_chars)                     # un-stripped: one character per box
-            output = post.en_postprocess(first if len(first) == len(heights) else output, word_end_idx, heights, bottoms)
+            output = post.en_postprocess(output, word_end_idx, heights, bottoms)   # the stripped string, as infer_effocr.py:338-341
         return output, output_nns, char_bboxes, word_bboxes

@@ -10,6 +10,7 @@ several Python threads sharing one instance (infer_effocr_onnx_multi.py:161-163,
 Here ``model`` is the path of the encoder weights (``enc_best.pth`` state dict with ``net.`` keys, or
 ``.safetensors``) instead of an ``.onnx`` graph; there is no ONNXRuntime and no CPU fallback.
 """
+import queue
 import threading
 
 import numpy as np
@@ -19,10 +20,28 @@ from . import weights as W
 from .encoders import HipEncoder
 
 
+class _Lane:
+    """One in-flight ``run`` call: its own HIP stream and pinned host staging buffers (grown on demand), so that the
+    host->device copy of one call overlaps the kernels of another (the encoder keeps one workspace per stream)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.h_in = None
+        self.h_out = None
+
+    def staging(self, n_in, n_out):
+        if self.h_in is None or self.h_in.numel() < n_in:
+            self.h_in = torch.empty(n_in, dtype=torch.float32).pin_memory()
+        if self.h_out is None or self.h_out.numel() < n_out:
+            self.h_out = torch.empty(n_out, dtype=torch.float32).pin_memory()
+        return self.h_in[:n_in], self.h_out[:n_out]
+
+
 class EffRecognizer:
 
     def __init__(self, model, num_cores=None, providers=None, arch=None, precision="bf16", img_size=224,
-                 device="cuda:0"):
+                 device="cuda:0", lanes=2):
         # num_cores / providers are ORT knobs (recognizer_engine.py:10-15): accepted and ignored.
         self.num_cores, self.providers = num_cores, providers
         if isinstance(model, dict):
@@ -31,7 +50,13 @@ class EffRecognizer:
             sd = W.load_checkpoint(model)
         self.arch = arch or W.infer_arch(sd)
         self._eng_net = HipEncoder(self.arch, sd, img_size=img_size, precision=precision, device=device)
-        self._run_lock = threading.Lock()   # one instance is shared by N threads in the reference
+        # One instance is shared by N Python threads in the reference (infer_effocr_onnx_multi.py:207-223,350-364).
+        # `lanes` calls can be in flight at once; further callers wait for a free lane.  ctypes releases the GIL during
+        # the enqueue and torch releases it during copies / synchronisation, so the threads really overlap:
+        # H2D of call i+1 (pinned, async, own stream) runs under the kernels of call i.
+        self._lanes = queue.SimpleQueue()
+        for _ in range(max(1, int(lanes))):
+            self._lanes.put(_Lane(self._eng_net.device))
 
     def __call__(self, imgs):
         return self.run(imgs)
@@ -47,8 +72,20 @@ class EffRecognizer:
             raise ValueError(f"Unexpected input data type. Actual: {imgs.dtype}, expected: float32")
         if imgs.ndim != 4 or imgs.shape[1] != 3:
             raise ValueError(f"Invalid rank / channels for input: imgs, got shape {imgs.shape}")
-        with self._run_lock:
-            x = torch.from_numpy(np.ascontiguousarray(imgs)).to(self._eng_net.device, non_blocking=False)
-            emb = self._eng_net.forward(x, normalize=False)
-            out = emb.cpu().numpy()
+        eng = self._eng_net
+        B, D = int(imgs.shape[0]), eng.embed_dim
+        if B == 0:
+            return [np.empty((0, D), dtype=np.float32)]
+        lane = self._lanes.get()                             # blocks while every lane is busy
+        try:
+            h_in, h_out = lane.staging(imgs.size, B * D)
+            h_in.view(imgs.shape).copy_(torch.from_numpy(np.ascontiguousarray(imgs)))    # pageable -> pinned (host memcpy)
+            with torch.cuda.device(eng.device), torch.cuda.stream(lane.stream):
+                x = h_in.view(imgs.shape).to(eng.device, non_blocking=True)
+                emb = eng.forward(x, normalize=False)
+                h_out.view(B, D).copy_(emb, non_blocking=True)
+                lane.stream.synchronize()
+            out = h_out.view(B, D).numpy().copy()               # fresh ndarray owned by the caller
+        finally:
+            self._lanes.put(lane)
         return [out]

@@ -90,7 +90,8 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  * results differ only by operand-rounding noise of the precision mode).  [default]
  *   "use_panel"   [1] row-panel GEMMs with the LayerNorm fused into the panel load; 0: K-streaming GEMMs + LayerNorm kernel
  *   "use_blocked" [1] fragment-blocked activation layout; 0: row-major activations
- *   "use_qkvattn" [1] attn.qkv + attention as one kernel per image (ViT-S / 128-wide; no qkv tensor in memory);
+ *   "use_qkvattn" [1] attn.qkv + attention as one kernel per image (ViT-S / 128-wide; no qkv tensor in memory) for batches of
+ *                     192 crops or more (one image per workgroup needs ~a round of CUs); 2: for every batch size;
  *                     0: row-panel LN1+qkv kernel + attention kernel
  *   "use_mlp"     [1] LN2+fc1+GELU+fc2+residual as one kernel; 0: row-panel fc1 + K-streaming fc2
  *   "use_gemm3"   [1] 128-row wave-tile GEMM over blocked operands (fc2; every ViT-B linear); 0: gemm2 / gemm
@@ -131,6 +132,10 @@ int effocr_knn_ip_topk(const float* q_dev, int64_t nq, const float* xb_dev, int6
  *   xb_bf16_dev  bf16 copy of xb_dev made with effocr_convert_bf16;  xnorm_max >= the L2 norm of every index row
  *   d % 64 == 0, k <= 32, ntotal >= k. */
 size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k);
+/* Byte offset, inside the screened search's workspace, of its int32 OVERFLOW FLAG: non-zero after a call in which some
+ * query had more than 512 candidates within the error band, i.e. the call also ran the exact pass (results are
+ * identical either way; a caller that sees it repeatedly should use effocr_knn_ip_topk directly). */
+size_t effocr_knn_screen_flag_offset(int64_t nq, int64_t ntotal, int d, int k);
 int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, int64_t ntotal, int d,
                                 int k, float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev,
                                 size_t workspace_bytes, void* stream);

@@ -134,7 +134,8 @@ def test_input_validation(dev):
 def test_every_switchable_path_matches_the_oracle(dev, B):
     """Default path (row-panel qkv / proj + fused MLP) and every A/B switch of the library — unfused MLP, projection
     fused into the MLP kernel, register-resident row-block linears, gemm2 instead of gemm3, no tail split — against
-    oracle A at batch sizes that exercise single-panel, ragged and multi-panel grids."""
+    oracle A at batch sizes that exercise single-panel, ragged and multi-panel grids; the one-image-per-workgroup qkv+attention
+    kernel (default from 192 crops on) is forced on for every batch size, alone and combined with the other switches."""
     from effocr_amd.encoders import HipEncoder
     arch = "vit_small_patch16_224"
     sd = init_state_dict(arch, seed=6, img_size=224)
@@ -144,12 +145,56 @@ def test_every_switchable_path_matches_the_oracle(dev, B):
         enc = HipEncoder(arch, sd, precision=prec, device=dev)
         outs = {"default": enc.forward(x.to(dev)).cpu()}
         for name, opts in [("unfused_mlp", {"use_mlp": 0}), ("proj_in_mlp", {"use_projf": 1}), ("rowlin", {"use_rowlin": 1}),
-                           ("gemm2_fc2", {"use_mlp": 0, "use_gemm3": 0}), ("no_tail_split", {"tail_split": 0})]:
+                           ("gemm2_fc2", {"use_mlp": 0, "use_gemm3": 0}), ("no_tail_split", {"tail_split": 0}),
+                           ("fused_qkv_attention", {"use_qkvattn": 2}), ("fused_qkv_attention+proj_in_mlp", {"use_qkvattn": 2, "use_projf": 1}),
+                           ("fused_qkv_attention_no_tail_split", {"use_qkvattn": 2, "tail_split": 0}), ("panel_qkv+attention", {"use_qkvattn": 0})]:
             for k, v in opts.items():
                 enc.set_option(k, v)
             outs[name] = enc.forward(x.to(dev)).cpu()
             for k in opts:                                   # back to the defaults
-                enc.set_option(k, {"use_mlp": 1, "use_projf": 0, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1}[k])
+                enc.set_option(k, {"use_mlp": 1, "use_projf": 0, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1, "use_qkvattn": 1}[k])
         assert torch.equal(outs["default"], enc.forward(x.to(dev)).cpu())          # switches restored, run-to-run bitwise
         for name, o in outs.items():
             assert rel_err(o, ref) <= REL[prec], (name, prec, B, rel_err(o, ref))
+
+
+def test_fused_attention_default_dispatch_and_full_batch(dev):
+    """From 192 crops on the default path is the fused qkv+attention kernel (persistent workgroups: 300 crops = 2 images on
+    44 of 256 workgroups) with the MLP kernel's second output feeding it; it must agree with the panel path on the same
+    batch at the precision mode's noise, be deterministic, and match oracle A on sampled rows."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    sd = init_state_dict(arch, seed=2, img_size=224)
+    x = torch.randn(300, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+    for prec in ("bf16", "fp16"):
+        enc = HipEncoder(arch, sd, precision=prec, device=dev)
+        e1 = enc.forward(x)
+        assert torch.equal(e1, enc.forward(x))
+        enc.set_option("use_qkvattn", 0)
+        e0 = enc.forward(x)
+        assert not torch.equal(e0, e1)                       # really two different kernel sequences
+        assert rel_err(e1.cpu(), e0.cpu()) <= REL[prec]
+        sel = [0, 150, 299]
+        ref = encoder_forward(arch, sd, x[sel].cpu())
+        assert rel_err(e1[sel].cpu(), ref) <= REL[prec] and rel_err(e0[sel].cpu(), ref) <= REL[prec]
+
+
+def test_full_size_config4_encoder_properties(dev):
+    """BASELINE configs[3] encoder at full size: ViT-B/16, 1024 crops (gemm3 main + 64-token-tile tail launches at
+    M = 201 728 rows, 1.2 GB hidden buffer): determinism, unit norms, batch invariance at the precision bound, sampled rows
+    against oracle A."""
+    from effocr_amd.encoders import HipEncoder
+    from oracle.encoders_ref import l2_normalize
+    arch = "vit_base_patch16_224"
+    sd = init_state_dict(arch, seed=0)
+    enc = HipEncoder(arch, sd, precision="bf16", device=dev)
+    x = torch.randn(1024, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
+    e1 = enc.forward(x, normalize=True)
+    assert torch.equal(e1, enc.forward(x, normalize=True))
+    assert torch.isfinite(e1).all()
+    assert ((e1.norm(dim=1) - 1).abs().max()).item() < 1e-5
+    sub = enc.forward(x[500:564].contiguous(), normalize=True)
+    assert rel_err(sub.cpu(), e1[500:564].cpu()) <= REL["bf16"]
+    sel = [0, 777, 1023]
+    ref = l2_normalize(encoder_forward(arch, sd, x[sel].cpu()))
+    assert rel_err(e1[sel].cpu(), ref) <= REL["bf16"]

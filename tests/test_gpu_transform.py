@@ -117,7 +117,11 @@ def test_recognize_boxes_end_to_end(dev):
     chars = [chr(0x3041 + i) for i in range(len(boxes))]
     sd = init_state_dict("resnet18", seed=1)
     enc = HipEncoder("resnet18", sd, img_size=32, precision="fp32", device=dev)
-    ref_crops = R.transform_boxes(img, [R.round_box(b[:4]) for b in boxes], size=32)
+    # reference convention (infer_effocr.py:226,286-291): double_clipped is hard-coded True -> every crop spans the whole
+    # line height: (x0, 0, x1, H) after rounding.  The index is built from exactly those crops on the CPU.
+    H = img.shape[0]
+    clipped = [(R.round_box(b[:4])[0], 0, R.round_box(b[:4])[2], H) for b in boxes]
+    ref_crops = R.transform_boxes(img, clipped, size=32)
     ref_emb = l2_normalize(encoder_forward("resnet18", sd, torch.from_numpy(ref_crops))).numpy()
     knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
     knn.train(torch.from_numpy(ref_emb).to(dev))
@@ -128,6 +132,20 @@ def test_recognize_boxes_end_to_end(dev):
     same = sum([chars[j] for j in I_ref[i]] == nearest[i] for i in range(len(boxes)))
     assert same >= len(boxes) - 1                      # fp32 GPU vs CPU embeddings: at most one near-tie may swap
     assert rec.recognize_boxes(img, []) == ([], [], "")
+    # the flag really changes the crops: tight boxes give different embeddings (not the self-retrieval above) ...
+    from effocr_amd.transforms import PairedTransform
+    tf = PairedTransform(size=32, device=dev)
+    tight = tf.boxes(img, boxes)
+    full = tf.boxes(img, clipped, already_int=True)
+    assert not torch.equal(tight, full)
+    np.testing.assert_allclose(full.cpu().numpy(), ref_crops, atol=3e-5)
+    # ... and vertical lines are clipped the other way: (0, y0, W, y1)
+    vb = [(10.2, y + 0.4, 50.7, y + 24.6) for y in range(2, 50, 25)]
+    W_ = img.shape[1]
+    n_v, _, _ = rec.recognize_boxes(img, vb, vertical=True)
+    want = tf.boxes(img, [(0, R.round_box(b)[1], W_, R.round_box(b)[3]) for b in vb], already_int=True)
+    got_idx = rec.neighbors(want)[1][:, 0].cpu().tolist()
+    assert [n[0] for n in n_v] == [chars[i] for i in got_idx]
 
 
 def test_line_recognizer_en_end_to_end(dev):
@@ -147,7 +165,7 @@ def test_line_recognizer_en_end_to_end(dev):
     sd = init_state_dict("resnet18", seed=2)
     enc = HipEncoder("resnet18", sd, img_size=32, precision="fp32", device=dev)
     tf = PairedTransform(size=32, device=dev)
-    emb = enc.forward(tf.boxes(img, [(x, 10, x + 30, 50) for x in xs], already_int=True), normalize=True)
+    emb = enc.forward(tf.boxes(img, [(x, 0, x + 30, 60) for x in xs], already_int=True), normalize=True)   # double-clipped crops (reference default)
     knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
     knn.train(emb)
     rec = Recognizer(enc, knn, list(text), knn=3)
@@ -158,3 +176,16 @@ def test_line_recognizer_en_end_to_end(dev):
     out_jp, _, cb_jp, wb_jp = jp.infer(img, [[chars_b]])
     assert out_jp == text and wb_jp is None
     assert jp.infer(img, [[chars_b[:1] * 0]]) == (None, None, None, None)            # nothing above the score threshold
+
+
+def test_device_transform_matches_committed_golden(dev):
+    """tests/golden/crop_transform.npz (make_golden.py: oracle output, itself cross-checked against torch interpolate):
+    the HIP kernel against the COMMITTED vectors, both resize flavours, no oracle import on this path."""
+    import os
+    from effocr_amd.transforms import PairedTransform
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crop_transform.npz"))
+    img, boxes, size = g["image"], [tuple(int(v) for v in b) for b in g["boxes"]], int(g["size"])
+    for aa, key in ((True, "out_aa"), (False, "out_plain")):
+        got = PairedTransform(size=size, device=dev, antialias=aa).boxes(img, boxes, already_int=True).cpu().numpy()
+        assert got.shape == g[key].shape
+        np.testing.assert_allclose(got, g[key], atol=3e-5 if aa else 2e-4)
