@@ -6,7 +6,7 @@ conventions.  All compute is hand-written HIP in ``libeffocr_hip.so`` (C ABI: in
 from ._lib import EffOCRHipError, build, lib  # noqa: F401
 from .weights import init_state_dict, load_checkpoint, save_checkpoint, embed_dim  # noqa: F401
 
-__all__ = ["AutoEncoderFactory", "HipEncoder", "EffRecognizer", "FaissKNN", "IndexFlatIP", "InferenceModel",
+__all__ = ["AutoEncoderFactory", "HipEncoder", "EffRecognizer", "EffLocalizer", "FaissKNN", "IndexFlatIP", "InferenceModel",
            "Recognizer", "build", "lib", "EffOCRHipError"]
 
 
@@ -18,6 +18,9 @@ def __getattr__(name):
     if name == "EffRecognizer":
         from .recognizer_engine import EffRecognizer
         return EffRecognizer
+    if name in ("EffLocalizer", "HipLocalizer"):
+        from . import localizer_engine
+        return getattr(localizer_engine, name)
     if name in ("FaissKNN", "IndexFlatIP", "InferenceModel", "read_index", "write_index", "l2_normalize"):
         from . import knn
         return getattr(knn, name)

@@ -71,6 +71,21 @@ def _declare(lib):
         "effocr_gather_rows": (i32, [f32p, i64p, i64, i32, f32p, vp]),
         "effocr_crop_transform": (i32, [vp, i32, i32, i64, vp, i32, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),
                                         c.POINTER(c.c_float), f32p, vp]),
+        "effocr_localizer_create": (i32, [c.c_char_p, i32, i32, i32, c.POINTER(vp)]),
+        "effocr_localizer_destroy": (None, [vp]),
+        "effocr_localizer_num_params": (i32, [vp]),
+        "effocr_localizer_param_name": (c.c_char_p, [vp, i32]),
+        "effocr_localizer_param_numel": (i64, [vp, i32]),
+        "effocr_localizer_set_param": (i32, [vp, c.c_char_p, vp, i64]),
+        "effocr_localizer_weights_bytes": (sz, [vp]),
+        "effocr_localizer_upload": (i32, [vp, vp, sz]),
+        "effocr_localizer_num_predictions": (i64, [vp]),
+        "effocr_localizer_num_outputs": (i32, [vp]),
+        "effocr_localizer_workspace_bytes": (sz, [vp, i32]),
+        "effocr_localizer_forward": (i32, [vp, f32p, i32, f32p, vp, sz, vp]),
+        "effocr_letterbox": (i32, [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32, i32, f32p, vp]),
+        "effocr_nms_workspace_bytes": (sz, [i32, i32]),
+        "effocr_nms": (i32, [f32p, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
         "effocr_op_linear": (i32, [i32, i32, vp, vp, f32p, f32p, vp, i32, i32, i32, vp]),
         "effocr_op_layernorm": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
         "effocr_op_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),

@@ -136,17 +136,35 @@ int crop_transform(const uint8_t* img, int H, int W, int64_t stride, const int* 
 
 // resnet.hip
 struct ConvArgs {
-  const float* in;      // NHWC fp32 [B,H,W,Cin]
+  const float* in;      // NHWC fp32 [B,H,W,in_ld] (channels in_off .. in_off+Cin of every pixel)
   const float* w;       // [Cout][KH*KW*Cin] fp32, BN folded
   const float* bias;    // [Cout] folded BN shift
-  const float* resid;   // optional NHWC [B,OH,OW,Cout]
-  float* out;           // NHWC [B,OH,OW,Cout]
+  const float* resid;   // optional NHWC [B,OH,OW,res_ld] (+ res_off)
+  float* out;           // NHWC [B,OH,OW,out_ld] (channels out_off .. out_off+Cout)
   int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu;
+  // channel-slice addressing (0 = dense: ld = channel count, offset 0): lets producers write straight into the slices of a
+  // concatenation buffer and consumers read one (YOLOv5 C3 / SPPF / neck concats never materialise a copy)
+  int in_ld, in_off, out_ld, out_off, res_ld, res_off;
+  int silu;             // epilogue x * sigmoid(x) (ultralytics Conv = Conv2d + BN + SiLU); relu and silu are exclusive
 };
 int conv2d_nhwc(const ConvArgs& a, hipStream_t s);
 // conv1 7x7/2 pad 3 im2col straight from the NCHW input: rows [B*OH*OW][160] (147 taps (ky,kx,c) + zero pad)
 int im2col_conv1(const float* x, float* col, int B, int H, int W, int OH, int OW, hipStream_t s);
 int maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
 int global_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, int l2norm, hipStream_t s);
+
+// yolo.hip — the non-conv pieces of the YOLOv5 localizer (onnx_engines/localizer_engine.py) on NHWC fp32 activations
+// generic im2col for a stem conv with few input channels: x NCHW [B,Cin,H,W] -> col [B*OH*OW][kpad], k = (ky*KW + kx)*Cin + c, zero padded
+int im2col_nchw(const float* x, float* col, int B, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW, int kpad, hipStream_t s);
+int upsample2x_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s);
+int maxpool5_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s);
+// Detect head decode of one level: raw [B,ny,nx,raw_ld] (channel a*no + o) -> pred [B,total,no] rows row0 + (a*ny + y)*nx + x
+int yolo_decode(const float* raw, int raw_ld, float* pred, int B, int ny, int nx, int na, int no, float stride, const float* anchors_px,
+                int64_t total, int64_t row0, hipStream_t s);
+int letterbox_u8(const uint8_t* img, int H, int W, int64_t row_stride, int bgr, int out_h, int out_w, int new_h, int new_w, int top, int left,
+                 float fill, float* out, hipStream_t s);
+size_t nms_workspace_bytes(int n, int max_nms);
+int nms_yolo(const float* pred, int n, int nc, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+             float* out, int* count, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace effocr

@@ -30,7 +30,7 @@ __device__ __forceinline__ void conv_stage_load(u32x4 (&r)[4], const ConvArgs& a
     const int iy = rc[i].iy0 + ky, ix = rc[i].ix0 + kx;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-      const float* p = a.in + (((int64_t)rc[i].b * a.H + iy) * a.W + ix) * a.Cin + ci0 + c * 4;
+      const float* p = a.in + (((int64_t)rc[i].b * a.H + iy) * a.W + ix) * a.in_ld + a.in_off + ci0 + c * 4;
       v = *reinterpret_cast<const u32x4*>(p);
     }
     r[i] = v;
@@ -103,15 +103,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         if (n >= a.Cout) continue;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
         f32x4 v = {acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1], acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]};
+        if (a.silu) {                                    // x * sigmoid(x), before the residual (Bottleneck: x + cv2(cv1(x)))
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+        }
         if (a.resid) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)m * a.Cout + n);
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)m * a.res_ld + a.res_off + n);
           v += rv;
         }
         if (a.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        *reinterpret_cast<f32x4*>(a.out + (int64_t)m * a.Cout + n) = v;
+        *reinterpret_cast<f32x4*>(a.out + (int64_t)m * a.out_ld + a.out_off + n) = v;
       }
     }
   }
@@ -197,9 +201,14 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 
 }  // namespace
 
-int conv2d_nhwc(const ConvArgs& a, hipStream_t s) {
+int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (a.in_ld == 0) a.in_ld = a.Cin;
+  if (a.out_ld == 0) a.out_ld = a.Cout;
+  if (a.res_ld == 0) a.res_ld = a.Cout;
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   if (M <= 0) return EFFOCR_OK;
+  if ((a.in_ld | a.in_off | a.out_ld | a.out_off | a.res_ld | a.res_off) & 3) return fail(EFFOCR_EUNSUPPORTED, "conv2d: channel strides / offsets must be multiples of 4");
   if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
   if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
   const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);

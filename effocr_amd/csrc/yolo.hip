@@ -1,0 +1,336 @@
+// Non-convolution kernels of the YOLOv5 character / word localizer (BASELINE.json config 5; reference:
+// onnx_engines/localizer_engine.py — an ONNXRuntime session over an ultralytics YOLOv5 export + letterbox + NMS).
+// Activations are NHWC fp32 like the resnet path; every kernel reads / writes CHANNEL SLICES of wider buffers so that
+// the network's concatenations (C3, SPPF, neck) are never copied.  The convolutions themselves are resnet.hip's
+// implicit-GEMM kernel (exact fp32 MFMA) with a SiLU epilogue.
+//   im2col_nchw     stem conv (3 input channels, 6x6 / stride 2): rows for the 1x1 implicit GEMM
+//   upsample2x      nn.Upsample(scale_factor=2, mode="nearest")
+//   maxpool5        nn.MaxPool2d(5, 1, 2) (SPPF)
+//   yolo_decode     ultralytics Detect.forward in inference mode: sigmoid, grid / anchor decode, (bs, na*ny*nx, no) layout
+//   letterbox_u8    EffLocalizer.letterbox + load_localizer_img (localizer_engine.py:75-138): cv2.resize(INTER_LINEAR)
+//                   fixed-point bilinear, 114-grey border, BGR->RGB, /255, CHW
+//   nms_*           EffLocalizer.non_max_suppression (localizer_engine.py:171-277): objectness / class-confidence filter,
+//                   best class, confidence sort, class-offset boxes, torchvision.ops.nms, max_det
+#include "common.hpp"
+#include "kernels.hpp"
+#include <math.h>
+
+namespace effocr {
+namespace {
+
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int Cin, int H, int W,
+                                                          int KH, int KW, int stride, int pad, int OH, int OW, int kpad) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * OH * OW * kpad;
+  if (id >= total) return;
+  const int k = (int)(id % kpad);
+  const int64_t m = id / kpad;
+  float v = 0.f;
+  if (k < KH * KW * Cin) {
+    const int c = k % Cin, tap = k / Cin, kx = tap % KW, ky = tap / KW;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH);
+    const int64_t b = m / ((int64_t)OW * OH);
+    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * Cin + c) * H + iy) * (int64_t)W + ix];
+  }
+  col[id] = v;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, int in_ld, int in_off, float* __restrict__ out, int out_ld,
+                                                         int out_off, int B, int H, int W, int C) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)B * 2 * H * 2 * W * C4;
+  if (id >= total) return;
+  const int c4 = (int)(id % C4);
+  const int64_t p = id / C4;
+  const int ox = (int)(p % (2 * W)), oy = (int)((p / (2 * W)) % (2 * H));
+  const int64_t b = p / ((int64_t)4 * W * H);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((b * H + (oy >> 1)) * W + (ox >> 1)) * in_ld + in_off + c4 * 4);
+  *reinterpret_cast<f32x4*>(out + p * out_ld + out_off + c4 * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__ in, int in_ld, int in_off, float* __restrict__ out, int out_ld,
+                                                       int out_off, int B, int H, int W, int C) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)B * H * W * C4;
+  if (id >= total) return;
+  const int c4 = (int)(id % C4);
+  const int64_t p = id / C4;
+  const int ox = (int)(p % W), oy = (int)((p / W) % H);
+  const int64_t b = p / ((int64_t)W * H);
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int ky = -2; ky <= 2; ++ky)
+    for (int kx = -2; kx <= 2; ++kx) {
+      const int iy = oy + ky, ix = ox + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((b * H + iy) * W + ix) * in_ld + in_off + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+  *reinterpret_cast<f32x4*>(out + p * out_ld + out_off + c4 * 4) = m;
+}
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// one thread per (image, anchor, y, x, o)
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restrict__ raw, int raw_ld, float* __restrict__ pred, int B, int ny, int nx,
+                                                          int na, int no, float stride, float aw0, float ah0, float aw1, float ah1, float aw2,
+                                                          float ah2, int64_t total, int64_t row0) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t cnt = (int64_t)B * na * ny * nx * no;
+  if (id >= cnt) return;
+  const int o = (int)(id % no);
+  int64_t t = id / no;
+  const int x = (int)(t % nx); t /= nx;
+  const int y = (int)(t % ny); t /= ny;
+  const int an = (int)(t % na);
+  const int64_t b = t / na;
+  const float y0 = sigmoidf(raw[((b * ny + y) * nx + x) * raw_ld + an * no + o]);
+  float v = y0;
+  if (o == 0) v = (y0 * 2.0f + ((float)x - 0.5f)) * stride;          // (y * 2 + grid) * stride, grid = index - 0.5 (Detect._make_grid)
+  else if (o == 1) v = (y0 * 2.0f + ((float)y - 0.5f)) * stride;
+  else if (o == 2) { const float aw = an == 0 ? aw0 : (an == 1 ? aw1 : aw2); const float s2 = y0 * 2.0f; v = s2 * s2 * aw; }
+  else if (o == 3) { const float ah = an == 0 ? ah0 : (an == 1 ? ah1 : ah2); const float s2 = y0 * 2.0f; v = s2 * s2 * ah; }
+  pred[(b * total + row0 + ((int64_t)an * ny + y) * nx + x) * no + o] = v;
+}
+
+// cv2.resize(src, (new_w, new_h), INTER_LINEAR) on uint8 (OpenCV resize.cpp, restated): source coordinate
+// fx = (dx + 0.5) * (src_w / new_w) - 0.5, sx = floor(fx), clamped; weights rounded to 11-bit fixed point
+// (cvRound((1 - f) * 2048), cvRound(f * 2048)); horizontal pass in int (x 2^11), vertical pass
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  Then the 114 border, channel order, /255, CHW.
+__device__ __forceinline__ void lin_coef(int d, int src, int dst, int& s0, int& s1, int& a0, int& a1) {
+  const double scale = (double)src / (double)dst;
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= src - 1) { f = 0.f; s = src - 1; }
+  s0 = s; s1 = s + 1 < src ? s + 1 : src - 1;
+  a0 = (int)rintf((1.f - f) * 2048.f);
+  a1 = (int)rintf(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ img, int H, int W, int64_t rs, int bgr, int out_h, int out_w,
+                                                        int new_h, int new_w, int top, int left, float fill, float* __restrict__ out) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= out_h * out_w) return;
+  const int ox = id % out_w, oy = id / out_w;
+  const int dx = ox - left, dy = oy - top;
+  float v[3] = {fill, fill, fill};
+  if (dx >= 0 && dx < new_w && dy >= 0 && dy < new_h) {
+    if (new_w == W && new_h == H) {                       // letterbox skips the resize when the size already matches
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (float)img[(int64_t)dy * rs + dx * 3 + c];
+    } else {
+      int x0, x1, ax0, ax1, y0, y1, by0, by1;
+      lin_coef(dx, W, new_w, x0, x1, ax0, ax1);
+      lin_coef(dy, H, new_h, y0, y1, by0, by1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int S0 = (int)img[(int64_t)y0 * rs + x0 * 3 + c] * ax0 + (int)img[(int64_t)y0 * rs + x1 * 3 + c] * ax1;
+        const int S1 = (int)img[(int64_t)y1 * rs + x0 * 3 + c] * ax0 + (int)img[(int64_t)y1 * rs + x1 * 3 + c] * ax1;
+        const int r = (((by0 * (S0 >> 4)) >> 16) + ((by1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v[c] = (float)(r < 0 ? 0 : (r > 255 ? 255 : r));
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[((int64_t)(bgr ? 2 - c : c) * out_h + oy) * out_w + ox] = v[c] / 255.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- NMS
+// Workspace: [counter int x 64 | cand (row index, conf, cls) | sorted rows (offset box 4, conf, cls, raw box 4) | mask words]
+struct NmsWs { size_t counter, cand_i, cand_s, cand_c, srt, mask, total; };
+NmsWs nms_ws(int n, int max_nms) {
+  NmsWs w; size_t off = 0;
+  auto take = [&](size_t b) { const size_t o = off; off = align_up(off + b, 256); return o; };
+  const size_t m = (size_t)(n < max_nms ? n : max_nms);
+  w.counter = take(256);
+  w.cand_i = take((size_t)n * 4); w.cand_s = take((size_t)n * 4); w.cand_c = take((size_t)n * 4);
+  w.srt = take(m * 10 * 4);
+  w.mask = take(m * ((m + 63) / 64) * 8);
+  w.total = off;
+  return w;
+}
+
+// candidates: objectness > thr, then conf = obj * max class prob > thr (non-multi-label branch: best class only)
+__global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict__ pred, int n, int nc, float thr, int* __restrict__ counter,
+                                                         int* __restrict__ ci, float* __restrict__ cs, int* __restrict__ cc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pred + (int64_t)i * (5 + nc);
+  const float obj = p[4];
+  if (!(obj > thr)) return;
+  float best = -INFINITY; int bj = 0;
+  for (int j = 0; j < nc; ++j) { const float c = p[5 + j] * obj; if (c > best) { best = c; bj = j; } }   // first maximum wins
+  if (!(best > thr)) return;
+  const int pos = atomicAdd(counter, 1);
+  ci[pos] = i; cs[pos] = best; cc[pos] = bj;
+}
+
+// rank by (confidence descending, row index ascending) — counting sort, O(m^2) compares spread over m threads;
+// rows ranked >= max_nms are dropped (the reference keeps the 30000 most confident)
+__global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__ pred, int nc, const int* __restrict__ counter, const int* __restrict__ ci,
+                                                       const float* __restrict__ cs, const int* __restrict__ cc, int max_nms, float max_wh,
+                                                       int agnostic, float* __restrict__ srt) {
+  const int m = *counter;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= m) return;
+  const float s = cs[p]; const int i = ci[p];
+  int rank = 0;
+  for (int q = 0; q < m; ++q) {
+    const float sq = cs[q];
+    rank += (sq > s || (sq == s && ci[q] < i)) ? 1 : 0;
+  }
+  if (rank >= max_nms) return;
+  const float* b = pred + (int64_t)i * (5 + nc);
+  const float x1 = b[0] - b[2] / 2, y1 = b[1] - b[3] / 2, x2 = b[0] + b[2] / 2, y2 = b[1] + b[3] / 2;   // xywh2xyxy
+  const float off = agnostic ? 0.f : (float)cc[p] * max_wh;
+  float* o = srt + (int64_t)rank * 10;
+  o[0] = x1 + off; o[1] = y1 + off; o[2] = x2 + off; o[3] = y2 + off; o[4] = s; o[5] = (float)cc[p];
+  o[6] = x1; o[7] = y1; o[8] = x2; o[9] = y2;
+}
+
+// mask[i][w] bit j: box 64w + j (ranked after i) overlaps box i with IoU > thr (torchvision.ops.nms: inter / (a_i + a_j - inter))
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ srt, const int* __restrict__ counter, int max_nms, float thr,
+                                                       unsigned long long* __restrict__ mask) {
+  int m = *counter; m = m < max_nms ? m : max_nms;
+  const int nw = (m + 63) / 64;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)m * nw) return;
+  const int i = (int)(id / nw), w = (int)(id % nw);
+  const float* a = srt + (int64_t)i * 10;
+  const float ax1 = a[0], ay1 = a[1], ax2 = a[2], ay2 = a[3];
+  const float aa = (ax2 - ax1) * (ay2 - ay1);
+  unsigned long long bits = 0ull;
+  for (int j = 0; j < 64; ++j) {
+    const int q = w * 64 + j;
+    if (q <= i || q >= m) continue;
+    const float* b = srt + (int64_t)q * 10;
+    const float iw = fminf(ax2, b[2]) - fmaxf(ax1, b[0]), ih = fminf(ay2, b[3]) - fmaxf(ay1, b[1]);
+    const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+    const float ab = (b[2] - b[0]) * (b[3] - b[1]);
+    if (inter / (aa + ab - inter) > thr) bits |= 1ull << j;
+  }
+  mask[id] = bits;
+}
+
+// greedy scan in rank order by ONE wave: lane l holds the words l, l+64, ... of the `removed` bit set
+constexpr int NMS_WPL = 8;                                // words per lane: up to 64 * 8 * 64 = 32768 ranked boxes
+__global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ srt, const int* __restrict__ counter, int max_nms, int max_det,
+                                                      const unsigned long long* __restrict__ mask, float* __restrict__ out, int* __restrict__ count) {
+  int m = *counter; m = m < max_nms ? m : max_nms;
+  const int nw = (m + 63) / 64;
+  const int lane = threadIdx.x;
+  unsigned long long rem[NMS_WPL];
+#pragma unroll
+  for (int t = 0; t < NMS_WPL; ++t) rem[t] = 0ull;
+  int kept = 0;
+  for (int i0 = 0; i0 < m && kept < max_det; i0 += 8) {
+    // the next 8 rows' masks are requested together (one memory latency per 8 boxes instead of one per box)
+    unsigned long long row[8][NMS_WPL];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int t = 0; t < NMS_WPL; ++t) {
+        const int w = lane + 64 * t;
+        row[r][t] = (i0 + r < m && w < nw) ? mask[(int64_t)(i0 + r) * nw + w] : 0ull;
+      }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int i = i0 + r;
+      if (i >= m || kept >= max_det) break;
+      const int w = i >> 6, t = w >> 6, src = w & 63;
+      unsigned long long word = 0ull;
+#pragma unroll
+      for (int tt = 0; tt < NMS_WPL; ++tt) if (tt == t) word = rem[tt];
+      const unsigned lo = __shfl((unsigned)(word & 0xffffffffull), src, 64), hi = __shfl((unsigned)(word >> 32), src, 64);
+      const unsigned long long ww = ((unsigned long long)hi << 32) | lo;
+      if ((ww >> (i & 63)) & 1ull) continue;              // suppressed by a kept, more confident box
+      if (lane < 6) {
+        const float* s = srt + (int64_t)i * 10;
+        out[(int64_t)kept * 6 + lane] = lane < 4 ? s[6 + lane] : s[lane];
+      }
+      ++kept;
+#pragma unroll
+      for (int tt = 0; tt < NMS_WPL; ++tt) rem[tt] |= row[r][tt];
+    }
+  }
+  if (lane == 0) *count = kept;
+}
+
+}  // namespace
+
+int im2col_nchw(const float* x, float* col, int B, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW, int kpad, hipStream_t s) {
+  const int64_t total = (int64_t)B * OH * OW * kpad;
+  if (total <= 0) return EFFOCR_OK;
+  if (kpad < KH * KW * Cin) return fail(EFFOCR_EINVAL, "im2col: padded K smaller than the tap count");
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, col, B, Cin, H, W, KH, KW, stride, pad, OH, OW, kpad);
+  return check_launch("im2col_nchw");
+}
+
+int upsample2x_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s) {
+  const int64_t total = (int64_t)B * 4 * H * W * (C / 4);
+  if (total <= 0) return EFFOCR_OK;
+  if ((C | in_ld | in_off | out_ld | out_off) & 3) return fail(EFFOCR_EUNSUPPORTED, "upsample: channel counts / strides / offsets must be multiples of 4");
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld, in_off, out, out_ld, out_off, B, H, W, C);
+  return check_launch("upsample2x");
+}
+
+int maxpool5_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s) {
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  if (total <= 0) return EFFOCR_OK;
+  if ((C | in_ld | in_off | out_ld | out_off) & 3) return fail(EFFOCR_EUNSUPPORTED, "maxpool5: channel counts / strides / offsets must be multiples of 4");
+  hipLaunchKernelGGL(maxpool5_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld, in_off, out, out_ld, out_off, B, H, W, C);
+  return check_launch("maxpool5");
+}
+
+int yolo_decode(const float* raw, int raw_ld, float* pred, int B, int ny, int nx, int na, int no, float stride, const float* anchors_px,
+                int64_t total, int64_t row0, hipStream_t s) {
+  const int64_t cnt = (int64_t)B * na * ny * nx * no;
+  if (cnt <= 0) return EFFOCR_OK;
+  if (na != 3) return fail(EFFOCR_EUNSUPPORTED, "yolo_decode: three anchors per level");
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, raw, raw_ld, pred, B, ny, nx, na, no, stride,
+                     anchors_px[0], anchors_px[1], anchors_px[2], anchors_px[3], anchors_px[4], anchors_px[5], total, row0);
+  return check_launch("yolo_decode");
+}
+
+int letterbox_u8(const uint8_t* img, int H, int W, int64_t row_stride, int bgr, int out_h, int out_w, int new_h, int new_w, int top, int left,
+                 float fill, float* out, hipStream_t s) {
+  if (H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || new_h <= 0 || new_w <= 0 || top < 0 || left < 0 || top + new_h > out_h || left + new_w > out_w)
+    return fail(EFFOCR_EINVAL, "letterbox: bad geometry");
+  hipLaunchKernelGGL(letterbox_kernel, dim3((unsigned)((out_h * out_w + 255) / 256)), dim3(256), 0, s, img, H, W, row_stride, bgr, out_h, out_w,
+                     new_h, new_w, top, left, fill, out);
+  return check_launch("letterbox");
+}
+
+size_t nms_workspace_bytes(int n, int max_nms) { return n <= 0 ? 256 : nms_ws(n, max_nms).total; }
+
+int nms_yolo(const float* pred, int n, int nc, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+             float* out, int* count, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (n < 0 || nc < 1 || max_det < 1 || max_nms < 1) return fail(EFFOCR_EINVAL, "nms: bad sizes");
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f) || !(iou_thres >= 0.f && iou_thres <= 1.f)) return fail(EFFOCR_EINVAL, "nms: thresholds must lie in [0, 1]");
+  if (max_nms > 64 * 64 * NMS_WPL) return fail(EFFOCR_EUNSUPPORTED, "nms: at most 32768 ranked boxes");
+  if (n == 0) return hipMemsetAsync(count, 0, 4, s) == hipSuccess ? EFFOCR_OK : fail(EFFOCR_EHIP, "nms: memset failed");
+  const NmsWs w = nms_ws(n, max_nms);
+  if (ws_bytes < w.total) return fail(EFFOCR_EWORKSPACE, "nms: workspace too small");
+  char* W = static_cast<char*>(ws);
+  int* counter = reinterpret_cast<int*>(W + w.counter);
+  int* ci = reinterpret_cast<int*>(W + w.cand_i); float* cs = reinterpret_cast<float*>(W + w.cand_s); int* cc = reinterpret_cast<int*>(W + w.cand_c);
+  float* srt = reinterpret_cast<float*>(W + w.srt);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(W + w.mask);
+  if (hipMemsetAsync(counter, 0, 256, s) != hipSuccess) return fail(EFFOCR_EHIP, "nms: memset failed");
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(nms_filter_kernel, dim3(gb), dim3(256), 0, s, pred, n, nc, conf_thres, counter, ci, cs, cc);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(gb), dim3(256), 0, s, pred, nc, counter, ci, cs, cc, max_nms, max_wh, agnostic, srt);
+  const int mcap = n < max_nms ? n : max_nms;
+  const int64_t words = (int64_t)mcap * ((mcap + 63) / 64);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, srt, counter, max_nms, iou_thres, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, s, srt, counter, max_nms, max_det, mask, out, count);
+  return check_launch("nms");
+}
+
+}  // namespace effocr

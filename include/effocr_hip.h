@@ -164,6 +164,46 @@ int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64
                           const float* std, const float* fill, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Localizer engine: the YOLOv5 character / word detector the reference runs through ONNXRuntime
+ * (onnx_engines/localizer_engine.py:14-66 EffLocalizer with model_backend == 'yolo'; driver
+ * infer_effocr_onnx_multi.py:236-262).  Same handle protocol as the encoder: create -> set_param x N ->
+ * upload -> forward.  arch "yolov5s" (ultralytics v6 yaml); parameter names are the ultralytics state-dict
+ * keys ("model.0.conv.weight", "model.0.bn.running_var", ..., "model.24.m.2.bias", "model.24.anchors").
+ *   forward:  x_dev [B,3,in_h,in_w] fp32 (letterboxed RGB, 0..1 — what load_localizer_img builds, :75-85)
+ *             -> pred_dev [B, num_predictions, 5 + num_classes] fp32 = the exported model's output 0
+ *             (xywh in input pixels, objectness, class probabilities; 25200 rows at 640 x 640).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct effocr_localizer effocr_localizer_t;
+int effocr_localizer_create(const char* arch, int num_classes, int in_h, int in_w, effocr_localizer_t** out);
+void effocr_localizer_destroy(effocr_localizer_t* loc);
+int effocr_localizer_num_params(const effocr_localizer_t* loc);
+const char* effocr_localizer_param_name(const effocr_localizer_t* loc, int i);
+int64_t effocr_localizer_param_numel(const effocr_localizer_t* loc, int i);
+int effocr_localizer_set_param(effocr_localizer_t* loc, const char* name, const float* host, int64_t numel);
+size_t effocr_localizer_weights_bytes(const effocr_localizer_t* loc);
+int effocr_localizer_upload(effocr_localizer_t* loc, void* weights_dev, size_t bytes);
+int64_t effocr_localizer_num_predictions(const effocr_localizer_t* loc);
+int effocr_localizer_num_outputs(const effocr_localizer_t* loc);             /* 5 + num_classes */
+size_t effocr_localizer_workspace_bytes(const effocr_localizer_t* loc, int batch);
+int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int batch, float* pred_dev, void* workspace_dev,
+                             size_t workspace_bytes, void* stream);
+/* EffLocalizer.letterbox + load_localizer_img (localizer_engine.py:75-85,107-138) for ONE image on the device:
+ * image_dev uint8 HWC (bgr != 0: cv2.imread order, channels are reversed like the reference's [::-1]) is resized to
+ * new_w x new_h with cv2.resize(INTER_LINEAR)'s fixed-point arithmetic, placed at (left, top) in an out_w x out_h canvas of
+ * grey 114, scaled by 1/255 and written CHW (RGB) to out_dev [3,out_h,out_w] fp32.  The caller computes new_w/new_h/top/left
+ * with the reference's formula (effocr_amd/localizer_engine.py letterbox_geometry). */
+int effocr_letterbox(const uint8_t* image_dev, int height, int width, int64_t row_stride, int bgr, int out_h, int out_w, int new_h,
+                     int new_w, int top, int left, float* out_dev, void* stream);
+/* EffLocalizer.non_max_suppression (localizer_engine.py:171-277; single-label branch, no masks) for ONE image:
+ * pred_dev [n, 5 + num_classes] -> out_dev [<= max_det, 6] = (x1, y1, x2, y2, conf, cls) in confidence order, *count_dev rows.
+ * objectness > conf_thres, conf = obj * best class > conf_thres, at most max_nms (<= 32768) boxes by confidence, boxes offset by
+ * cls * max_wh unless agnostic, greedy IoU > iou_thres suppression (torchvision.ops.nms), first max_det.  Equal confidences rank
+ * by ascending prediction row (the reference's argsort leaves that order open). */
+size_t effocr_nms_workspace_bytes(int n, int max_nms);
+int effocr_nms(const float* pred_dev, int n, int num_classes, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh,
+               int agnostic, float* out_dev, int* count_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Individual encoder operators (exported so that each kernel is parity-tested on its own).
  * Operand buffers are in `precision`'s element type unless stated fp32.
  * ------------------------------------------------------------------------------------------ */

@@ -378,3 +378,44 @@ def test_bench_self_launch_and_scaling_flags():
     assert [shard_bounds(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
     src = open(spec.origin).read()
     assert "torch.distributed.run" in src and "subprocess.call" in src
+
+
+def test_yolov5s_table_and_letterbox_geometry():
+    """The layer table has ultralytics' published YOLOv5s (v6) size — 7,235,389 parameters at 80 classes ("YOLOv5s summary:
+    270 layers, 7235389 parameters") — and letterbox_geometry is the arithmetic of localizer_engine.py:107-138."""
+    from effocr_amd.localizer_engine import init_yolov5s_state_dict, letterbox_geometry, yolov5s_param_shapes
+    from oracle import yolo_ref as Y
+    sh = yolov5s_param_shapes(80)
+    n = sum(int(np.prod(v)) for k, v in sh.items() if not k.endswith(("running_mean", "running_var", "anchors")))
+    assert n == 7235389
+    sd = init_yolov5s_state_dict(2, seed=0)
+    assert set(sd) == set(yolov5s_param_shapes(2)) and all(tuple(sd[k].shape) == tuple(v) for k, v in yolov5s_param_shapes(2).items())
+    assert torch.equal(sd["model.0.conv.weight"], init_yolov5s_state_dict(2, seed=0)["model.0.conv.weight"])
+    for hw in [(50, 300), (256, 4096), (640, 640), (1000, 37), (481, 640)]:
+        nh, nw, top, bottom, left, right, ratio, _ = letterbox_geometry(hw, (640, 640), auto=False)
+        im = np.zeros(hw + (3,), dtype=np.uint8)
+        out, r2, _ = Y.letterbox(im, (640, 640), auto=False)
+        assert out.shape[:2] == (nh + top + bottom, nw + left + right) == (640, 640) and r2 == ratio
+    # hand-computed: 50 x 300 -> r = min(12.8, 2.1333) -> 640 x 107, dh = 533 / 2 = 266.5 -> top 266, bottom 267
+    assert letterbox_geometry((50, 300), (640, 640), auto=False)[:6] == (107, 640, 266, 267, 0, 0)
+
+
+def test_yolo_oracle_nms_and_resize_hand_cases():
+    """The restated pieces on cases small enough to check by hand."""
+    from oracle import yolo_ref as Y
+    # three boxes of one class: B overlaps A (IoU 0.6) and is less confident -> dropped at 0.5, kept at 0.7; C is elsewhere
+    pred = torch.tensor([[[50, 50, 20, 20, 0.9, 0.9, 0.1], [52.5, 50, 20, 20, 0.8, 0.9, 0.1], [200, 50, 20, 20, 0.7, 0.2, 0.9]]])
+    o = Y.non_max_suppression(pred, 0.25, 0.5, max_det=10)[0]
+    assert o.shape == (2, 6) and o[0, :4].tolist() == [40, 40, 60, 60] and abs(o[0, 4] - 0.81) < 1e-6 and o[1, 5] == 1
+    assert Y.non_max_suppression(pred, 0.25, 0.8, max_det=10)[0].shape == (3, 6)
+    # same box, different classes: the class offset keeps both
+    pred2 = torch.tensor([[[50, 50, 20, 20, 0.9, 0.9, 0.1], [50, 50, 20, 20, 0.8, 0.1, 0.9]]])
+    assert Y.non_max_suppression(pred2, 0.25, 0.1, max_det=10)[0].shape == (2, 6)
+    assert Y.non_max_suppression(pred2, 0.25, 0.1, agnostic=True, max_det=10)[0].shape == (1, 6)
+    # objectness passes but obj * cls does not
+    assert Y.non_max_suppression(torch.tensor([[[5, 5, 2, 2, 0.5, 0.5, 0.5]]]), 0.3, 0.5)[0].shape == (0, 6)
+    # 2x upscale of a 1 x 2 image: half-pixel centres -> [a, (3a+b)/4, (a+3b)/4, b] in cv2's fixed point
+    im = np.array([[[0, 0, 0], [200, 100, 40]]], dtype=np.uint8)
+    r = Y.resize_linear_u8(im, 4, 1)
+    assert r[0, :, 0].tolist() == [0, 50, 150, 200] and r[0, :, 1].tolist() == [0, 25, 75, 100]
+    assert np.array_equal(Y.resize_linear_u8(im, 2, 1), im)
