@@ -64,6 +64,7 @@ def _declare(lib):
         "effocr_knn_workspace_bytes": (sz, [i64, i64, i32, i32]),
         "effocr_knn_ip_topk": (i32, [f32p, i64, f32p, i64, i32, i32, f32p, i64p, vp, sz, vp]),
         "effocr_knn_screen_workspace_bytes": (sz, [i64, i64, i32, i32]),
+        "effocr_knn_set_option": (i32, [c.c_char_p, i32]),
         "effocr_knn_screen_flag_offset": (sz, [i64, i64, i32, i32]),
         "effocr_knn_ip_topk_screened": (i32, [f32p, i64, f32p, vp, i64, i32, i32, c.c_float, f32p, i64p, vp, sz, vp]),
         "effocr_convert_bf16": (i32, [f32p, i64, vp, vp]),

@@ -753,6 +753,12 @@ int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void
 
 size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k) { return knn_screen_workspace_bytes(nq, ntotal, d, k); }
 
+int effocr_knn_set_option(const char* name, int value) {
+  if (!name) return fail(EFFOCR_EINVAL, "knn_set_option: NULL name");
+  if (std::string(name) == "force_tile") { knn_force_tile_kernel(value); return EFFOCR_OK; }
+  return fail(EFFOCR_EINVAL, std::string("knn_set_option: unknown option '") + name + "'");
+}
+
 size_t effocr_knn_screen_flag_offset(int64_t nq, int64_t ntotal, int d, int k) { return knn_screen_flag_offset(nq, ntotal, d, k); }
 
 int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, int64_t ntotal, int d, int k,

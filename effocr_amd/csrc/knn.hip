@@ -31,6 +31,7 @@ namespace {
 
 using namespace tile128;
 
+bool g_knn_force_tile = false;        // A/B switch (tests): 1 = always the 128-query tile kernel
 constexpr int ID_NONE = INT_MAX;          // internal sentinel id (ranks after every real id)
 constexpr int MAX_CHUNKS = 256;
 
@@ -67,6 +68,7 @@ struct KnnArgs {
   const float* adist; const float* qnorm; float eps_scale;   // tau[q] = adist[q][k-1] - eps_scale * qnorm[q]
   int* cand; int* cnt; int cap;     // candidate ids [B][cap], counters [B]
   const int* run_flag;              // non-NULL: the launch is a no-op unless *run_flag != 0 (fallback after an overflow)
+  int ring;                         // knn_stream_kernel: LDS-DMA stages per wave
 };
 
 // E = float: exact scores (the product's definition).  E = __bf16: screening scores s^ from bf16-rounded operands
@@ -429,6 +431,206 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
   }
 }
 
+
+// ---- small batches (B <= 32 queries: the reference's per-line calls, infer_effocr.py:313-317): the HBM-bound regime --------
+// The 128-query tile kernel above spends 128 queries' worth of fp32 MFMA whatever B is (1.2 ms per pass over a 1M x 384
+// index: 16 % of the HBM rate).  Here the queries are ONE 32-wide MFMA column tile that lives in LDS for the whole kernel,
+// and the index streams from HBM straight into MFMA A-operand registers — no LDS staging, no barrier in the loop:
+//   * the index goes HBM -> LDS by global_load_lds in fully coalesced pieces (8 rows x 128 bytes per instruction; loading
+//     the row-per-lane MFMA layout straight from memory was address-unit bound at 2.9 TB/s): every WAVE owns a private ring of
+//     32-row x 128-byte stages, so the loop has no workgroup barrier — a wave's own vmcnt orders its DMAs before its reads;
+//   * v_mfma_f32_32x32x2_f32 takes A[row = lane & 31][k = lane >> 5]: the lane pair (r, r + 32) reads the SAME 16 bytes
+//     X[row r][4m .. 4m+3] from the (XOR-swizzled) stage and feeds k = 4m + half, then 4m + 2 + half: two MFMAs per read, k
+//     ascending, so a score is still bit for bit the ascending-k fmaf chain of oracle/flat_ip.c;
+//   * queries: LDS image [m][half][query] of float2 (Q[q][4m + half], Q[q][4m + 2 + half]): one conflict-free ds_read_b64
+//     per two MFMAs;
+//   * a wave owns 32-row blocks of its workgroup's chunk round-robin, two to three stages in flight (64-96 KB per CU);
+//     2 x D/4 MFMAs per block = 16 B/clk/CU of index at the MFMA rate, i.e. the matrix pipe is ~2/3 busy at the HBM rate;
+//   * per-lane sorted top-k lists as above; the 16 partial lists of a query (8 waves x 2 half-waves) merge through LDS,
+//     chunks through knn_merge_kernel.
+constexpr int KS_THREADS = 512;
+template <int KMAX>
+__global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  const int w = wave_id();
+  const int chunk = blockIdx.x;
+  const int D = a.D, nm = D / 4;
+  const float* Q = static_cast<const float*>(a.q);
+  const float* X = static_cast<const float*>(a.xb);
+  f32x2* sQ = reinterpret_cast<f32x2*>(smem);                       // [nm][2][32]
+  for (int id = tid; id < nm * 64; id += KS_THREADS) {
+    const int q = id & 31, h = (id >> 5) & 1, m = id >> 6;
+    f32x2 v = {0.f, 0.f};
+    if (q < a.B) { v[0] = Q[(int64_t)q * D + 4 * m + h]; v[1] = Q[(int64_t)q * D + 4 * m + 2 + h]; }
+    sQ[id] = v;
+  }
+  __syncthreads();
+
+  float ls[KMAX];
+  int li[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) { ls[t] = -FLT_MAX; li[t] = ID_NONE; }
+
+  const int row_lo = chunk * a.tiles_per_chunk * 128;
+  int row_hi = row_lo + a.tiles_per_chunk * 128;
+  row_hi = row_hi < a.N ? row_hi : a.N;
+  const f32x2* qp = sQ + half * 32 + r31;
+  constexpr int NWAVE = KS_THREADS / 64;
+  constexpr int WSTEP = NWAVE * 32;                                 // rows between a wave's consecutive blocks
+  constexpr int STG = 4096;                                         // one stage: 32 rows x 128 bytes (32 k)
+  const int nsl = D / 32;                                           // stages (k slabs) per row block
+  const int R = a.ring;                                             // stages per wave (2..4), sized by the launcher to fit the LDS
+  char* ring = smem + (size_t)D * 128 + (size_t)w * R * STG;
+  // stream of this wave: stage t = (block t / nsl, slab t % nsl).  DMA: 4 x global_load_lds, lane -> (row 8i + lane / 8,
+  // chunk lane % 8); the SOURCE chunk is XOR-swizzled with the row so that the row-per-lane fragment reads below hit
+  // different banks (the LDS destination of a DMA is always lane-linear).
+  const int nblk = row_lo + w * 32 < row_hi ? (row_hi - row_lo - w * 32 + WSTEP - 1) / WSTEP : 0;
+  const int nst = nblk * nsl;
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    const int blk = t / nsl, sl = t - blk * nsl;
+    const int r0i = row_lo + w * 32 + blk * WSTEP;
+    char* dst = ring + (t % R) * STG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = 8 * i + (lane >> 3);
+      int row = r0i + rl;
+      row = row < a.N ? row : a.N - 1;                              // clamp: rows past the end are masked below
+      const char* src = reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + (((lane & 7) ^ (rl & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+  for (int t = 0; t < R - 1 && t < nst; ++t) issue(t);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int sl = 0, r0 = row_lo + w * 32;
+  for (int t = 0; t < nst; ++t) {
+    // stage t has landed when at most the younger stages' pieces are outstanding (own DMAs only: no barrier needed)
+    const int younger = (nst - 1 - t) < (R - 2) ? (nst - 1 - t) : (R - 2);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* st = ring + (t % R) * STG + r31 * 128;
+    f32x4 xv[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) xv[m] = *reinterpret_cast<const f32x4*>(st + ((m ^ (r31 & 7)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ... and the fragments of stage t-1 are long consumed:
+    if (t + R - 1 < nst) issue(t + R - 1);                          // its slot takes stage t+R-1
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const f32x2 qv = qp[(sl * 8 + m) * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][1] : xv[m][0], qv[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][3] : xv[m][2], qv[1], acc, 0, 0, 0);
+    }
+    if (++sl == nsl) {
+      // C layout: col = query (r31), rows = index rows (r & 3) + 8 (r >> 2) + 4 half, ascending with r
+      uint32_t hits = 0;
+      const float thr = ls[KMAX - 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        hits |= (n < a.N && acc[r] > thr) ? (1u << r) : 0u;
+      }
+      if (__any(hits != 0)) {
+        float cand[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cand[r] = acc[r];
+#pragma unroll 1
+        for (int bsel = 0; bsel < 16; ++bsel) {
+          const bool mine = (hits >> bsel) & 1u;
+          if (__any(mine)) {
+            const int n = r0 + (bsel & 3) + 8 * (bsel >> 2) + 4 * half;
+            const float sc = cand[bsel];
+            if (mine) topk_insert<KMAX>(ls, li, sc, n);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      sl = 0; r0 += WSTEP;
+    }
+  }
+
+  // ---- merge the 16 partial lists of every query through LDS (the query image is dead)
+  __syncthreads();
+  constexpr int NSRC = (KS_THREADS / 64) * 2;
+  float* mS = reinterpret_cast<float*>(smem);                       // [32][NSRC][KMAX]
+  int* mI = reinterpret_cast<int*>(smem + 32 * NSRC * KMAX * 4);
+  {
+    const int src = w * 2 + half;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      mS[(r31 * NSRC + src) * KMAX + t] = ls[t];
+      mI[(r31 * NSRC + src) * KMAX + t] = li[t];
+    }
+  }
+  __syncthreads();
+  if (tid < 32 && tid < a.B) {
+    const float* s0 = mS + tid * NSRC * KMAX;
+    const int* i0 = mI + tid * NSRC * KMAX;
+    int ptr[NSRC];
+#pragma unroll
+    for (int c = 0; c < NSRC; ++c) ptr[c] = 0;
+    const int nout = (a.nchunks == 1) ? a.k : KMAX;
+    for (int o = 0; o < nout; ++o) {
+      float bs = -FLT_MAX; int bi = ID_NONE; int bsrc = -1;
+      if (o < KMAX) {
+#pragma unroll
+        for (int c = 0; c < NSRC; ++c) {
+          if (ptr[c] < KMAX) {
+            const float sc = s0[c * KMAX + ptr[c]]; const int ic = i0[c * KMAX + ptr[c]];
+            if (bsrc < 0 || before(sc, ic, bs, bi)) { bs = sc; bi = ic; bsrc = c; }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NSRC; ++c) ptr[c] += (c == bsrc);
+      }
+      if (a.nchunks == 1) {
+        a.dist[(int64_t)tid * a.k + o] = bs;
+        a.idx[(int64_t)tid * a.k + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
+      } else {
+        const int64_t off = ((int64_t)chunk * a.B + tid) * KMAX + o;
+        a.pdist[off] = bs;
+        a.pidx[off] = bi;
+      }
+    }
+  }
+}
+
+template <int KMAX>
+int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
+  KnnArgs a = a_in;
+  const size_t q_bytes = (size_t)a.D * 128, m_bytes = (size_t)32 * (KS_THREADS / 64) * 2 * KMAX * 8;
+  int ring = (int)((160 * 1024 - q_bytes) / ((KS_THREADS / 64) * 4096));
+  ring = ring > 4 ? 4 : ring;
+  if (ring < 2) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim too large for the LDS image");
+  a.ring = ring;
+  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * ring * 4096;
+  const size_t lds = s_bytes > m_bytes ? s_bytes : m_bytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((knn_stream_kernel<KMAX>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
+  int rc = check_launch("knn_stream");
+  if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
+  hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
+                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag);
+  return check_launch("knn_merge");
+}
+int launch_knn_stream_k(int kmax, const KnnArgs& a, hipStream_t s) {
+  switch (kmax) {
+    case 1: return launch_knn_stream<1>(a, s);
+    case 16: return launch_knn_stream<16>(a, s);
+    case 32: return launch_knn_stream<32>(a, s);
+  }
+  return fail(EFFOCR_EINVAL, "knn: internal");
+}
+
 }  // namespace
 
 size_t knn_workspace_bytes(int64_t B, int64_t N, int D, int k) {
@@ -455,6 +657,8 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
   a.pidx = reinterpret_cast<int*>(static_cast<char*>(ws) + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
   a.dist = dist; a.idx = idx;
   if (N == 0) { a.tiles_per_chunk = 0; a.nchunks = 1; }
+  // up to 32 queries against a large index: the streaming kernel (HBM-bound); same chunking, same merge, same bits
+  if (B <= 32 && N >= 4096 && D <= 768 && !g_knn_force_tile) return launch_knn_stream_k(p.kmax, a, s);
   return launch_knn_k<float>(p.kmax, a, s);
 }
 
@@ -479,6 +683,7 @@ size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B <= 0 || k <= 0) return 0;
   return screen_ws(B, N, D, k).total;
 }
+void knn_force_tile_kernel(int on) { g_knn_force_tile = on != 0; }
 size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k) {
   if (B <= 0 || k <= 0) return 0;
   return screen_ws(B, N, D, k).flag;

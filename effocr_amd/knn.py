@@ -93,10 +93,13 @@ class IndexFlatIP:
             if self.screen == "auto" and self.screen_overflows >= self.SCREEN_MAX_OVERFLOWS:
                 self.screen = False
 
-    def _use_screen(self, k):
+    def _use_screen(self, k, nq=None):
         if self.screen is False or self.d % 64 != 0 or k > 32 or self.ntotal < max(k, 1):
             return False
-        return True if self.screen is True else self.ntotal >= self.SCREEN_MIN_ROWS
+        if self.screen is True:
+            return True
+        # up to 32 queries (one text line) the exact search streams the fp32 rows once at the HBM rate: nothing to screen
+        return self.ntotal >= self.SCREEN_MIN_ROWS and (nq is None or nq > 32)
 
     def _screen_copy(self):
         if self._xb16 is None:
@@ -141,7 +144,7 @@ class IndexFlatIP:
         if n == 0:
             return D, I
         self._poll_overflow()
-        if self._use_screen(k):
+        if self._use_screen(k, n):
             xb16 = self._screen_copy()
             need = int(self._L.effocr_knn_screen_workspace_bytes(n, self.ntotal, self.d, k))
             with torch.cuda.device(self.device):

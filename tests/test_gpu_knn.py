@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from effocr_amd import _lib
 from oracle import knn_ref
 
 pytestmark = pytest.mark.gpu
@@ -171,10 +172,39 @@ def test_screened_auto_threshold_and_invalidation(dev):
     assert not idx._use_screen(10)
     idx.add(torch.nn.functional.normalize(torch.randn(70_000, 128, device=dev), dim=1))
     assert idx._use_screen(10) and not idx._use_screen(33)
-    q = idx._xb[:4].clone()
+    assert idx._use_screen(10, 33) and not idx._use_screen(10, 32)          # <= 32 queries: the exact streaming kernel, nothing to screen
+    q = idx._xb[:40].clone()
     D1, I1 = idx.search_device(q, 5)
-    assert idx._xb16 is not None and (I1[:, 0].cpu() == torch.arange(4)).all()
+    assert idx._xb16 is not None and (I1[:, 0].cpu() == torch.arange(40)).all()
+    q = q[:4]
     idx.remove_ids(np.array([0]))
     assert idx._xb16 is None
     D2, I2 = idx.search_device(q[1:], 5)
     assert (I2[:, 0].cpu() == torch.arange(3)).all()        # rows shifted down by one
+
+
+@pytest.mark.parametrize("B,N,D,k", [(1, 5000, 384, 10), (16, 70001, 384, 10), (32, 4096, 512, 1), (7, 200000, 768, 32), (32, 33333, 128, 16), (5, 4100, 1024, 10)])
+def test_streaming_kernel_small_batches_bit_exact(hip_lib, dev, B, N, D, k):
+    """<= 32 queries against >= 4096 rows run the streaming kernel (index rows straight into MFMA operands at the HBM rate):
+    scores and ids bit-identical to the C oracle AND to the 128-query tile kernel (A/B switch), incl. planted exact ties."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator().manual_seed(B + N + D)
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    X[N // 2] = X[3]
+    X[N - 1] = X[3]                                         # three identical rows: ids 3 < N/2 < N-1 must come out in this order
+    Q = torch.nn.functional.normalize(X[:B] + 0.05 * torch.randn(B, D, generator=g), dim=1)
+    if B > 3:
+        Q[3] = X[3]
+    idx = IndexFlatIP(D, device=dev, screen=False)
+    idx.add(X)
+    Dv, Iv = idx.search_device(Q.to(dev), k)
+    D_ref, I_ref = knn_ref.flat_ip_search(Q.numpy(), X.numpy(), k)
+    assert np.array_equal(Iv.cpu().numpy(), I_ref)
+    assert np.array_equal(Dv.cpu().numpy().view(np.uint32), D_ref.view(np.uint32))
+    _lib.check(hip_lib.effocr_knn_set_option(b"force_tile", 1), "knn_set_option")
+    try:
+        Dt, It = idx.search_device(Q.to(dev), k)
+    finally:
+        _lib.check(hip_lib.effocr_knn_set_option(b"force_tile", 0), "knn_set_option")
+    assert torch.equal(It, Iv) and torch.equal(Dt.view(torch.int32), Dv.view(torch.int32))
+    assert hip_lib.effocr_knn_set_option(b"nope", 1) == -1

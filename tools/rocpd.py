@@ -8,6 +8,8 @@ FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of a wide co
 import json, os, re, sqlite3, sys
 
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
+    ("qkvattn_kernel", "qkv_attn_fused"), ("knn_stream_kernel", "knn_stream"), ("knn_rerank", "knn_rerank"), ("knn_prep", "knn_prep"),
+    ("layernorm_blocked_kernel", "layernorm_blocked"), ("conv_igemm", "conv_igemm"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi12ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "mlp_fused_tail"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "mlp_fused_tail"), ("mlp_reduce_kernel", "mlp_fused_reduce"),
     ("rowlin_kernel", "rowlin"), ("layernorm_blocked", "layernorm_blocked"),
@@ -45,9 +47,12 @@ def pmc_by_kernel(db):
 
 def main(tag):
     src = f"gpurun_out/prof_{tag}"
+    if not os.path.isdir(src):
+        raise SystemExit(f"{src} not found (run tools/prof.sh {tag} on the GPU box first)")
     os.makedirs("profiles", exist_ok=True)
     with open(f"profiles/{tag}_kernel_stats.txt", "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (1x MI355X, tag {tag})\n")
+        cmdline = open(f"{src}/cmd.txt").read().strip() if os.path.exists(f"{src}/cmd.txt") else "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {cmdline}   (1x MI355X, tag {tag})\n")
         f.write("# durations from the rocpd 'kernels' view; 5 timed + 2 warm-up + 1 profiled step => 8 forwards x 12 blocks = 96 launches per block kernel\n")
         stats(f"{src}/stats/stats_results.db", f)
     allc = {}
@@ -61,7 +66,7 @@ def main(tag):
         f.write(f"# rocprofv3 --kernel-trace --pmc <set> (one pass per set, no other trace domain), per-dispatch averages, tag {tag}\n")
         f.write("# SQ_* cycle counters are quad-cycles summed over waves/SEs; SQ_VALU_MFMA_BUSY_CYCLES = 32 x N_mfma; FETCH/WRITE_SIZE in KB\n")
         for k, d in sorted(allc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-            if not any(s in k for s in ("panel", "gemm", "attention", "knn_partial", "mlp", "rowlin")):
+            if not any(s in k for s in ("panel", "gemm", "attention", "knn", "mlp", "rowlin", "qkv", "layernorm")):
                 continue
             f.write(f"\n[{k}]\n")
             for c in ctrs:
