@@ -436,15 +436,16 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
 // The 128-query tile kernel above spends 128 queries' worth of fp32 MFMA whatever B is (1.2 ms per pass over a 1M x 384
 // index: 16 % of the HBM rate).  Here the queries are ONE 32-wide MFMA column tile that lives in LDS for the whole kernel,
 // and the index streams from HBM straight into MFMA A-operand registers — no LDS staging, no barrier in the loop:
-//   * the index goes HBM -> LDS by global_load_lds in fully coalesced pieces (8 rows x 128 bytes per instruction; loading
-//     the row-per-lane MFMA layout straight from memory was address-unit bound at 2.9 TB/s): every WAVE owns a private ring of
-//     32-row x 128-byte stages, so the loop has no workgroup barrier — a wave's own vmcnt orders its DMAs before its reads;
+//   * the index is read in fully coalesced pieces (8 rows x 128 bytes per instruction; loading the row-per-lane MFMA layout
+//     straight from memory was address-unit bound at 2.9 TB/s, and an LDS-DMA ring was latency bound at 3.5 TB/s: the bytes
+//     in flight were capped by the LDS left next to the query image): four 32-row x 128-byte stages per wave wait in
+//     REGISTERS (128 KB in flight per CU) and pass through a wave-private LDS buffer only to be transposed;
 //   * v_mfma_f32_32x32x2_f32 takes A[row = lane & 31][k = lane >> 5]: the lane pair (r, r + 32) reads the SAME 16 bytes
 //     X[row r][4m .. 4m+3] from the (XOR-swizzled) stage and feeds k = 4m + half, then 4m + 2 + half: two MFMAs per read, k
 //     ascending, so a score is still bit for bit the ascending-k fmaf chain of oracle/flat_ip.c;
 //   * queries: LDS image [m][half][query] of float2 (Q[q][4m + half], Q[q][4m + 2 + half]): one conflict-free ds_read_b64
 //     per two MFMAs;
-//   * a wave owns 32-row blocks of its workgroup's chunk round-robin, two to three stages in flight (64-96 KB per CU);
+//   * a wave owns 32-row blocks of its workgroup's chunk round-robin; no workgroup barrier inside the loop;
 //     2 x D/4 MFMAs per block = 16 B/clk/CU of index at the MFMA rate, i.e. the matrix pipe is ~2/3 busy at the HBM rate;
 //   * per-lane sorted top-k lists as above; the 16 partial lists of a query (8 waves x 2 half-waves) merge through LDS,
 //     chunks through knn_merge_kernel.
@@ -480,52 +481,60 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   constexpr int NWAVE = KS_THREADS / 64;
   constexpr int WSTEP = NWAVE * 32;                                 // rows between a wave's consecutive blocks
   constexpr int STG = 4096;                                         // one stage: 32 rows x 128 bytes (32 k)
-  const int nsl = D / 32;                                           // stages (k slabs) per row block
-  const int R = a.ring;                                             // stages per wave (2..4), sized by the launcher to fit the LDS
-  char* ring = smem + (size_t)D * 128 + (size_t)w * R * STG;
-  // stream of this wave: stage t = (block t / nsl, slab t % nsl).  DMA: 4 x global_load_lds, lane -> (row 8i + lane / 8,
-  // chunk lane % 8); the SOURCE chunk is XOR-swizzled with the row so that the row-per-lane fragment reads below hit
-  // different banks (the LDS destination of a DMA is always lane-linear).
+  constexpr int P = 4;                                              // stages in flight per wave, in REGISTERS (16 KB per wave, 128 KB per CU)
+  const int nsl = D / 32;                                           // stages (k slabs) per row block; D % 128 == 0 -> P divides it
+  char* stg = smem + (size_t)D * 128 + (size_t)w * 2 * STG;        // the wave's private transpose buffer (two stages)
+  // stream of this wave: stage t = (block t / nsl, slab t % nsl).  A stage is fetched by 4 fully coalesced 16-byte loads per
+  // lane (lane -> row 8i + lane / 8, chunk lane % 8: 8 rows x 128 contiguous bytes per instruction), parked in registers
+  // while P - 1 older stages are consumed, then transposed through the wave's LDS buffer into the row-per-lane MFMA layout.
+  // The chunk position is XOR-swizzled with the row so that both the writes and the fragment reads spread over the banks.
+  // Everything is wave-private: no workgroup barrier in the loop, and ordinary loads let the compiler count vmcnt itself.
   const int nblk = row_lo + w * 32 < row_hi ? (row_hi - row_lo - w * 32 + WSTEP - 1) / WSTEP : 0;
   const int nst = nblk * nsl;
-  auto issue = [&](int t) __attribute__((always_inline)) {
-    const int blk = t / nsl, sl = t - blk * nsl;
+  f32x4 rg[P][4];
+  auto fetch = [&](f32x4 (&r)[4], int blk, int sl) __attribute__((always_inline)) {
     const int r0i = row_lo + w * 32 + blk * WSTEP;
-    char* dst = ring + (t % R) * STG;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int rl = 8 * i + (lane >> 3);
-      int row = r0i + rl;
+      int row = r0i + 8 * i + (lane >> 3);
       row = row < a.N ? row : a.N - 1;                              // clamp: rows past the end are masked below
-      const char* src = reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + (((lane & 7) ^ (rl & 7)) << 4);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      r[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + ((lane & 7) << 4));
     }
   };
-  for (int t = 0; t < R - 1 && t < nst; ++t) issue(t);
+  int fb = 0, fs = 0;                                               // (block, slab) of the next stage to fetch
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    if (fb < nblk) fetch(rg[u], fb, fs);
+    if (++fs == nsl) { fs = 0; ++fb; }
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   int sl = 0, r0 = row_lo + w * 32;
-  for (int t = 0; t < nst; ++t) {
-    // stage t has landed when at most the younger stages' pieces are outstanding (own DMAs only: no barrier needed)
-    const int younger = (nst - 1 - t) < (R - 2) ? (nst - 1 - t) : (R - 2);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* st = ring + (t % R) * STG + r31 * 128;
-    f32x4 xv[8];
+  const int wr = lane >> 3, wc = lane & 7;
+  for (int t0 = 0; t0 < nst; t0 += P) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) xv[m] = *reinterpret_cast<const f32x4*>(st + ((m ^ (r31 & 7)) << 4));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ... and the fragments of stage t-1 are long consumed:
-    if (t + R - 1 < nst) issue(t + R - 1);                          // its slot takes stage t+R-1
+    for (int u = 0; u < P; ++u) {
+      char* buf = stg + (u & 1) * STG;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const f32x2 qv = qp[(sl * 8 + m) * 64];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][1] : xv[m][0], qv[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][3] : xv[m][2], qv[1], acc, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int rl = 8 * i + wr;
+        *reinterpret_cast<f32x4*>(buf + rl * 128 + ((wc ^ (rl & 7)) << 4)) = rg[u][i];
+      }
+      if (fb < nblk) fetch(rg[u], fb, fs);                           // the slot's next stage (P stages ahead)
+      if (++fs == nsl) { fs = 0; ++fb; }
+      f32x4 xv[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xv[m] = *reinterpret_cast<const f32x4*>(buf + r31 * 128 + ((m ^ (r31 & 7)) << 4));
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const f32x2 qv = qp[((sl + u) * 8 + m) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][1] : xv[m][0], qv[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][3] : xv[m][2], qv[1], acc, 0, 0, 0);
+      }
     }
-    if (++sl == nsl) {
+    sl += P;
+    if (sl == nsl) {
       // C layout: col = query (r31), rows = index rows (r & 3) + 8 (r >> 2) + 4 half, ascending with r
       uint32_t hits = 0;
       const float thr = ls[KMAX - 1];
@@ -604,11 +613,8 @@ template <int KMAX>
 int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   KnnArgs a = a_in;
   const size_t q_bytes = (size_t)a.D * 128, m_bytes = (size_t)32 * (KS_THREADS / 64) * 2 * KMAX * 8;
-  int ring = (int)((160 * 1024 - q_bytes) / ((KS_THREADS / 64) * 4096));
-  ring = ring > 4 ? 4 : ring;
-  if (ring < 2) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim too large for the LDS image");
-  a.ring = ring;
-  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * ring * 4096;
+  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * 2 * 4096;
+  if (s_bytes > 160 * 1024) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim too large for the LDS image");
   const size_t lds = s_bytes > m_bytes ? s_bytes : m_bytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -658,7 +664,7 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
   a.dist = dist; a.idx = idx;
   if (N == 0) { a.tiles_per_chunk = 0; a.nchunks = 1; }
   // up to 32 queries against a large index: the streaming kernel (HBM-bound); same chunking, same merge, same bits
-  if (B <= 32 && N >= 4096 && D <= 768 && !g_knn_force_tile) return launch_knn_stream_k(p.kmax, a, s);
+  if (B <= 32 && N >= 4096 && D % 128 == 0 && D <= 768 && !g_knn_force_tile) return launch_knn_stream_k(p.kmax, a, s);
   return launch_knn_k<float>(p.kmax, a, s);
 }
 
