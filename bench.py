@@ -23,6 +23,8 @@ Extra objects on the line:
                 EffRecognizer.run(numpy) (pinned staging + per-call streams; PCIe-inclusive, 1 and 4 caller threads),
                 plus the k-NN alone at B in {1, 16, 64} against a 1M-row index where HBM is the roof.
   c4            N=1: BASELINE configs[3] — ViT-B/16 + 1M x 768 index: crops/s, per-linear TFLOP/s, k-NN time.
+  c5            N=1: BASELINE configs[4] on one GPU — 4096 x 256 text-line images through the YOLOv5s localizer (letterbox,
+                fp32-MFMA convolutions, NMS on the device), the boxes cropped on the device, ViT-S/16 + k-NN: lines/s, stage times.
 """
 import argparse
 import json
@@ -286,6 +288,8 @@ def main():
                     del enc, x_full, x_shard
                     torch.cuda.empty_cache()
                     line["c4"] = c4_extras(a, dev)
+                    torch.cuda.empty_cache()
+                    line["c5"] = c5_extras(a, dev)
             except Exception as e:                          # extras never take the headline down
                 line["extras_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not a.no_cpu_baseline:
@@ -391,6 +395,88 @@ def c4_extras(a, dev):
             "encoder_ms": round(1e3 * te, 3), "encoder_mfma_frac": round(1024 * FLOP_PER_CROP[arch] / te / MFMA_PEAK[a.precision], 4),
             "kernel_TFLOPs": lin, "knn_ms": round(1e3 * tk, 3),
             "knn_hbm_frac_bf16_two_passes": round(2 * N * D * 2.0 / tk / 8.0e12, 4), "knn_mfma_bf16_frac": round(2 * 2.0 * 1024 * N * D / tk / 2.5e15, 4)}
+
+
+YOLO_STRIDE = {0: 2, 1: 4, 2: 4, 3: 8, 4: 8, 5: 16, 6: 16, 7: 32, 8: 32, 9: 32, 10: 32, 13: 16, 14: 16, 17: 8, 18: 16, 20: 16, 21: 32, 23: 32}
+
+
+def yolov5s_flops(nc, h, w):
+    """2 * MACs of every convolution of the layer table at an h x w input."""
+    from effocr_amd.localizer_engine import yolov5s_param_shapes
+    fl = 0.0
+    for k, shp in yolov5s_param_shapes(nc).items():
+        if not (k.endswith("conv.weight") or (k.startswith("model.24.m.") and k.endswith(".weight"))):
+            continue
+        parts = k.split(".")
+        st = (8, 16, 32)[int(parts[3])] if parts[1] == "24" else YOLO_STRIDE[int(parts[1])]
+        n = 1
+        for v in shp:
+            n *= v
+        fl += 2.0 * n * (h // st) * (w // st)
+    return fl
+
+
+def c5_extras(a, dev):
+    """BASELINE configs[4] (full pipeline) on ONE GPU: synthetic 4096 x 256 uint8 text-line images -> EffLocalizer (device
+    letterbox to 640 x 640, YOLOv5s, NMS) -> character boxes scaled back and double-clipped as infer_effocr_onnx_multi.py:313-318
+    -> device crop transform -> ViT-S/16 (bf16) -> k-NN against the 10k index.  Seeded random localizer weights with the
+    Detect biases raised so that every line yields boxes; at most 64 boxes per line go on (a text line has tens of glyphs)."""
+    import numpy as np
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import FaissKNN, IndexFlatIP
+    from effocr_amd.localizer_engine import EffLocalizer, init_yolov5s_state_dict
+    from effocr_amd.transforms import PairedTransform
+    from effocr_amd.weights import init_state_dict
+    nc = 2
+    sd = init_yolov5s_state_dict(nc, seed=0)
+    for l in range(3):
+        b = sd[f"model.24.m.{l}.bias"].view(3, nc + 5)
+        b[:, 4] += 5.5
+        b[:, 5] += 2.5
+    loc = EffLocalizer(sd, iou_thresh=0.05, conf_thresh=0.5, device=dev)
+    arch = "vit_small_patch16_224"
+    enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=224), img_size=224, precision=a.precision, device=dev)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.train(torch.nn.functional.normalize(torch.randn(a.index_rows, enc.embed_dim, generator=torch.Generator().manual_seed(0)), dim=1))
+    tf = PairedTransform(size=224, device=dev)
+    rng = np.random.default_rng(0)
+    lines = [(rng.integers(0, 256, (256, 4096, 3)) // 32 * 32).astype(np.uint8) for _ in range(8)]
+    H, W = 256, 4096
+
+    def one(im):
+        t0 = time.perf_counter()
+        res = loc([im])[0]
+        t1 = time.perf_counter()
+        chars = res[res[:, -1] == 0][:64, :4]
+        boxes = []
+        for bb in chars:
+            x0, x1 = int(round(float(torch.round(bb[0])) * W / 640)), int(round(float(torch.round(bb[2])) * W / 640))
+            if x1 > x0:
+                boxes.append((max(x0, 0), 0, min(x1, W), H))
+        n = len(boxes)
+        if n:
+            crops = tf.boxes(im, boxes, already_int=True)
+            ids = knn(enc.forward(crops, normalize=True), k=a.k)[1]
+            ids.cpu()
+        torch.cuda.synchronize(dev)
+        return t1 - t0, time.perf_counter() - t1, n
+
+    for im in lines[:2]:
+        one(im)
+    tl = tr = nb = 0
+    for im in lines:
+        a_, b_, n = one(im)
+        tl += a_; tr += b_; nb += n
+    # the localizer network alone, batched, device-resident input
+    x = torch.rand(16, 3, 640, 640, device=dev)
+    tn = _time_gpu(lambda: loc._eng_net.forward(x), dev, 5)
+    fl = yolov5s_flops(nc, 640, 640)
+    return {"workload": "BASELINE configs[4] on 1 GPU: 4096x256 uint8 text-line images -> YOLOv5s localizer (640x640 letterbox, fp32 MFMA, device NMS) "
+                        f"-> <=64 char boxes per line -> device crops -> {arch} ({a.precision}) -> {a.index_rows}-row IndexFlatIP, k={a.k}; seeded random weights",
+            "lines_per_s": round(len(lines) / (tl + tr), 2), "boxes_per_line": round(nb / len(lines), 1),
+            "localizer_ms_per_line": round(1e3 * tl / len(lines), 3), "recognizer_ms_per_line": round(1e3 * tr / len(lines), 3),
+            "localizer_network_images_per_s_batch16": round(16 / tn, 1), "localizer_network_ms_per_image": round(1e3 * tn / 16, 3),
+            "localizer_GFLOP_per_image": round(fl / 1e9, 2), "localizer_mfma_fp32_frac": round(16 * fl / tn / 157.3e12, 4)}
 
 
 if __name__ == "__main__":
