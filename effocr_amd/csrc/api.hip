@@ -5,6 +5,10 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#ifndef EFFOCR_EXP
+#define EFFOCR_EXP 0
+#endif
+
 #include <math.h>
 #include <string.h>
 #include <map>
@@ -814,6 +818,7 @@ int effocr_op_ln_linear(int precision, int epilogue, const float* x_dev, const f
   return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
 
+#if EFFOCR_EXP != 0
 // experiment hook: LN-fused linear with an in-kernel timeline buffer (2 x 512 x 4 u64, device)
 int effocr_dbg_ln_linear(int precision, int epilogue, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                          const void* w_dev, const float* bias_dev, void* out_dev, int m, int n, int k, int debug,
@@ -823,6 +828,7 @@ int effocr_dbg_ln_linear(int precision, int epilogue, const float* x_dev, const 
   p.out = out_dev; p.ldo = n; p.M = m; p.N = n; p.K = k; p.debug = debug & 0xff; p.panel_rows = (debug >> 8) & 0xff; p.dbg = dbg_dev;
   return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
+#endif   // experiment builds only (make EXP=n): not part of the shipped ABI
 
 int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev, const void* w_blk_dev, const float* bias_dev,
                              const float* resid_blk_dev, void* out_blk_dev, int m, int n, int k, int rows_alloc, void* stream) {

@@ -218,8 +218,8 @@ class HipLocalizer:
                                                 _lib.ptr(out), _lib.current_stream(self.device)), "effocr_letterbox")
         return out
 
-    def nms(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False):
-        """pred [n, 5 + nc] (one image) -> [m,6] device tensor, m <= max_det (non_max_suppression(...)[0])."""
+    def nms_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False):
+        """pred [n, 5 + nc] (one image) -> (rows [max_det,6], count [1] int32), both on the device, no synchronisation."""
         if not (0 <= conf_thres <= 1):
             raise AssertionError(f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0")
         if not (0 <= iou_thres <= 1):
@@ -230,10 +230,16 @@ class HipLocalizer:
         cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
         need = int(self._L.effocr_nms_workspace_bytes(n, MAX_NMS))
         with self._lock, torch.cuda.device(self.device):
-            ws = self._workspace("nms", need)
+            # one scratch per call in flight: successive images of a batch must not share the candidate lists
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
             _lib.check(self._L.effocr_nms(_lib.ptr(pred), n, self.nc, float(conf_thres), float(iou_thres), int(max_det), MAX_NMS, MAX_WH,
                                           1 if agnostic else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(),
                                           _lib.current_stream(self.device)), "effocr_nms")
+        return out, cnt
+
+    def nms(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False):
+        """pred [n, 5 + nc] (one image) -> [m,6] device tensor, m <= max_det (non_max_suppression(...)[0])."""
+        out, cnt = self.nms_async(pred, conf_thres, iou_thres, max_det, agnostic)
         return out[: int(cnt.item())]
 
 
@@ -265,19 +271,29 @@ class EffLocalizer:
         eng = self._eng_net
         if not isinstance(imgs, (list, tuple)):
             imgs = [imgs]
-        outs = []
+        xs = []
         for img in imgs:
             if isinstance(img, str):
-                x = self.load_localizer_img(img)
+                xs.append(self.load_localizer_img(img))
             elif isinstance(img, np.ndarray) and img.dtype == np.uint8:
-                x = eng.letterbox(img, bgr=False)
+                xs.append(eng.letterbox(img, bgr=False))
             else:
                 x = torch.as_tensor(img)
                 if x.dtype != torch.float32:
                     raise ValueError(f"Unexpected input data type. Actual: {x.dtype}, expected: float32")
                 if x.dim() == 3:
                     x = x.unsqueeze(0)
-                x = x.to(eng.device)
-            pred = eng.forward(x)
-            outs.append(eng.nms(pred[0], self._conf_thresh, self._iou_thresh, max_det=1000).cpu())
-        return outs
+                xs.append(x.to(eng.device))
+        # the reference runs the session image by image (localizer_engine.py:52); here the letterboxed images go through the
+        # network in batches of up to 16 and the per-image NMS launches are queued back to back: ONE synchronisation per call
+        rows, cnts = [], []
+        for b0 in range(0, len(xs), 16):
+            pred = eng.forward(torch.cat(xs[b0:b0 + 16], dim=0))
+            for i in range(pred.shape[0]):
+                r, c = eng.nms_async(pred[i], self._conf_thresh, self._iou_thresh, max_det=1000)
+                rows.append(r)
+                cnts.append(c)
+        if not rows:
+            return []
+        counts = torch.cat(cnts).cpu().tolist()
+        return [r[:n].cpu() for r, n in zip(rows, counts)]

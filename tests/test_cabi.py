@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound(hip_lib):
     raw = ctypes.CDLL(_lib.SO_PATH)
     for n in names:
         assert hasattr(raw, n), f"{n} declared in effocr_hip.h but not exported"
-    assert set(_lib.EXPORTS) <= set(names) | {"effocr_dbg_ln_linear"}
+    assert set(_lib.EXPORTS) <= set(names)
     assert hip_lib.effocr_abi_version() == 1
 
 

@@ -1,3 +1,4 @@
+# needs an experiment build of the library (make -C effocr_amd/csrc EXP=1): effocr_dbg_ln_linear is compiled out of the shipped .so
 """experiment: timeline of two workgroups of the panel kernel (s_memtime stamps; build with EXP=9)."""
 import ctypes, sys, math, torch, statistics
 from effocr_amd import _lib
