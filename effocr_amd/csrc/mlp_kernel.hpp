@@ -35,8 +35,8 @@
 #endif
 // timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
 // the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 no residual loads after the projection,
-// 256 no stores of the second output, 512 second output skipped altogether
-#if EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000
+// 256 no stores of the second output, 512 second output skipped altogether, 4096 weight stream from 128 KB only (L2-hot)
+#if (EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000) || (EFFOCR_EXP >= 4000 && EFFOCR_EXP < 12000)
 #define MLX (EFFOCR_EXP - 2000)
 #else
 #define MLX 0
@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * (c0 + c) + 8 * kh) * 512;
   };
   auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS
+#if (MLX & 4096)
+    const char* src = stage_src(s & 7) + lane * 16;      // experiment: the whole stream re-reads the first 8 stages (128 KB: always L2-hot)
+#else
     const char* src = stage_src(s) + lane * 16;
+#endif
     char* dst = sW + (s & (R - 1)) * MLP_STAGE + w * 4096;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);

@@ -42,6 +42,26 @@ __global__ __launch_bounds__(512, 2) void k_glds(const char* __restrict__ w, siz
   if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<float*>(smem);
 }
 
+// mode 2: the same L2-resident stream by ORDINARY loads (16 B/lane to VGPRs, UNR loads in flight per lane), contiguous 1 KB per wave
+// instruction: is the ~37 GB/s per CU of the LDS-DMA path a property of global_load_lds or of the L2 -> CU path?
+template <int UNR>
+__global__ __launch_bounds__(512, 2) void k_plain(const char* __restrict__ w, size_t wbytes, int iters, float* sink) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  size_t off = (size_t)wv * UNR * 1024;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (int it = 0; it < iters; ++it) {
+    u32x4 v[UNR];
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) v[i] = *reinterpret_cast<const u32x4*>(w + off + i * 1024 + lane * 16);
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) acc ^= v[i];
+    off += (size_t)8 * UNR * 1024;
+    if (off + (size_t)UNR * 1024 > wbytes) off = (size_t)wv * UNR * 1024;
+  }
+  if (acc[0] == 0x12345678u && acc[3] == 7u) sink[blockIdx.x] = 1.f;
+}
+
 // mode 1: stores.  STRIDED: lane (t = lane&31, half) writes BYTES at row t (row pitch `pitch`), + half*BYTES
 //         contiguous: lane writes BYTES at base + lane*BYTES
 template <int BYTES, bool STRIDED>
@@ -82,6 +102,10 @@ int main() {
 #define GL(P, R, B) { float ms = timeit([&] { hipLaunchKernelGGL((k_glds<P, R, B>), dim3(NCU), dim3(512), 0, 0, w, wbytes, iters, sink); }); \
     double bytes = (double)iters * 8 * P * 1024; printf("  pieces/wave %d rowB %3d barrier %d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  chip %5.2f TB/s  (%.0f cyc/iter)\n", P, R, (int)B, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, bytes * NCU / (ms * 1e-3) / 1e12, ms * 1e-3 * clk / iters); }
   GL(1, 64, false) GL(2, 64, false) GL(2, 128, false) GL(2, 64, true) GL(2, 128, true) GL(4, 128, false) GL(4, 128, true) GL(8, 128, false) GL(8, 128, true)
+  printf("== ordinary global_load_dwordx4 from the same buffer (1 KB contiguous per wave instruction), 256 workgroups x 8 waves\n");
+#define PL(U) { float ms = timeit([&] { hipLaunchKernelGGL((k_plain<U>), dim3(NCU), dim3(512), 0, 0, w, wbytes, iters, sink); }); \
+    double bytes = (double)iters * 8 * U * 1024; printf("  loads in flight/lane %2d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  chip %5.2f TB/s\n", U, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, bytes * NCU / (ms * 1e-3) / 1e12); }
+  PL(1) PL(2) PL(4) PL(8)
   printf("== stores, 256 workgroups x 8 waves; each store instruction = 64 lanes\n");
   const int sit = 200, per = 16;
 #define ST(BY, STR, PITCH) { float ms = timeit([&] { hipLaunchKernelGGL((k_store<BY, STR>), dim3(NCU), dim3(512), 0, 0, out, (size_t)PITCH, sit, per); }); \
