@@ -42,6 +42,64 @@ __global__ __launch_bounds__(512, 2) void k_glds(const char* __restrict__ w, siz
   if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<float*>(smem);
 }
 
+// mode 3: the LDS-DMA stream through BUFFER instructions (SGPR resource + 32-bit per-lane offset instead of a 64-bit per-lane address)
+template <int PIECES>
+__global__ __launch_bounds__(512, 2) void k_bufglds(const char* __restrict__ w, size_t wbytes, int iters, float* sink) {
+  constexpr int NSLOT = (150 / (8 * PIECES)) >= 3 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[150 * 1024];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, (int)wbytes, 0x00020000);
+  const size_t stage_bytes = (size_t)8 * PIECES * 1024;
+  unsigned off = 0;
+  for (int it = 0; it < iters; ++it) {
+    char* dst = smem + (it % NSLOT) * stage_bytes;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int piece = wv * PIECES + i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, lane * 16, (int)(off + piece * 1024), 0, 0);
+    }
+    if (PIECES == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    off += (unsigned)stage_bytes;
+    if (off + stage_bytes > wbytes) off = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<float*>(smem);
+}
+
+// the same with global_load_lds and fully contiguous 1 KB pieces (the blocked weight copies of the product kernels)
+template <int PIECES, int THREADS>
+__global__ __launch_bounds__(THREADS, 1) void k_glds_contig(const char* __restrict__ w, size_t wbytes, int iters, float* sink) {
+  constexpr int NW = THREADS / 64;
+  __shared__ __attribute__((aligned(16))) char smem[3 * NW * PIECES * 1024];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t stage_bytes = (size_t)NW * PIECES * 1024;
+  size_t off = 0;
+  for (int it = 0; it < iters; ++it) {
+    char* dst = smem + (it % 3) * stage_bytes;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int piece = wv * PIECES + i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + off + piece * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+    if (PIECES == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    off += stage_bytes;
+    if (off + stage_bytes > wbytes) off = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<float*>(smem);
+}
+
 // mode 2: the same L2-resident stream by ORDINARY loads (16 B/lane to VGPRs, UNR loads in flight per lane), contiguous 1 KB per wave
 // instruction: is the ~37 GB/s per CU of the LDS-DMA path a property of global_load_lds or of the L2 -> CU path?
 template <int UNR>
@@ -102,6 +160,14 @@ int main() {
 #define GL(P, R, B) { float ms = timeit([&] { hipLaunchKernelGGL((k_glds<P, R, B>), dim3(NCU), dim3(512), 0, 0, w, wbytes, iters, sink); }); \
     double bytes = (double)iters * 8 * P * 1024; printf("  pieces/wave %d rowB %3d barrier %d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  chip %5.2f TB/s  (%.0f cyc/iter)\n", P, R, (int)B, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, bytes * NCU / (ms * 1e-3) / 1e12, ms * 1e-3 * clk / iters); }
   GL(1, 64, false) GL(2, 64, false) GL(2, 128, false) GL(2, 64, true) GL(2, 128, true) GL(4, 128, false) GL(4, 128, true) GL(8, 128, false) GL(8, 128, true)
+  printf("== LDS-DMA by buffer_load ... lds (SGPR resource + 32-bit offsets), contiguous 1 KB pieces, 8 waves\n");
+#define BG(P) { float ms = timeit([&] { hipLaunchKernelGGL((k_bufglds<P>), dim3(NCU), dim3(512), 0, 0, w, wbytes, iters, sink); }); \
+    double bytes = (double)iters * 8 * P * 1024; printf("  pieces/wave %d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  (%.0f cyc/iter)\n", P, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, ms * 1e-3 * clk / iters); }
+  BG(1) BG(2) BG(4) BG(8)
+  printf("== LDS-DMA by global_load_lds, contiguous 1 KB pieces: 8 waves vs 4 waves (one per SIMD, the fused-MLP / gemm3 geometry)\n");
+#define GC(P, T) { float ms = timeit([&] { hipLaunchKernelGGL((k_glds_contig<P, T>), dim3(NCU), dim3(T), 0, 0, w, wbytes, iters, sink); }); \
+    double bytes = (double)iters * (T / 64) * P * 1024; printf("  %d waves, pieces/wave %d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  (%.0f cyc/iter, %.0f cyc per piece per wave)\n", T / 64, P, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, ms * 1e-3 * clk / iters, ms * 1e-3 * clk / iters / P); }
+  GC(4, 512) GC(4, 256) GC(8, 256) GC(2, 256)
   printf("== ordinary global_load_dwordx4 from the same buffer (1 KB contiguous per wave instruction), 256 workgroups x 8 waves\n");
 #define PL(U) { float ms = timeit([&] { hipLaunchKernelGGL((k_plain<U>), dim3(NCU), dim3(512), 0, 0, w, wbytes, iters, sink); }); \
     double bytes = (double)iters * 8 * U * 1024; printf("  loads in flight/lane %2d: %7.1f us  %6.1f GB/s/CU  %5.1f B/clk/CU  chip %5.2f TB/s\n", U, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / clk, bytes * NCU / (ms * 1e-3) / 1e12); }
