@@ -113,6 +113,36 @@ template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (
   constexpr int DEG = lo ? 6 : 8;
   constexpr float c6[7] = {3.986083969e-01f, -6.556460269e-02f, 9.218763890e-03f, -9.056357457e-04f, 5.740218682e-05f, -2.075315505e-06f, 3.214920233e-08f};
   constexpr float c8[9] = {3.989074382e-01f, -6.636037144e-02f, 9.830130026e-03f, -1.114147779e-03f, 9.457434347e-05f, -5.760762241e-06f, 2.343669162e-07f, -5.633299462e-09f, 5.998041464e-11f};
+  if constexpr (N == 8) {
+    // Eight values = FOUR packed chains kept in lock step.  A v_pk_fma_f32 consuming the previous packed result needs a wait
+    // state; left alone the scheduler walks one chain at a time to save registers (an s_nop behind every packed FMA: 277 per
+    // 192 MFMAs in the fused MLP's loop), and a sched_barrier does not survive instruction selection — the empty asm with
+    // every chain value as an in/out operand does.  Same arithmetic, value for value, as the scalar form below.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 u[4], t[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i] = f32x2{__builtin_amdgcn_fmed3f(x[2 * i], -L, L), __builtin_amdgcn_fmed3f(x[2 * i + 1], -L, L)};
+      t[i] = u[i] * u[i];
+      const float ch = lo ? c6[DEG] : c8[DEG], cl = lo ? c6[DEG - 1] : c8[DEG - 1];
+      p[i] = __builtin_elementwise_fma(f32x2{ch, ch}, t[i], f32x2{cl, cl});
+    }
+#pragma unroll
+    for (int k = DEG - 2; k >= 0; --k) {
+      asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+      const float ck = lo ? c6[k] : c8[k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{ck, ck});
+    }
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 xv = {x[2 * i], x[2 * i + 1]};
+      const f32x2 r = xv * __builtin_elementwise_fma(u[i], p[i], f32x2{0.5f, 0.5f});
+      x[2 * i] = r[0]; x[2 * i + 1] = r[1];
+    }
+    return;
+  }
   float u[N], t[N], p[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {

@@ -241,21 +241,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   // pre-activations (bias added, rounded to the operand type: "parked"), then GELU'd IN PLACE, 4 values at a time.
   // (Two alternating sets, with the GELU spread over both phases, do not fit next to the 96 VGPRs of xn: spills.)
   struct HSet { u32x4 u[8]; };
-  // half-unit q (0..15) = words 2*(q&1), 2*(q&1)+1 of unit q>>1: 4 values (keeps the polynomial's temporaries to 16 VGPRs)
+  // unit q (0..7) = 8 values = four independent v_pk_fma_f32 Horner chains: a packed FMA needs a wait state before a dependent
+  // packed FMA, and with two chains (4 values at a time) every one of the 224 was followed by an s_nop
   auto gelu_unit = [&](HSet& hs, auto Q) __attribute__((always_inline)) {     // Q: compile-time -> static register indices
-    typedef __attribute__((__vector_size__(4 * sizeof(E)))) E E4;
-    constexpr int u = decltype(Q)::value >> 1, h2 = (decltype(Q)::value & 1) * 2;
-    const u32x2 pw = {hs.u[u][h2], hs.u[u][h2 + 1]};
-    const E4 pv = __builtin_bit_cast(E4, pw);
-    float v[4];
+    typedef __attribute__((__vector_size__(8 * sizeof(E)))) E E8;
+    constexpr int u = decltype(Q)::value;
+    const E8 pv = __builtin_bit_cast(E8, hs.u[u]);
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (float)pv[e];
+    for (int e = 0; e < 8; ++e) v[e] = (float)pv[e];
 #if !(MLX & 4)
-    gelu_fold_n<E, 4>(v);
+    gelu_fold_n<E, 8>(v);
 #endif
-    const u32x2 o = pack4<E>(v[0], v[1], v[2], v[3]);
-    hs.u[u][h2] = o[0];
-    hs.u[u][h2 + 1] = o[1];
+    const u32x2 o0 = pack4<E>(v[0], v[1], v[2], v[3]);
+    const u32x2 o1 = pack4<E>(v[4], v[5], v[6], v[7]);
+    hs.u[u] = u32x4{o0[0], o0[1], o1[0], o1[1]};
   };
   // acc1 (+ bias1 of chunk c) -> set, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
   auto park = [&](HSet& hs, int c) __attribute__((always_inline)) {
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
   static_assert(NC >= 3, "mlp: at least three hidden chunks");
   typedef std::integral_constant<int, FAR> Far;
-  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 16> U16_;
+  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 8> U16_;   // 8 units per chunk
   HSet S;
   phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
   park(S, 0);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
   phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
   park(S, NC - 1);
-  sfor<0, 16>([&](auto Q) { gelu_unit(S, Q); });
+  sfor<0, 8>([&](auto Q) { gelu_unit(S, Q); });
   phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
 
 #if (MLX & 1)
