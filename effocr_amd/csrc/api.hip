@@ -34,7 +34,7 @@ struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std:
 
 struct VitCfg { int D, depth, heads, mlp; };
 struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w;
-                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, fc2w_p, projw_pp, fc2w_pp, projb_p, fc2b_p; };   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // _p: blocked + k permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
+                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, projw_pp, fc2w_pp, projb_p, fc2b_p; };   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // fc2w_pp: k also permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
 struct ConvSpec { std::string w, bn; int cin, cout, k, stride, pad; size_t w_off, b_off; };
 
 }  // namespace
@@ -151,7 +151,6 @@ void build_vit(effocr_encoder* e) {
     for (int i = 0; i < depth; ++i) {
       VitLayerOff& L = e->layers[i];
       L.fc2w_b = a.take((size_t)D * mlp * es);
-      L.fc2w_p = a.take((size_t)D * mlp * es);
       L.fc2w_pp = a.take((size_t)D * mlp * es);
       L.projw_pp = a.take((size_t)D * D * es);
       L.projb_p = a.take((size_t)D * 4);
@@ -278,7 +277,6 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
     put_op(blob, L.fc2w, P(e, p + "mlp.fc2.weight").data(), (size_t)D * e->vit.mlp, e->prec);
     if (e->prec != PREC_FP32) {
       put_op_blocked(blob, L.fc2w_b, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec);
-      put_op_blocked(blob, L.fc2w_p, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec, true);
       put_op_blocked(blob, L.fc2w_pp, P(e, p + "mlp.fc2.weight").data(), D, e->vit.mlp, e->prec, true, true);
       put_op_blocked(blob, L.projw_pp, P(e, p + "attn.proj.weight").data(), D, D, e->prec, false, true);
       put_f32_rowperm(blob, L.projb_p, P(e, p + "attn.proj.bias").data(), D);
@@ -435,10 +433,10 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       if (mlpf) {
         MlpArgs m{};
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
-        m.W2p = wb + L.fc2w_p; m.b2 = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
+        m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
         m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split;   // the hidden buffer is free on this path
         if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
-          m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p); m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b);
+          m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p);
           if (qaf && i + 1 < e->vit.depth) {
             m.xn_out = xn; m.gamma_n = F(e->layers[i + 1].ln1w); m.beta_n = F(e->layers[i + 1].ln1b);
             xn_ready = true;
@@ -842,24 +840,26 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
 }
 
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                          const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                          const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev,
                           int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream) {
-  if (m > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_dev))
+  if (m > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_perm_dev || !b2_dev))
     return fail(EFFOCR_EINVAL, "op_mlp_blocked: NULL device pointer");
   MlpArgs a{};
-  a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_dev;
+  a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_perm_dev;
+  a.b2_logical = b2_dev;
   a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
   return mlp_fused(precision, a, S(stream));
 }
 
 int effocr_op_mlp_ln_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                             const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                             const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev,
                              const float* gamma_next_dev, const float* beta_next_dev, void* xn_blk_dev,
                              int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream) {
-  if (m > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_dev || !gamma_next_dev || !beta_next_dev || !xn_blk_dev))
+  if (m > 0 && (!x_blk_dev || !gamma_dev || !beta_dev || !w1_blk_dev || !b1_dev || !w2_perm_dev || !b2_perm_dev || !b2_dev || !gamma_next_dev || !beta_next_dev || !xn_blk_dev))
     return fail(EFFOCR_EINVAL, "op_mlp_ln_blocked: NULL device pointer");
   MlpArgs a{};
-  a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_dev;
+  a.x = x_blk_dev; a.gamma = gamma_dev; a.beta = beta_dev; a.eps = eps; a.W1b = w1_blk_dev; a.b1 = b1_dev; a.W2p = w2_perm_dev; a.b2 = b2_perm_dev;
+  a.b2_logical = b2_dev;
   a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
   a.xn_out = xn_blk_dev; a.gamma_n = gamma_next_dev; a.beta_n = beta_next_dev;
   return mlp_fused(precision, a, S(stream));

@@ -41,15 +41,16 @@ struct MlpArgs {
   float* x;                         // fp32 residual stream, fragment-blocked, updated in place
   const float* gamma; const float* beta; float eps;   // norm2
   const void* W1b; const float* b1; // fc1 weight [H,D] fragment-blocked, bias [H]
-  const void* W2p; const float* b2; // fc2 weight [D,H] fragment-blocked with the k index permuted per 16 (see put_op_blocked), bias [D]
+  const void* W2p; const float* b2; // fc2 weight [D,H] fragment-blocked, k index permuted per 16 AND rows permuted per 32 (put_op_blocked perm16 +
+                                    // rowperm), bias [D] permuted like the rows (put_f32_rowperm)
   int M, D, H;
   int rows_alloc;                   // rows addressable in x (multiple of 32, >= M)
   float* partial; size_t partial_bytes;   // optional scratch for the tail split (>= 4 * 64 * 128 * D * 4 bytes covers every case)
   int no_tail_split;                // 1: single launch (A/B switch)
   int panel0, tail_rb;              // set by the launcher
   // optional leading projection + residual (attn.proj): x <- x + A . Wp^T + bp, fused in front of the MLP.  Then Wpp is
-  // Wp fragment-blocked with the rows of every 32-row block permuted, bp / b2 permuted alike, W2p additionally row-
-  // permuted (put_op_blocked rowperm), and b2_logical is the unpermuted fc2 bias (tail reduction)
+  // Wp fragment-blocked with the rows of every 32-row block permuted, bp permuted alike.  b2_logical is the unpermuted
+  // fc2 bias (tail reduction; always required).
   const void* A; const void* Wpp; const float* bp; const float* b2_logical;
   // optional second output: xn_out (16-bit, fragment-blocked) = LayerNorm(x_new; gamma_n, beta_n) — the NEXT block's
   // norm1, computed in the epilogue where a lane pair holds the whole new row (feeds qkvattn.hip)

@@ -20,6 +20,7 @@ int mlp_fused(int prec, const MlpArgs& a, hipStream_t s) {
   if (a.rows_alloc % 32 != 0 || a.rows_alloc < a.M) return fail(EFFOCR_EINVAL, "mlp_fused: rows_alloc must be a multiple of 32 covering M");
   const bool proj = a.A != nullptr;
   if (proj && (!a.Wpp || !a.bp)) return fail(EFFOCR_EINVAL, "mlp_fused: the projection needs its weight and bias");
+  if (!a.b2_logical) return fail(EFFOCR_EINVAL, "mlp_fused: the unpermuted fc2 bias is required");
   if (a.xn_out && (!a.gamma_n || !a.beta_n)) return fail(EFFOCR_EINVAL, "mlp_fused: the second output needs the next norm's weight and bias");
   if (prec == PREC_BF16) return proj ? mlp_launch_bf16p(a, s) : mlp_launch_bf16(a, s);
   return proj ? mlp_launch_f16p(a, s) : mlp_launch_f16(a, s);

@@ -169,7 +169,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       for (int i = 0; i < 4; ++i) issue_piece(s0, i);
     }
 
-  // ---- LayerNorm in registers: xv (this lane's half of the row, fp32) -> xf[t] = B-operand fragment of k16 step t
+  f32x16 acc1[4];                                        // hT tiles of the current chunk
+  f32x16 acc2[OT];                                       // outT tiles
+  if constexpr (PARTIAL || PROJ) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+  }
+
+  // ---- LayerNorm in registers: xv (this lane's half of the row, fp32) -> xf[t] = B-operand fragment of k16 step t.
+  // Whole panels: the fp32 row moves on into the fc2 accumulators (acc2 = x + bias2; fc2 accumulates on top), so the
+  // residual is read ONCE per block.  W2's rows are permuted per 32 (api.hip rowperm32) such that registers 4q..4q+3 of
+  // output tile t ARE the fp32 chunk 8t + 4(q>>1) + 2half + (q&1) = xv[2(2t + (q>>1)) + (q&1)]: no exchange.
   auto layernorm_to_xf = [&]() __attribute__((always_inline)) {
     float sm = 0.f;
 #pragma unroll
@@ -183,8 +195,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
     ss += __shfl_xor(ss, 32, 64);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
-#pragma unroll
-    for (int t = 0; t < NXF; ++t) {
+    sfor<0, NXF>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
       u32x2 pk[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -194,23 +206,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         const f32x4 v = xv[2 * t + j];
         pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
                          (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
+        if constexpr (!PARTIAL) {
+          constexpr int tt = t >> 1;
+          const int q = 2 * (t & 1) + j;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + tt * 32 + 8 * q + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2[tt][4 * q + e] = v[e] + bv[e];
+        }
       }
       const u32x4 q = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
       xf[t] = __builtin_bit_cast(V8, q);
-    }
+      if constexpr (!PARTIAL) __builtin_amdgcn_sched_barrier(0);   // in order: the row's registers become the accumulators' one chunk pair at a time
+    });
   };
   if constexpr (!PROJ) layernorm_to_xf();
-
-  f32x16 acc1[4];                                        // hT tiles of the current chunk
-  f32x16 acc2[OT];                                       // outT tiles
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
-#pragma unroll
-  for (int t = 0; t < OT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
   const int wo = half * 512 + r31 * 16;                  // + (row block i * 8 + 2 * c4) * 512 inside a stage
   int s = 0;                                             // ring stage counter
@@ -432,9 +445,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 #if (MLX & 1)
   if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
 #endif
-  // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row:
-  // standard C-layout 8t + 2q + half; with PROJ (row-permuted weight copies) 8t + 4(q>>1) + 2half + (q&1)
-  auto cq = [&](int t, int q) __attribute__((always_inline)) { return PROJ ? 8 * t + 4 * (q >> 1) + 2 * half + (q & 1) : 8 * t + 2 * q + half; };
+  // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row (W2's
+  // rows are permuted per 32: api.hip rowperm32).  Whole panels: acc2 already holds x + bias2 + fc2 — nothing is re-read.
+  int hf = half;
+  asm volatile("" : "+v"(hf));                           // opaque: else the LayerNorm's 48 chunk offsets are kept (spilled) across the main loop for this
+  auto cq = [&](int t, int q) __attribute__((always_inline)) { return 8 * t + 4 * (q >> 1) + 2 * hf + (q & 1); };
   if constexpr (PARTIAL) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
     const int64_t rbl = rb - (int64_t)a.panel0 * 4;
@@ -447,69 +462,54 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
-  } else if (a.xn_out && !(MLX & 512) && rb * 32 + r31 < a.M) {
-    // ---- epilogue with the second output.  The lane pair (r31, half 0 / 1) holds the whole new row: pass 1 stores it
-    // and parks it in the accumulators, then two-pass statistics (one cross-half exchange each) and the next
-    // block's norm1 applied on the way out, rounded to the operand type (same arithmetic as layernorm_blocked_kernel)
+  } else if (rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
     float sm = 0.f;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
-      f32x4 rv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)cq(t, q) * 512);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + t * 32 + 8 * q + 4 * half);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = acc2[t][4 * q + e] + bv[e] + rv[q][e]; acc2[t][4 * q + e] = o[e]; }
+        const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
         sm += (o[0] + o[1]) + (o[2] + o[3]);
         *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
       }
     });
-    sm += __shfl_xor(sm, 32, 64);
-    const float mean = sm * (1.0f / D);
-    float ss = 0.f;
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
+    if (a.xn_out && !(MLX & 512)) {
+      // ---- second output.  The lane pair (r31, half 0 / 1) holds the whole new row: two-pass statistics (one cross-half
+      // exchange each) and the next block's norm1 applied on the way out, rounded to the operand type (same arithmetic as
+      // layernorm_blocked_kernel).  Registers 8p..8p+7 of tile t = 16-bit chunk 4t + 2p + half: one 16-byte store.
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm * (1.0f / D);
+      float ss = 0.f;
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float d = acc2[t][r] - mean; ss += d * d; }
-    });
-    ss += __shfl_xor(ss, 32, 64);
-    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
-    char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
+        for (int r = 0; r < 16; ++r) { const float d = acc2[t][r] - mean; ss += d * d; }
+      });
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+      char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = cq(t, q);                          // fp32 chunk of the row = features 4c..4c+3 = half (c & 1) of 16-bit chunk c >> 1
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+        for (int p = 0; p < 2; ++p) {
+          u32x2 pk[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int q = 2 * p + j, c = cq(t, q);       // fp32 chunk c = features 4c..4c+3 = half j of 16-bit chunk c >> 1
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+            pk[j] = pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
+                             (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
+          }
+          const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
 #if (MLX & 256)
-        if (mean == 12345.f)
+          if (mean == 12345.f)
 #endif
-        *reinterpret_cast<u32x2*>(nr + (size_t)(c >> 1) * 512 + (c & 1) * 8) =
-            pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
-                     (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
-      }
-    });
-  } else if (rb * 32 + r31 < a.M) {
-    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-      f32x4 rv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(xr + (size_t)cq(t, q) * 512);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + t * 32 + 8 * q + 4 * half);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc2[t][4 * q + e] + bv[e] + rv[q][e];
-        *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
-      }
-    });
+          *reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512) = o;
+        }
+      });
+    }
   }
 }
 
@@ -581,7 +581,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
     int rc = check_launch("mlp_fused(tail)");
     if (rc) return rc;
     const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical ? a.b2_logical : a.b2,
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical,
                        (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M);
     rc = check_launch("mlp_reduce");
     if (rc || !a.xn_out) return rc;

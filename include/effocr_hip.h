@@ -241,27 +241,29 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
  * Linear(d,h) -> GELU(erf) -> Linear(h,d); models/encoders.py:58,63):  x_blk (fp32, in/out) <- x + fc2(gelu(fc1(LN(x)))).
  * w1_blk: fc1.weight [h,d] 16-bit fragment-blocked.  w2_perm: fc2.weight [d,h] 16-bit fragment-blocked with the k
  * (hidden) index permuted inside every group of 16: element e of 16-byte chunk c holds
- * k = 16*(c/2) + (e&3) + 8*(e>>2) + 4*(c&1).  (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m.
+ * k = 16*(c/2) + (e&3) + 8*(e>>2) + 4*(c&1), AND its rows (output features) permuted inside every block of 32:
+ * position p holds source row 8*(2*(r>>3) + hh) + (r&7) with hh = (p>>2)&1, r = (p&3) + 4*(p>>3)  ("P32": with it the
+ * MFMA accumulators of a lane are the very fp32 chunks its LayerNorm read, so the kernel starts fc2's accumulators at
+ * x + bias and never re-reads the residual).  b2_perm: fc2 bias P32-permuted; b2: the same bias unpermuted (tail reduction).
+ * (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m.
  * scratch_dev (optional, may be NULL): device scratch of scratch_bytes; with >= 64 MiB the 128-row panels of the last,
  * partially filled round of CUs are split over the hidden dimension and reduced in a fixed order (same result
  * bit for bit run to run; differs from the unsplit path only by fp32 summation order). */
 int effocr_op_mlp_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                          const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                          const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev,
                           int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream);
 /* The same kernel with its SECOND output: xn_blk (16-bit blocked [m,d]) = LayerNorm(x_new; gamma_next, beta_next, eps), i.e.
  * the NEXT block's norm1 applied to the updated residual stream, computed in the epilogue where a lane pair holds the
  * whole new row (input of effocr_op_qkv_attn_blocked).  Other arguments as effocr_op_mlp_blocked. */
 int effocr_op_mlp_ln_blocked(int precision, float* x_blk_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                             const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_dev,
+                             const void* w1_blk_dev, const float* b1_dev, const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev,
                              const float* gamma_next_dev, const float* beta_next_dev, void* xn_blk_dev,
                              int m, int d, int h, int rows_alloc, void* scratch_dev, size_t scratch_bytes, void* stream);
 /* attn.proj + residual fused in front of the MLP (everything a timm Block does after attention):
  *   x_blk <- y + fc2(gelu(fc1(LN(y)))),  y = x + a . wp^T + bp.
- * a_blk [m,d] 16-bit blocked (attention output).  Row permutation P32 inside every block of 32 rows / entries:
- * position p holds source index 8*(2*(r>>3) + hh) + (r&7) with hh = (p>>2)&1, r = (p&3) + 4*(p>>3).
- *   wp_perm  attn.proj.weight [d,d] blocked, rows P32-permuted;  bp_perm  its bias, P32-permuted
- *   w2_perm  mlp.fc2.weight [d,h] blocked, k permuted per 16 (as in op_mlp_blocked) AND rows P32-permuted
- *   b2_perm  fc2 bias P32-permuted;  b2  the same bias unpermuted (used by the tail reduction)
+ * a_blk [m,d] 16-bit blocked (attention output).
+ *   wp_perm  attn.proj.weight [d,d] blocked, rows P32-permuted (see op_mlp_blocked);  bp_perm  its bias, P32-permuted
+ *   w2_perm, b2_perm, b2  as in op_mlp_blocked
  * Other arguments as effocr_op_mlp_blocked. */
 int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_blk_dev, const void* wp_perm_dev, const float* bp_perm_dev,
                                const float* gamma_dev, const float* beta_dev, float eps, const void* w1_blk_dev, const float* b1_dev,

@@ -254,13 +254,13 @@ def test_mlp_fused_blocked(hip_lib, dev, prec, shape, scratch):
     b1, b2 = 0.5 * torch.randn(H, generator=g), 0.5 * torch.randn(D, generator=g)
     ra = (M + 127) // 128 * 128
     xd = to_blocked(x, ra).to(dev)
-    w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm16_columns(w2), D).to(dev)
-    gd, bd, b1d, b2d = gamma.to(dev), beta.to(dev), b1.to(dev), b2.to(dev)
+    w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm32_rows(perm16_columns(w2)), D).to(dev)
+    gd, bd, b1d, b2d, b2pd = gamma.to(dev), beta.to(dev), b1.to(dev), b2.to(dev), perm32_rows(b2).to(dev)
     # with scratch the panels of the last partially filled round of CUs are split over the hidden dimension:
     # M = 985 -> 8 panels x 4 parts; 40000 -> 256 + 57 x 4; 17920 -> 140 panels x 2 parts (140 * 4 > 256 CUs)
     sc = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if scratch else None
     _lib.check(hip_lib.effocr_op_mlp_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6, _lib.ptr(w1d), _lib.ptr(b1d),
-                                             _lib.ptr(w2d), _lib.ptr(b2d), M, D, H, ra, _lib.ptr(sc), sc.numel() if scratch else 0,
+                                             _lib.ptr(w2d), _lib.ptr(b2pd), _lib.ptr(b2d), M, D, H, ra, _lib.ptr(sc), sc.numel() if scratch else 0,
                                              _stream(dev)), "op_mlp_blocked")
     torch.cuda.synchronize()
     got = from_blocked(xd.cpu(), M, D, ra).double()
@@ -425,12 +425,12 @@ def test_mlp_fused_second_output(hip_lib, dev, prec, shape, scratch):
     b1, b2 = 0.5 * torch.randn(H, generator=g), 0.5 * torch.randn(D, generator=g)
     ra = (M + 127) // 128 * 128
     xd = to_blocked(x, ra).to(dev)
-    w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm16_columns(w2), D).to(dev)
-    gd, bd, b1d, b2d, gnd, bnd = gamma.to(dev), beta.to(dev), b1.to(dev), b2.to(dev), gn.to(dev), bn.to(dev)
+    w1d, w2d = to_blocked(w1, H).to(dev), to_blocked(perm32_rows(perm16_columns(w2)), D).to(dev)
+    gd, bd, b1d, b2d, gnd, bnd, b2pd = gamma.to(dev), beta.to(dev), b1.to(dev), b2.to(dev), gn.to(dev), bn.to(dev), perm32_rows(b2).to(dev)
     xn = torch.zeros(ra * D, dtype=TDT[prec], device=dev)
     sc = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if scratch else None
     _lib.check(hip_lib.effocr_op_mlp_ln_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6, _lib.ptr(w1d), _lib.ptr(b1d),
-                                                _lib.ptr(w2d), _lib.ptr(b2d), _lib.ptr(gnd), _lib.ptr(bnd), _lib.ptr(xn), M, D, H, ra,
+                                                _lib.ptr(w2d), _lib.ptr(b2pd), _lib.ptr(b2d), _lib.ptr(gnd), _lib.ptr(bnd), _lib.ptr(xn), M, D, H, ra,
                                                 _lib.ptr(sc), sc.numel() if scratch else 0, _stream(dev)), "op_mlp_ln_blocked")
     torch.cuda.synchronize()
     got_x = from_blocked(xd.cpu(), M, D, ra)
