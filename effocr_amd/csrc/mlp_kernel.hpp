@@ -182,19 +182,36 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   // Whole panels: the fp32 row moves on into the fc2 accumulators (acc2 = x + bias2; fc2 accumulates on top), so the
   // residual is read ONCE per block.  W2's rows are permuted per 32 (api.hip rowperm32) such that registers 4q..4q+3 of
   // output tile t ARE the fp32 chunk 8t + 4(q>>1) + 2half + (q&1) = xv[2(2t + (q>>1)) + (q&1)]: no exchange.
+  // (PROJ: the row sits in acc2 — chunk i of the lane's order = registers 4(i&3).. of tile i>>2 — else in xv)
+  auto row = [&](auto I_) __attribute__((always_inline)) -> f32x4 {
+    constexpr int i = decltype(I_)::value;
+    if constexpr (PROJ) return f32x4{acc2[i >> 2][4 * (i & 3)], acc2[i >> 2][4 * (i & 3) + 1], acc2[i >> 2][4 * (i & 3) + 2], acc2[i >> 2][4 * (i & 3) + 3]};
+    else return xv[i];
+  };
+  // (PROJ) the row stays in the accumulator registers between the passes: without the pin the compiler keeps pass 1's 192
+  // VGPR copies of it alive for the later passes and spills them
+  auto pin_row = [&]() __attribute__((always_inline)) {
+    if constexpr (PROJ) {
+#pragma unroll
+      for (int t = 0; t < OT; ++t) asm volatile("" : "+a"(acc2[t]));
+    }
+  };
   auto layernorm_to_xf = [&]() __attribute__((always_inline)) {
     float sm = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2 * NXF; ++i) sm += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    pin_row();
+    sfor<0, 2 * NXF>([&](auto I_) { const f32x4 v = row(I_); sm += (v[0] + v[1]) + (v[2] + v[3]); });
     sm += __shfl_xor(sm, 32, 64);
     const float mean = sm * (1.0f / D);
     float ss = 0.f;
+    pin_row();
+    sfor<0, 2 * NXF>([&](auto I_) {
+      const f32x4 v = row(I_);
 #pragma unroll
-    for (int i = 0; i < 2 * NXF; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+      for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; ss += d * d; }
+    });
     ss += __shfl_xor(ss, 32, 64);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+    pin_row();
     sfor<0, NXF>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
       u32x2 pk[2];
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         const int c = 4 * t + 2 * half + j;
         const f32x4 gm = *reinterpret_cast<const f32x4*>(sG + c * 4);
         const f32x4 bt = *reinterpret_cast<const f32x4*>(sBt + c * 4);
-        const f32x4 v = xv[2 * t + j];
+        const f32x4 v = j == 0 ? row(std::integral_constant<int, 2 * t>{}) : row(std::integral_constant<int, 2 * t + 1>{});
         pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
                          (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
         if constexpr (!PARTIAL) {
@@ -386,11 +403,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         });
       });
     });
-    // x_new = outT + bias + x: with the row-permuted weight, registers 4q..4q+3 of tile t are the fp32 chunk
-    // 8t + 4(q>>1) + 2half + (q&1) of the row = xv[2(2t + (q>>1)) + (q&1)].  Nothing is stored here: acc2 keeps
-    // outT + bias, fc2 accumulates on top of it and the final epilogue adds the (old) residual once.  Of a split
-    // tail panel only part 0 keeps it (the reduction adds every part to the old x).
-    const bool keep = !PARTIAL || c0 == 0;
+    // y = x + outT + bias IN PLACE: with the row-permuted weight, registers 4q..4q+3 of tile t are the fp32 chunk
+    // 8t + 4(q>>1) + 2half + (q&1) of the row, i.e. chunk 4t + q of the lane's LayerNorm order.  The new row never leaves
+    // the accumulators: LayerNorm reads it there, fc2 accumulates on top of it (+ bias2), the epilogue stores it.  Of a
+    // split tail panel only part 0 keeps the row (the reduction then adds no residual).
     __builtin_amdgcn_sched_barrier(0);                   // the 48 residual loads must not move up into the projection,
     asm volatile("" ::: "memory");                       // where the attention fragments still hold 96 VGPRs
     sfor<0, OT>([&](auto T_) {
@@ -399,10 +415,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       for (int q = 0; q < 4; ++q) {
 #if (MLX & 128)
         const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f + q};
-        xv[2 * (2 * t + (q >> 1)) + (q & 1)] = cst;
+        xv[4 * t + q] = cst;
         if (a.M < 0)
 #endif
-        xv[2 * (2 * t + (q >> 1)) + (q & 1)] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
+        xv[4 * t + q] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
       }
     });
     sfor<0, OT>([&](auto T_) {
@@ -411,14 +427,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       for (int q = 0; q < 4; ++q) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(sBp + t * 32 + 8 * q + 4 * half);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pb = acc2[t][4 * q + e] + bv[e];
-          xv[2 * (2 * t + (q >> 1)) + (q & 1)][e] += pb;
-          acc2[t][4 * q + e] = keep ? pb : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += bv[e] + xv[4 * t + q][e];
       }
     });
     layernorm_to_xf();
+    if constexpr (PARTIAL) {                             // straight-line (a branch over 192 accumulators makes the compiler spill them)
+      const float kf = c0 == 0 ? 1.f : 0.f;
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] *= kf;
+    }
   }
 
   // Schedule (ring stream order A(0) | A(1) | B(0) | A(2) | B(1) | ...).  ONE hand-over set: parked after A(c) — once B(c-1)
@@ -513,9 +532,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   }
 }
 
-// x[row block rb0 + i] += bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
+// x[row block rb0 + i] = (add_x ? x : 0) + bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* partial, const float* b2, int64_t rb0, int tail_rb,
-                                                         int D, int nparts, int64_t M) {
+                                                         int D, int nparts, int64_t M, int add_x) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (row block, chunk, row) in blocked order
   const int64_t per_rb = (int64_t)(D / 4) * 32;
   if (id >= (int64_t)tail_rb * per_rb) return;
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* 
     for (int e = 0; e < 4; ++e) acc[e] += pv[e];
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e] + v[e];
+  for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e] + (add_x ? v[e] : 0.f);   // with the projection in front part 0 carries the whole new row
   *xp = v;
 }
 
@@ -582,7 +601,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
     if (rc) return rc;
     const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical,
-                       (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M);
+                       (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M, PROJ ? 0 : 1);
     rc = check_launch("mlp_reduce");
     if (rc || !a.xn_out) return rc;
     // second output for the split panels: the blocked LayerNorm kernel over their rows (a few thousand)

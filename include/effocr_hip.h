@@ -97,7 +97,7 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *   "use_gemm3"   [1] 128-row wave-tile GEMM over blocked operands (fc2; every ViT-B linear); 0: gemm2 / gemm
  *   "use_gemm2"   [1] DMA-ring GEMM for the patch embedding (and fc2 when use_gemm3 = 0)
  *   "tail_split"  [1] split the panels / tiles of the last, partially filled round of CUs
- *   "use_projf"   [0] attn.proj + residual fused in front of the fused MLP kernel
+ *   "use_projf"   [1] attn.proj + residual fused in front of the fused MLP kernel (0: its own row-panel launch)
  *   "use_rowlin"  [0] register-resident-input kernels for LN1+qkv and proj+residual
  *   "panel_rows"  [128] row-panel height, 64 or 128;  "chunk" (= set_chunk);  "debug" (experiment hooks) */
 int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value);

@@ -132,8 +132,8 @@ def test_input_validation(dev):
 
 @pytest.mark.parametrize("B", [1, 3, 70])
 def test_every_switchable_path_matches_the_oracle(dev, B):
-    """Default path (row-panel qkv / proj + fused MLP) and every A/B switch of the library — unfused MLP, projection
-    fused into the MLP kernel, register-resident row-block linears, gemm2 instead of gemm3, no tail split — against
+    """Default path (row-panel qkv + attention, projection fused into the fused MLP kernel) and every A/B switch of the library —
+    unfused MLP, projection as its own row-panel launch, register-resident row-block linears, gemm2 instead of gemm3, no tail split — against
     oracle A at batch sizes that exercise single-panel, ragged and multi-panel grids; the one-image-per-workgroup qkv+attention
     kernel (default from 192 crops on) is forced on for every batch size, alone and combined with the other switches."""
     from effocr_amd.encoders import HipEncoder
@@ -144,15 +144,15 @@ def test_every_switchable_path_matches_the_oracle(dev, B):
     for prec in ("bf16", "fp16"):
         enc = HipEncoder(arch, sd, precision=prec, device=dev)
         outs = {"default": enc.forward(x.to(dev)).cpu()}
-        for name, opts in [("unfused_mlp", {"use_mlp": 0}), ("proj_in_mlp", {"use_projf": 1}), ("rowlin", {"use_rowlin": 1}),
+        for name, opts in [("unfused_mlp", {"use_mlp": 0}), ("separate_proj", {"use_projf": 0}), ("rowlin", {"use_rowlin": 1}),
                            ("gemm2_fc2", {"use_mlp": 0, "use_gemm3": 0}), ("no_tail_split", {"tail_split": 0}),
-                           ("fused_qkv_attention", {"use_qkvattn": 2}), ("fused_qkv_attention+proj_in_mlp", {"use_qkvattn": 2, "use_projf": 1}),
+                           ("fused_qkv_attention", {"use_qkvattn": 2}), ("fused_qkv_attention+separate_proj", {"use_qkvattn": 2, "use_projf": 0}),
                            ("fused_qkv_attention_no_tail_split", {"use_qkvattn": 2, "tail_split": 0}), ("panel_qkv+attention", {"use_qkvattn": 0})]:
             for k, v in opts.items():
                 enc.set_option(k, v)
             outs[name] = enc.forward(x.to(dev)).cpu()
             for k in opts:                                   # back to the defaults
-                enc.set_option(k, {"use_mlp": 1, "use_projf": 0, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1, "use_qkvattn": 1}[k])
+                enc.set_option(k, {"use_mlp": 1, "use_projf": 1, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1, "use_qkvattn": 1}[k])
         assert torch.equal(outs["default"], enc.forward(x.to(dev)).cpu())          # switches restored, run-to-run bitwise
         for name, o in outs.items():
             assert rel_err(o, ref) <= REL[prec], (name, prec, B, rel_err(o, ref))
