@@ -34,8 +34,9 @@
 #define EFFOCR_EXP 0
 #endif
 // timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
-// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 no residual loads after the projection,
-// 256 no stores of the second output, 512 second output skipped altogether, 4096 weight stream from 128 KB only (L2-hot)
+// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 (unused),
+// 256 no stores of the second output, 512 second output skipped altogether, 4096 weight stream from 128 KB only (L2-hot),
+// 1024 s_memtime stamps of wave 0 per panel (effocr_exp_mlp_timeline in mlp_bf16p.hip, tools/mlp_timeline.py)
 #if (EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000) || (EFFOCR_EXP >= 4000 && EFFOCR_EXP < 12000)
 #define MLX (EFFOCR_EXP - 2000)
 #else
@@ -51,6 +52,15 @@ template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) 
     sfor<I + 1, N>(f);
   }
 }
+
+#if (MLX & 1024)
+__device__ unsigned long long mlp_timeline[2049 * 16];   // [panel][stamp] (experiments only); the last row is a dump for the other lanes
+// branch-free (a branch between the phases splits the basic blocks and makes the compiler spill hundreds of registers)
+#define MLP_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    mlp_timeline[((threadIdx.x == 0 && blockIdx.x < 2048) ? (int)blockIdx.x : 2048) * 16 + (i)] = t_; } while (0)
+#else
+#define MLP_STAMP(i) do {} while (0)
+#endif
 
 constexpr int MLP_PT = 128;                              // tokens per workgroup
 constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
@@ -89,6 +99,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
+  // First round of workgroups only: spread the start over `stagger` x 32 ticks.  All panels cost the same, so the
+  // workgroups of a launch otherwise stay in lock step from the first to the last round: every CU requests its rows at the
+  // same moment (61 MB per round: an HBM-bound 12 us during which nothing computes) and stores them at the same moment.
+  if (!PARTIAL && a.stagger > 0 && (int)blockIdx.x < a.stagger_wgs) {
+    const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((blockIdx.x >> 3) & 31) * a.stagger);
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
+  MLP_STAMP(0);
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
   const int panel = a.panel0 + (int)blockIdx.x / SPLIT;
   const int c0 = ((int)blockIdx.x % SPLIT) * NCW;        // first hidden chunk of this workgroup
@@ -96,13 +114,49 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
 
-  // ---- input rows first (oldest in the in-order VM queue: work can start while the ring fills).
+  // ---- every request of the prologue is in flight before anything waits: parameters (registers, oldest in the in-order VM
+  // queue), the wave's rows, then the first R-1 ring stages; the parameters go to LDS while the rest is still landing.
+  constexpr int NB1 = H / 256, ND = (D + 255) / 256;
+  float pb1[NB1], pdv[7][ND];
+#pragma unroll
+  for (int i = 0; i < NB1; ++i) pb1[i] = a.b1[tid + 256 * i];
+  const bool second = !PARTIAL && a.xn_out != nullptr;
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int n = tid + 256 * j;
+    if (n < D) {
+      pdv[0][j] = a.b2[n]; pdv[1][j] = a.gamma[n]; pdv[2][j] = a.beta[n];
+      if constexpr (PROJ) pdv[3][j] = a.bp[n];
+      if (second) { pdv[4][j] = a.gamma_n[n]; pdv[5][j] = a.beta_n[n]; }
+    }
+  }
+  asm volatile("" ::: "memory");
   // lane = (row r31, half): 16-bit k chunk 2t+half of its row = fp32 chunks 4t+2half, 4t+2half+1
+  f32x16 acc1[4];                                        // hT tiles of the current chunk
+  f32x16 acc2[OT];                                       // outT tiles
   f32x4 xv[2 * NXF];
   V8 xf[NXF];                                            // B-operand fragments: attention output (PROJ), then LayerNorm(x)
   const int64_t rbc = rb < (a.rows_alloc >> 5) ? rb : (a.rows_alloc >> 5) - 1;
   const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
+  // (PROJ) x is the projection's initial accumulator value (x + bias + a . Wp^T lands where LayerNorm reads it).  Output tile t,
+  // registers 4q..4q+3 = fp32 chunk 8t + 4(q>>1) + 2half + (q&1) of the row = xv[4t + q].  The rows of the first output group
+  // are requested here, the rest at the start of the projection (they land under its first group of MFMAs): no load latency
+  // in the middle of the kernel and never more than 128 VGPRs of rows next to the 96 of the attention fragments.
+  auto load_rows = [&](int t0, int t1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = t0; t < t1; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        xv[4 * t + q] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
+  };
   if constexpr (PROJ) {
+    load_rows(0, OT);
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] = xv[4 * t + q][e];
     const char* ab = static_cast<const char*>(a.A) + rbc * KC * 512 + half * 512 + r31 * 16;
 #pragma unroll
     for (int t = 0; t < NXF; ++t) xf[t] = *reinterpret_cast<const V8*>(ab + (size_t)t * 1024);
@@ -120,12 +174,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       }
     }
   }
-  for (int n = tid; n < H; n += 256) sB1[n] = a.b1[n];
-  for (int n = tid; n < D; n += 256) { sB2[n] = a.b2[n]; sG[n] = a.gamma[n]; sBt[n] = a.beta[n]; if constexpr (PROJ) sBp[n] = a.bp[n]; }
-  if constexpr (!PARTIAL) {
-    if (a.xn_out) for (int n = tid; n < D; n += 256) { sGn[n] = a.gamma_n[n]; sBn[n] = a.beta_n[n]; }
-  }
-  __syncthreads();                                       // parameters visible (and x has landed) before the ring starts filling
+  asm volatile("" ::: "memory");
 
   // ---- ring: stage s of the panel's stream.  Order: A(0) | A(1) | B(0) | A(2) | B(1) | ... | A(NC-1) | B(NC-2) | B(NC-1).
   // Wave w copies row block w of the stage: 4 pieces of 1 KB (two adjacent k-chunk cells each).
@@ -168,10 +217,22 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) issue_piece(s0, i);
     }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NB1; ++i) sB1[tid + 256 * i] = pb1[i];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int n = tid + 256 * j;
+    if (n < D) {
+      sB2[n] = pdv[0][j]; sG[n] = pdv[1][j]; sBt[n] = pdv[2][j];
+      if constexpr (PROJ) sBp[n] = pdv[3][j];
+      if (second) { sGn[n] = pdv[4][j]; sBn[n] = pdv[5][j]; }
+    }
+  }
+  __syncthreads();                                       // parameters visible
+  MLP_STAMP(1);
 
-  f32x16 acc1[4];                                        // hT tiles of the current chunk
-  f32x16 acc2[OT];                                       // outT tiles
-  if constexpr (PARTIAL || PROJ) {
+  if constexpr (PARTIAL && !PROJ) {
 #pragma unroll
     for (int t = 0; t < OT; ++t)
 #pragma unroll
@@ -236,11 +297,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       if constexpr (!PARTIAL) __builtin_amdgcn_sched_barrier(0);   // in order: the row's registers become the accumulators' one chunk pair at a time
     });
   };
-  if constexpr (!PROJ) layernorm_to_xf();
+  if constexpr (!PROJ) {
+    layernorm_to_xf();
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+  }
 
   const int wo = half * 512 + r31 * 16;                  // + (row block i * 8 + 2 * c4) * 512 inside a stage
   int s = 0;                                             // ring stage counter
@@ -307,11 +370,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
   // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
   // is one basic block (a scalar branch between two MFMAs is a bubble with one wave per SIMD; see gemm3.hip).
-  auto ring_stage = [&](auto REM, auto&& mfma1) __attribute__((always_inline)) {
+  auto ring_stage = [&](auto REM, auto&& mfma1, auto NOPF) __attribute__((always_inline)) {   // NOPF: do not prefetch stage s+1's first fragments
 #if (MLX & 8)
-    constexpr bool more = false, next = decltype(REM)::value >= 1;
+    constexpr bool more = false, next = decltype(REM)::value >= 1 && !decltype(NOPF)::value;
 #else
-    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1;
+    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1 && !decltype(NOPF)::value;
 #endif
     const char* st = sW + (s & (R - 1)) * MLP_STAGE;
     const char* stn = sW + ((s + 1) & (R - 1)) * MLP_STAGE;
@@ -361,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
             gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
           }
         }
-      });
+      }, std::false_type{});
     });
   };
   // ---- phase B of a chunk: (group g, k half kh) stages; B-operand = fragment 4*kh + c4 of `hs`
@@ -387,12 +450,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
             gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
           }
         }
-      });
+      }, std::false_type{});
     });
   };
 
   if constexpr (PROJ) {
-    // ---- projection: outT[D x 32 tok] = Wpp . a^T, (group g, k stage) ring stages; B-operand = attention fragments
+    // ---- projection: outT[D x 32 tok] = x + bias + Wpp . a^T, (group g, k stage) ring stages; B-operand = attention fragments.
+    // The accumulators of a group start at its rows + bias (first group: requested in the prologue; the others: requested
+    // below, landed under the first group's MFMAs).  The new row y never leaves the accumulators: LayerNorm reads it there,
+    // fc2 accumulates on top of it (+ bias2), the epilogue stores it.  Of a split tail panel only part 0 keeps the row (the
+    // reduction then adds no residual).
     sfor<0, OG>([&](auto G_) {
       constexpr int g = decltype(G_)::value;
       sfor<0, SA>([&](auto KS) {
@@ -400,37 +467,27 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
         ring_stage(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
           constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
           acc2[4 * g + i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc2[4 * g + i]);
-        });
+        }, std::integral_constant<bool, (g == OG - 1 && ks == SA - 1)>{});   // nothing of the ring held in registers across the LayerNorm
       });
     });
-    // y = x + outT + bias IN PLACE: with the row-permuted weight, registers 4q..4q+3 of tile t are the fp32 chunk
-    // 8t + 4(q>>1) + 2half + (q&1) of the row, i.e. chunk 4t + q of the lane's LayerNorm order.  The new row never leaves
-    // the accumulators: LayerNorm reads it there, fc2 accumulates on top of it (+ bias2), the epilogue stores it.  Of a
-    // split tail panel only part 0 keeps the row (the reduction then adds no residual).
-    __builtin_amdgcn_sched_barrier(0);                   // the 48 residual loads must not move up into the projection,
-    asm volatile("" ::: "memory");                       // where the attention fragments still hold 96 VGPRs
-    sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#if (MLX & 128)
-        const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f + q};
-        xv[4 * t + q] = cst;
-        if (a.M < 0)
-#endif
-        xv[4 * t + q] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
-      }
-    });
+    MLP_STAMP(2);
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(sBp + t * 32 + 8 * q + 4 * half);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += bv[e] + xv[4 * t + q][e];
+        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += bv[e];
       }
     });
+    MLP_STAMP(3);
     layernorm_to_xf();
+    load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)                          // (not before: the 64 registers are free for the compiler up to here)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+    MLP_STAMP(4);
     if constexpr (PARTIAL) {                             // straight-line (a branch over 192 accumulators makes the compiler spill them)
       const float kf = c0 == 0 ? 1.f : 0.f;
 #pragma unroll
@@ -449,17 +506,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   HSet S;
   phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
   park(S, 0);
+  MLP_STAMP(5);
 #pragma unroll 1
   for (int c = 1; c < NC - 1; ++c) {
     phase_a(Far{}, &S, U0_{}, U16_{});                    // A(c) + gelu(c-1)
     phase_b(Far{}, S, nullptr, U0_{}, U0_{});             // B(c-1)
     park(S, c);
   }
+  MLP_STAMP(6);
   phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
   phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
   park(S, NC - 1);
   sfor<0, 8>([&](auto Q) { gelu_unit(S, Q); });
   phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
+  MLP_STAMP(7);
 
 #if (MLX & 1)
   if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
@@ -530,6 +590,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
       });
     }
   }
+  MLP_STAMP(8);
 }
 
 // x[row block rb0 + i] = (add_x ? x : 0) + bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
@@ -587,6 +648,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   const int main_panels = split > 1 ? npanels - tail : npanels;
   if (main_panels > 0) {
     a.panel0 = 0;
+    a.stagger_wgs = main_panels >= 4 * slots ? slots : 0;   // (the spread costs ~0.4 panel times at the end of the launch: worth it from ~4 rounds on)
     hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 12, false, PROJ>), dim3((unsigned)main_panels), dim3(256), 0, s, a);
     int rc = check_launch("mlp_fused");
     if (rc) return rc;
