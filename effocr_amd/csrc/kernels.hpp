@@ -47,7 +47,7 @@ struct MlpArgs {
   int rows_alloc;                   // rows addressable in x (multiple of 32, >= M)
   float* partial; size_t partial_bytes;   // optional scratch for the tail split (>= 4 * 64 * 128 * D * 4 bytes covers every case)
   int no_tail_split;                // 1: single launch (A/B switch)
-  int panel0, tail_rb, stagger_wgs; // set by the launcher
+  int panel0, tail_rb, stagger_wgs, main_wgs; // set by the launcher
   int stagger;                      // > 0: the first round of workgroups starts spread over 32 x stagger clock ticks (see mlp_kernel.hpp)
   // optional leading projection + residual (attn.proj): x <- x + A . Wp^T + bp, fused in front of the MLP.  Then Wpp is
   // Wp fragment-blocked with the rows of every 32-row block permuted, bp permuted alike.  b2_logical is the unpermuted

@@ -73,8 +73,16 @@ constexpr int MLP_RING = 8;
 // Its weight copy has the rows of every 32-row block permuted (api.hip put_op_blocked rowperm) so that the swapped
 // C-layout hands each lane 8 CONSECUTIVE output features per (tile, register octet) — exactly the fp32 chunks
 // 4t+2half, 4t+2half+1 the LayerNorm below expects in xv[]: accumulators -> (+bias, +residual) -> xv, no exchange.
+template <int D, int H> constexpr int mlp_smem_bytes() { return MLP_RING * MLP_STAGE + (H + 6 * D) * 4; }
+// the workgroup's LDS: ONE object for both bodies of a kernel (whole panels / split parts) — a pointer parameter would make
+// the compiler lose the address space (and, measured, spill 370 registers in the LayerNorm)
+__shared__ __attribute__((aligned(16))) char mlp_smem[mlp_smem_bytes<384, 1536>()];
+
+// body of one workgroup: bid = its index among the workgroups of its kind (whole panels / split parts)
 template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ>
-__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
+__device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) {
+  static_assert(mlp_smem_bytes<D, H>() <= (int)sizeof(mlp_smem), "mlp: LDS object too small");
+  char* smem = mlp_smem;
   typedef typename Op16<E>::V8 V8;
   constexpr int KC = D / 8;                              // 16-B k chunks per xn row
   constexpr int NC = NCW;                                // hidden chunks of this workgroup (H / 128 in total)
@@ -87,7 +95,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   static_assert(D % 128 == 0 && H % 128 == 0 && (H / 128) % NCW == 0, "mlp: D and H must be multiples of 128");
   constexpr int NXF = D / 16;                            // xn B-operand fragments per lane (one per k16 step)
   constexpr int R = MLP_RING;
-  __shared__ __attribute__((aligned(16))) char smem[R * MLP_STAGE + (H + 6 * D) * 4];
   char* sW = smem;
   float* sB1 = reinterpret_cast<float*>(smem + R * MLP_STAGE);
   float* sB2 = sB1 + H;
@@ -102,14 +109,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   // First round of workgroups only: spread the start over `stagger` x 32 ticks.  All panels cost the same, so the
   // workgroups of a launch otherwise stay in lock step from the first to the last round: every CU requests its rows at the
   // same moment (61 MB per round: an HBM-bound 12 us during which nothing computes) and stores them at the same moment.
-  if (!PARTIAL && a.stagger > 0 && (int)blockIdx.x < a.stagger_wgs) {
-    const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((blockIdx.x >> 3) & 31) * a.stagger);
+  if (!PARTIAL && a.stagger > 0 && bid < a.stagger_wgs) {
+    const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((bid >> 3) & 31) * a.stagger);
     while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
   }
   MLP_STAMP(0);
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
-  const int panel = a.panel0 + (int)blockIdx.x / SPLIT;
-  const int c0 = ((int)blockIdx.x % SPLIT) * NCW;        // first hidden chunk of this workgroup
+  const int panel = (PARTIAL ? a.panel0 : 0) + bid / SPLIT;
+  const int c0 = (bid % SPLIT) * NCW;        // first hidden chunk of this workgroup
   const int64_t rb = (int64_t)panel * 4 + w;             // this wave's 32-row block of x
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
@@ -255,6 +262,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     if constexpr (PROJ) {
 #pragma unroll
       for (int t = 0; t < OT; ++t) asm volatile("" : "+a"(acc2[t]));
+    } else {                                             // (same for the VGPR copy: else (v - mean) of the variance pass is kept, i.e. spilled, for the last pass)
+#pragma unroll
+      for (int i = 0; i < 2 * NXF; ++i) asm volatile("" : "+v"(xv[i]));
     }
   };
   auto layernorm_to_xf = [&]() __attribute__((always_inline)) {
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   if constexpr (PARTIAL) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
     const int64_t rbl = rb - (int64_t)a.panel0 * 4;
-    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(blockIdx.x % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + r31 * 16;
+    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(bid % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + r31 * 16;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
@@ -593,6 +603,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
   MLP_STAMP(8);
 }
 
+// One launch for the whole panels (workgroups [0, main_wgs)) AND the split parts of the tail panels (TNCW hidden chunks each; TNCW = 0:
+// no tail): the parts are dispatched last, i.e. into the ragged end that the start spread of the first round leaves on the CUs.
+template <typename E, int D, int H, int TNCW, bool PROJ>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
+  if constexpr (TNCW == 0) {
+    mlp_fused_body<E, D, H, H / 128, false, PROJ>(a, (int)blockIdx.x);
+  } else {
+    if ((int)blockIdx.x < a.main_wgs) mlp_fused_body<E, D, H, H / 128, false, PROJ>(a, (int)blockIdx.x);
+    else mlp_fused_body<E, D, H, TNCW, true, PROJ>(a, (int)blockIdx.x - a.main_wgs);
+  }
+}
+
 // x[row block rb0 + i] = (add_x ? x : 0) + bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* partial, const float* b2, int64_t rb0, int tail_rb,
                                                          int D, int nparts, int64_t M, int add_x) {
@@ -631,8 +653,8 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   MlpArgs a = a_in;
   const int npanels = (a.M + MLP_PT - 1) / MLP_PT;
   if (a.D == 128 && a.H == 512) {
-    a.panel0 = 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512, 4, false, PROJ>), dim3((unsigned)npanels), dim3(256), 0, s, a);
+    a.panel0 = 0; a.main_wgs = npanels; a.stagger_wgs = 0;
+    hipLaunchKernelGGL((mlp_fused_kernel<E, 128, 512, 0, PROJ>), dim3((unsigned)npanels), dim3(256), 0, s, a);
     return check_launch("mlp_fused");
   }
   if (!(a.D == 384 && a.H == 1536)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
@@ -646,33 +668,26 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   const size_t need = (size_t)split * tail * MLP_PT * a.D * sizeof(float);
   if (split > 1 && (!a.partial || a.partial_bytes < need)) split = 1;
   const int main_panels = split > 1 ? npanels - tail : npanels;
-  if (main_panels > 0) {
-    a.panel0 = 0;
-    a.stagger_wgs = main_panels >= 4 * slots ? slots : 0;   // (the spread costs ~0.4 panel times at the end of the launch: worth it from ~4 rounds on)
-    hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 12, false, PROJ>), dim3((unsigned)main_panels), dim3(256), 0, s, a);
-    int rc = check_launch("mlp_fused");
-    if (rc) return rc;
-  }
-  if (split > 1) {
-    a.panel0 = main_panels;
-    a.tail_rb = tail * 4;
-    const dim3 grid((unsigned)(tail * split));
-    if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, true, PROJ>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, true, PROJ>), grid, dim3(256), 0, s, a);
-    int rc = check_launch("mlp_fused(tail)");
-    if (rc) return rc;
-    const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical,
-                       (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M, PROJ ? 0 : 1);
-    rc = check_launch("mlp_reduce");
-    if (rc || !a.xn_out) return rc;
-    // second output for the split panels: the blocked LayerNorm kernel over their rows (a few thousand)
-    const int64_t rb0 = (int64_t)main_panels * 4;
-    return layernorm_rows_blocked(sizeof(E) == 2 && std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16,
-                                  reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + rb0 * (a.D / 4) * 512), (int64_t)a.M - rb0 * 32, a.D,
-                                  a.gamma_n, a.beta_n, a.eps, static_cast<char*>(a.xn_out) + rb0 * (a.D / 8) * 512, s);
-  }
-  return EFFOCR_OK;
+  a.panel0 = main_panels;                                // first split panel
+  a.main_wgs = main_panels;
+  a.tail_rb = tail * 4;
+  a.stagger_wgs = main_panels >= 4 * slots ? slots : 0;  // (the spread costs ~0.4 panel times at the end of the launch: worth it from ~4 rounds on)
+  const dim3 grid((unsigned)(main_panels + (split > 1 ? tail * split : 0)));
+  if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, PROJ>), grid, dim3(256), 0, s, a);
+  else if (split == 2) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, PROJ>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 0, PROJ>), grid, dim3(256), 0, s, a);
+  int rc = check_launch("mlp_fused");
+  if (rc || split == 1) return rc;
+  const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical,
+                     (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M, PROJ ? 0 : 1);
+  rc = check_launch("mlp_reduce");
+  if (rc || !a.xn_out) return rc;
+  // second output for the split panels: the blocked LayerNorm kernel over their rows (a few thousand)
+  const int64_t rb0 = (int64_t)main_panels * 4;
+  return layernorm_rows_blocked(sizeof(E) == 2 && std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16,
+                                reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + rb0 * (a.D / 4) * 512), (int64_t)a.M - rb0 * 32, a.D,
+                                a.gamma_n, a.beta_n, a.eps, static_cast<char*>(a.xn_out) + rb0 * (a.D / 8) * 512, s);
 }
 
 }  // namespace
