@@ -34,7 +34,7 @@ struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std:
 
 struct VitCfg { int D, depth, heads, mlp; };
 struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w;
-                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, projw_pp, fc2w_pp, projb_p, fc2b_p; };   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // fc2w_pp: k also permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
+                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, projw_pp, fc2w_pp, projb_p, fc2b_p, qkvw_bv, qkvb_v; };   // qkvw_bv / qkvb_v: the v rows permuted per 32 (qkvattn.hip)   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // fc2w_pp: k also permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
 struct ConvSpec { std::string w, bn; int cin, cout, k, stride, pad; size_t w_off, b_off; };
 
 }  // namespace
@@ -156,6 +156,8 @@ void build_vit(effocr_encoder* e) {
       L.projw_pp = a.take((size_t)D * D * es);
       L.projb_p = a.take((size_t)D * 4);
       L.fc2b_p = a.take((size_t)D * 4);
+      L.qkvw_bv = a.take((size_t)3 * D * D * es);
+      L.qkvb_v = a.take((size_t)3 * D * 4);
       {                                                  // gemm3 can run every linear (default where no row-panel kernel exists)
         L.qkvw_b = a.take((size_t)3 * D * D * es);
         L.projw_b = a.take((size_t)D * D * es);
@@ -230,11 +232,12 @@ int rowperm32(int p) {
   const int h = (p >> 2) & 1, r = (p & 3) + 4 * (p >> 3);
   return 8 * (2 * (r >> 3) + h) + (r & 7);
 }
-void put_op_blocked(std::vector<char>& blob, size_t off, const float* src, int N, int K, int prec, bool perm16 = false, bool rowperm = false) {
+void put_op_blocked(std::vector<char>& blob, size_t off, const float* src, int N, int K, int prec, bool perm16 = false, bool rowperm = false,
+                    int rowperm_from = 0) {                // rowperm applies to rows >= rowperm_from (a multiple of 32)
   uint16_t* d = reinterpret_cast<uint16_t*>(blob.data() + off);
   const int kch = K / 8;
   for (int n = 0; n < N; ++n) {
-    const int ns = rowperm ? (n & ~31) + rowperm32(n & 31) : n;
+    const int ns = (rowperm && n >= rowperm_from) ? (n & ~31) + rowperm32(n & 31) : n;
     for (int c = 0; c < kch; ++c) {
       uint16_t* cell = d + ((size_t)(n >> 5) * kch + c) * 256 + (n & 31) * 8;
       for (int e = 0; e < 8; ++e) {
@@ -282,6 +285,9 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
       put_op_blocked(blob, L.projw_pp, P(e, p + "attn.proj.weight").data(), D, D, e->prec, false, true);
       put_f32_rowperm(blob, L.projb_p, P(e, p + "attn.proj.bias").data(), D);
       put_f32_rowperm(blob, L.fc2b_p, P(e, p + "mlp.fc2.bias").data(), D);
+      put_op_blocked(blob, L.qkvw_bv, P(e, p + "attn.qkv.weight").data(), 3 * D, D, e->prec, false, true, 2 * D);
+      put_f32(blob, L.qkvb_v, P(e, p + "attn.qkv.bias").data(), 2 * (size_t)D);
+      put_f32_rowperm(blob, L.qkvb_v + (size_t)2 * D * 4, P(e, p + "attn.qkv.bias").data() + 2 * D, D);
       {
         put_op_blocked(blob, L.qkvw_b, P(e, p + "attn.qkv.weight").data(), 3 * D, D, e->prec);
         put_op_blocked(blob, L.projw_b, P(e, p + "attn.proj.weight").data(), D, D, e->prec);
@@ -414,7 +420,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         if (!xn_ready && (rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
         xn_ready = false;
         QkvAttnArgs q{};
-        q.xn = xn; q.Wb = wb + L.qkvw_b; q.bias = F(L.qkvb); q.out = att;
+        q.xn = xn; q.Wb = wb + L.qkvw_bv; q.bias = F(L.qkvb_v); q.out = att;
         q.B = B; q.T = T; q.D = D; q.rows_alloc = (int64_t)w.rows;
         if ((rc = timed(e, "qkv_attn_fused", 2.0 * Md * 3.0 * Dd * Dd + 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return qkv_attn_fused(prec, q, s); }))) return rc;
       } else {

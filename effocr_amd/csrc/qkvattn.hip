@@ -24,7 +24,8 @@
 //                 * k^T: the same registers for the key tokens = the A-operand fragment of S^T under the SAME
 //                   permutation (a dot product does not care): each lane drops its 16 bytes into LDS at
 //                   [key tile][k-step][lane] and every wave later reads the slot of its own lane id;
-//                 * v (unswapped): lane (dim, half) holds keys {0-3, 8-11 | 4-7, 12-15} + 16m of its dim = the
+//                 * v (unswapped; its weight rows permuted per 32 on the host so that the output tile hands a lane 8
+//                   consecutive head dims): lane (dim, half) holds keys {0-3, 8-11 | 4-7, 12-15} + 16m of its dim = the
 //                   A-operand fragment of O^T = V^T P^T under exactly the key permutation in which the S^T
 //                   C-layout hands over P.  Same lane-linear LDS image, [key tile][m][dim tile][lane].
 //                 K and V of the image (<= 56 KB) are the only activations that cross waves.
@@ -355,13 +356,18 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
 #if !(QAX & 16)
         if (tq < T) {
           const float inv = 1.0f / l;
-          char* ob = static_cast<char*>(a.out) + half * 8;
+          // The v rows of the weight copy are permuted per 32 (api.hip rowperm32): registers 8p..8p+7 of dim tile db are the 8
+          // CONSECUTIVE head dims 32db + 16p + 8half.. = one whole 16-byte chunk of the output row (8-byte half chunks before).
+          char* ob = static_cast<char*>(a.out);
 #pragma unroll
           for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-              *reinterpret_cast<u32x2*>(ob + blk_off(tok0 + tq, (h * 64 + db * 32 + 8 * q4) / 8, D / 8)) =
-                  pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+            for (int p = 0; p < 2; ++p) {
+              const u32x2 lo = pack4<E>(o[db][8 * p] * inv, o[db][8 * p + 1] * inv, o[db][8 * p + 2] * inv, o[db][8 * p + 3] * inv);
+              const u32x2 hi = pack4<E>(o[db][8 * p + 4] * inv, o[db][8 * p + 5] * inv, o[db][8 * p + 6] * inv, o[db][8 * p + 7] * inv);
+              const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+              *reinterpret_cast<u32x4*>(ob + blk_off(tok0 + tq, h * 8 + db * 4 + 2 * p + half, D / 8)) = v;
+            }
         }
 #else
         if (l == 12345.f && o[0][0] == 1.f && o[1][3] == 2.f) *reinterpret_cast<float*>(a.out) = l;

@@ -285,7 +285,9 @@ int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const vo
  *   out_blk (16-bit [batch*tokens, d] blocked, feature = head*64 + dim) = softmax(q k^T / 8) v,
  *   [q | k | v] = xn_blk . wqkv^T + bias   (heads = d / 64)
  * xn_blk: norm1(x), 16-bit blocked [batch*tokens, d] (effocr_op_layernorm_blocked, or the fused MLP kernel's second output);
- * wqkv_blk: attn.qkv.weight [3d, d] 16-bit fragment-blocked.  d in {128, 384}; tokens <= 64 or in 193..224.
+ * wqkv_blk: attn.qkv.weight [3d, d] 16-bit fragment-blocked with the v rows (rows 2d..3d) P32-permuted (see
+ * effocr_op_mlp_blocked: then a lane of the output tile holds 8 consecutive head dims = one 16-byte store); bias: attn.qkv.bias
+ * with its v part permuted alike.  d in {128, 384}; tokens <= 64 or in 193..224.
  * The qkv tensor never exists in device memory. */
 int effocr_op_qkv_attn_blocked(int precision, const void* xn_blk_dev, const void* wqkv_blk_dev, const float* bias_dev,
                                void* out_blk_dev, int batch, int tokens, int d, int rows_alloc, void* stream);

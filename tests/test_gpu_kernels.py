@@ -375,7 +375,9 @@ def test_qkv_attn_fused_blocked(hip_lib, dev, prec, B, T, D):
     w = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(TDT[prec])
     bias = 0.5 * torch.randn(3 * D, generator=g)
     ra = (M + 127) // 128 * 128
-    xd, wd, bd = to_blocked(xn, ra).to(dev), to_blocked(w, 3 * D).to(dev), bias.to(dev)
+    wv, bvp = w.clone(), bias.clone()                      # the kernel's weight copy: v rows (and bias) P32-permuted
+    wv[2 * D:], bvp[2 * D:] = perm32_rows(w[2 * D:]), perm32_rows(bias[2 * D:])
+    xd, wd, bd = to_blocked(xn, ra).to(dev), to_blocked(wv, 3 * D).to(dev), bvp.to(dev)
     out = torch.zeros(ra * D, dtype=TDT[prec], device=dev)
     _lib.check(hip_lib.effocr_op_qkv_attn_blocked(_lib.PREC[prec], _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), B, T, D, ra,
                                                   _stream(dev)), "op_qkv_attn_blocked")

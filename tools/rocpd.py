@@ -10,8 +10,11 @@ import json, os, re, sqlite3, sys
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
     ("qkvattn_kernel", "qkv_attn_fused"), ("knn_stream_kernel", "knn_stream"), ("knn_rerank", "knn_rerank"), ("knn_prep", "knn_prep"),
     ("layernorm_blocked_kernel", "layernorm_blocked"), ("conv_igemm", "conv_igemm"),
-    ("mlp_fused_kernelIDF16bLi384ELi1536ELi12ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "mlp_fused_tail"),
-    ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "mlp_fused_tail"), ("mlp_reduce_kernel", "mlp_fused_reduce"),
+    # mlp_fused_kernel<E, D, H, TNCW, PROJ>: whole panels + the split parts of the tail panels (TNCW chunks each) in one launch
+    ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "proj_mlp_main"),
+    ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb0", "mlp_fused_main"),
+    ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb0", "mlp_fused_main"),
+    ("mlp_reduce_kernel", "mlp_fused_reduce"),
     ("rowlin_kernel", "rowlin"), ("layernorm_blocked", "layernorm_blocked"),
     ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
     ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm3_kernelIDF16bLi3ELi4ELi2", "gemm_fc2_resid"),
@@ -82,9 +85,10 @@ def main(tag):
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             traffic[k] = {"read_bytes": 2 * d["FETCH_SIZE"] * 1024, "write_bytes": d["WRITE_SIZE"] * 1024,
                           "hbm_bytes_per_launch": 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024}
-    parts = [traffic[k] for k in ("mlp_fused_main", "mlp_fused_tail", "mlp_fused_reduce") if k in traffic]
-    if parts:   # bench.py times the three launches of the fused MLP as ONE class ("mlp_fused"): same aggregate here
-        traffic["mlp_fused"] = {key: sum(p[key] for p in parts) for key in parts[0]}
+    for main, agg in (("proj_mlp_main", "proj_mlp_fused"), ("mlp_fused_main", "mlp_fused")):
+        parts = [traffic[k] for k in (main, "mlp_fused_reduce") if k in traffic]
+        if main in traffic:   # bench.py times the launches of the fused MLP (main + reduction) as ONE class: same aggregate here
+            traffic[agg] = {key: sum(p[key] for p in parts) for key in parts[0]}
     with open(f"profiles/{tag}_traffic.json", "w") as f:
         json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md)",
                    "kernels": traffic}, f, indent=1)
