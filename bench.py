@@ -287,6 +287,7 @@ def main():
                 if a.arch == "vit_small_patch16_224":
                     del enc, x_full, x_shard
                     torch.cuda.empty_cache()
+                    line["c1"] = c1_extras(a, dev)
                     line["c4"] = c4_extras(a, dev)
                     torch.cuda.empty_cache()
                     line["c5"] = c5_extras(a, dev)
@@ -363,6 +364,32 @@ def small_batch_extras(a, enc, knn, sd, dev):
                          "exact_mfma_fp32_frac": round(2.0 * B * N * D / te / 157.3e12, 4),
                          "screened_ms": round(1e3 * ts, 3), "screened_hbm_frac_bf16_two_passes": round(2 * N * D * 2.0 / ts / 8.0e12, 4)}
     out["knn_1M_rows"] = {"index": f"{N} x {D} fp32 ({N * D * 4 / 1e9:.2f} GB)", "k": a.k, "hbm_peak_GBps": 8000, **rows}
+    return out
+
+
+RESNET18_FLOP_32 = 74.0e6    # 2 x MACs of timm resnet18 (no fc) at a 32x32 input: conv1 4.8 + layer1 18.9 + layers 2-4 3 x 16.8 MFLOP
+
+
+def c1_extras(a, dev):
+    """BASELINE configs[0] on the GPU: timm resnet18 (fp32 MFMA implicit-GEMM conv) over 32x32 crops + a 96-glyph index, at the
+    reference's own call size (64 crops) and at 1024."""
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import FaissKNN, IndexFlatIP
+    from effocr_amd.weights import init_state_dict
+    arch = "resnet18"
+    enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=32), img_size=32, precision="fp32", device=dev)
+    g = torch.Generator(device=dev).manual_seed(13)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.index = IndexFlatIP(512, device=dev)
+    knn.index.add(torch.nn.functional.normalize(torch.randn(96, 512, generator=g, device=dev), dim=1))
+    out = {"workload": "BASELINE configs[0] shapes on one GPU: resnet18 (fp32 operands, v_mfma_f32_32x32x2), 3x32x32 crops resident in HBM, "
+                       "96 x 512 fp32 IndexFlatIP, k=10"}
+    for B in (64, 1024):
+        x = torch.randn(B, 3, 32, 32, generator=g, device=dev)
+        step = lambda: knn(enc.forward(x, normalize=True), k=10)
+        t = _time_gpu(step, dev, 20, warm=3)
+        out[f"B{B}"] = {"crops_per_s": round(B / t, 1), "ms_per_call": round(1e3 * t, 3),
+                        "encoder_mfma_fp32_frac": round(B * RESNET18_FLOP_32 / t / MFMA_PEAK["fp32"], 4)}
     return out
 
 
