@@ -39,6 +39,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}      # dense, MI355X_MICROARCH.md
 FLOP_PER_CROP = {"vit_small_patch16_224": 9.197e9, "vit_base_patch16_224": 35.13e9}
+# last block, tokens 1..196: attn.proj (2 D^2) + MLP (4 D H) per token — dead work for a class-token embedding (see "flop_per_crop")
+PRUNED_FLOP_PER_CROP = {"vit_small_patch16_224": 196 * (2.0 * 384 * 384 + 4.0 * 384 * 1536)}
 
 
 def measured_traffic(kernel_class):
@@ -280,7 +282,13 @@ def main():
                                 "flops_per_launch": fl, "avg_launch_us": round(sec * 1e6, 2), "launches": p["launches"],
                                 "traffic": measured_traffic(dom) if (a.arch == "vit_small_patch16_224" and a.batch == 1024 and world == 1) else None}
         if a.arch in FLOP_PER_CROP:
-            line["encoder_mfma_frac_end_to_end"] = round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)
+            # FLOPs the GPU actually executes per crop: the library runs the last block's attn.proj + MLP only on the class-token row of
+            # every image (the only row that reaches the embedding; same result as the reference, which computes and discards the other
+            # 196 rows).  The fraction of peak below prices EXECUTED work; the model's nominal FLOPs are reported beside it.
+            pruned = PRUNED_FLOP_PER_CROP.get(a.arch, 0.0) if "proj_mlp_cls" in table else 0.0
+            line["encoder_mfma_frac_end_to_end"] = round(value / world * (FLOP_PER_CROP[a.arch] - pruned) / MFMA_PEAK[a.precision], 4)
+            line["flop_per_crop"] = {"model": FLOP_PER_CROP[a.arch], "executed": FLOP_PER_CROP[a.arch] - pruned,
+                                     "encoder_mfma_frac_at_model_flops": round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)}
         if world == 1 and not a.no_extras:
             try:
                 line["small_batch"] = small_batch_extras(a, enc, knn, sd, dev)

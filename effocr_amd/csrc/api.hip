@@ -61,6 +61,7 @@ struct effocr_encoder {
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
   int use_rowlin = 0;               // 1: register-resident-input kernels (rowlin.hip) for LN1+qkv and proj+residual instead of the row-panel ones (measured 7 % slower: A/B switch)
+  int cls_only_last = 1;            // last block: attn.proj + MLP only on the class-token rows (the only rows that reach the output); 0: all tokens (A/B switch)
   int mlp_stagger = 3500;           // fused MLP: start spread of the first round of workgroups, clock ticks per step of 32 (0 = off; applies from 4 rounds of CUs on)
   int use_projf = 1;                // 1: attn.proj + residual fused in front of the fused MLP kernel (the new row stays in the accumulators: -0.9 ms and -0.6 GB of HBM traffic per forward vs the separate row-panel launch); 0: A/B switch
   int use_qkvattn = 1;              // fused norm1 + attn.qkv + attention kernel (qkvattn.hip): no qkv tensor in HBM (0: A/B switch)
@@ -400,6 +401,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
   g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn; g.blk_out = blk;
   if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return g2p ? gemm2_nt(prec, EPI_PATCH, g, s) : gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
+  const float* cls_x = nullptr;                        // compact class-token rows after the last block (cls_only_last)
   bool xn_ready = false;                               // xn holds norm1(x) of the coming block (written by the previous block's MLP epilogue)
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
@@ -444,6 +446,19 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split; m.stagger = e->mlp_stagger;   // the hidden buffer is free on this path
         if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
           m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p);
+          if (i + 1 == e->vit.depth && e->cls_only_last) {
+            // last block: only row 0 of every image reaches the output and proj / LayerNorm / MLP act per row: run them on the B
+            // gathered class-token rows (compact buffers in the qkv region, free from here on) instead of B*T rows
+            const size_t Bp = align_up((size_t)B, 128);
+            float* xc = reinterpret_cast<float*>(qkv);
+            void* ac = static_cast<char*>(qkv) + Bp * D * 4;    // Bp*D*6 bytes <= the region's M*D*6 for every (B, T)
+            if ((rc = timed(e, "gather_cls", 0.0, s, [&] { return gather_cls_rows_blocked(xs, att, B, T, D, xc, ac, s); }))) return rc;
+            m.x = xc; m.A = ac; m.M = B; m.rows_alloc = (int)Bp;
+            const double Bd = B;
+            if ((rc = timed(e, "proj_mlp_cls", 4.0 * Bd * Hd * Dd + 2.0 * Bd * Dd * Dd, s, [&] { return mlp_fused(prec, m, s); }))) return rc;
+            cls_x = xc;
+            continue;
+          }
           if (qaf && i + 1 < e->vit.depth) {
             m.xn_out = xn; m.gamma_n = F(e->layers[i + 1].ln1w); m.beta_n = F(e->layers[i + 1].ln1b);
             xn_ready = true;
@@ -501,6 +516,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] {
           return g3 ? gemm3_nt(prec, EPI_BIAS_RESID, g, s) : g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }
+  if (cls_x) return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(cls_x, B, 1, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, 1, emb, s); });
   return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, blk, emb, s); });
 }
 
@@ -673,6 +689,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
   if (n == "use_qkvattn") { enc->use_qkvattn = value; return EFFOCR_OK; }
   if (n == "use_projf") { enc->use_projf = value; return EFFOCR_OK; }
+  if (n == "cls_only_last") { enc->cls_only_last = value; return EFFOCR_OK; }
   if (n == "mlp_stagger") { enc->mlp_stagger = value < 0 ? 0 : value; return EFFOCR_OK; }
   if (n == "use_rowlin") { enc->use_rowlin = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }

@@ -157,6 +157,20 @@ __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__
   }
 }
 
+// Last transformer block: only the class-token row of every image reaches the output (global_pool = 'token'), and
+// attn.proj / the MLP / both LayerNorms act on each row independently — so the block's second half runs on B gathered rows.
+// Gathers row img*T of x (fp32 blocked) and of the attention output (16-bit blocked) into compact blocked buffers [B rows].
+__global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict__ x, const char* __restrict__ att, int B, int T, int D,
+                                                         float* __restrict__ xc, char* __restrict__ ac) {
+  const int nx = D / 4, na = D / 8;                       // 16-byte chunks per row
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)B * (nx + na)) return;
+  const int img = (int)(id / (nx + na)), c = (int)(id % (nx + na));
+  if (c < nx) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xc) + blk_off(img, c, nx)) =
+                  *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + blk_off((int64_t)img * T, c, nx));
+  else *reinterpret_cast<u32x4*>(ac + blk_off(img, c - nx, na)) = *reinterpret_cast<const u32x4*>(att + blk_off((int64_t)img * T, c - nx, na));
+}
+
 // token 0 of every image = cls_token + pos_embed[0] (pre-added on the host at weight upload)
 __global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D, int blocked) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -462,6 +476,14 @@ int launch_attn_mfma(const E* qkv, E* out, int B, int T, int heads, hipStream_t 
 }
 
 }  // namespace
+
+int gather_cls_rows_blocked(const float* x, const void* att, int B, int T, int D, float* xc, void* ac, hipStream_t s) {
+  if (B <= 0) return EFFOCR_OK;
+  const int64_t total = (int64_t)B * (D / 4 + D / 8);
+  hipLaunchKernelGGL(gather_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, static_cast<const char*>(att), B, T, D, xc,
+                     static_cast<char*>(ac));
+  return check_launch("gather_cls");
+}
 
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                    float eps, void* out, hipStream_t s) {

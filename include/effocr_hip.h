@@ -97,6 +97,9 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *   "use_gemm3"   [1] 128-row wave-tile GEMM over blocked operands (fc2; every ViT-B linear); 0: gemm2 / gemm
  *   "use_gemm2"   [1] DMA-ring GEMM for the patch embedding (and fc2 when use_gemm3 = 0)
  *   "tail_split"  [1] split the panels / tiles of the last, partially filled round of CUs
+ *   "cls_only_last" [1] last transformer block: attn.proj + MLP only on the class-token row of every image — the only row that
+ *                 reaches the embedding (global_pool = 'token'); proj / LayerNorm / MLP act per row, so the result is the same
+ *                 (0: all tokens, A/B switch)
  *   "mlp_stagger" [3500] fused MLP kernel: the first round of workgroups starts spread over 32 x this many clock ticks, so
  *                 that the CUs do not request / store their rows all at the same moment (0 = off; used from 4 rounds of CUs on)
  *   "use_projf"   [1] attn.proj + residual fused in front of the fused MLP kernel (0: its own row-panel launch)

@@ -147,12 +147,13 @@ def test_every_switchable_path_matches_the_oracle(dev, B):
         for name, opts in [("unfused_mlp", {"use_mlp": 0}), ("separate_proj", {"use_projf": 0}), ("rowlin", {"use_rowlin": 1}),
                            ("gemm2_fc2", {"use_mlp": 0, "use_gemm3": 0}), ("no_tail_split", {"tail_split": 0}),
                            ("fused_qkv_attention", {"use_qkvattn": 2}), ("fused_qkv_attention+separate_proj", {"use_qkvattn": 2, "use_projf": 0}),
-                           ("fused_qkv_attention_no_tail_split", {"use_qkvattn": 2, "tail_split": 0}), ("panel_qkv+attention", {"use_qkvattn": 0})]:
+                           ("fused_qkv_attention_no_tail_split", {"use_qkvattn": 2, "tail_split": 0}), ("panel_qkv+attention", {"use_qkvattn": 0}),
+                           ("all_tokens_in_last_block", {"cls_only_last": 0}), ("all_tokens_in_last_block+fused_qkv", {"cls_only_last": 0, "use_qkvattn": 2})]:
             for k, v in opts.items():
                 enc.set_option(k, v)
             outs[name] = enc.forward(x.to(dev)).cpu()
             for k in opts:                                   # back to the defaults
-                enc.set_option(k, {"use_mlp": 1, "use_projf": 1, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1, "use_qkvattn": 1}[k])
+                enc.set_option(k, {"use_mlp": 1, "use_projf": 1, "use_rowlin": 0, "use_gemm3": 1, "tail_split": 1, "use_qkvattn": 1, "cls_only_last": 1}[k])
         assert torch.equal(outs["default"], enc.forward(x.to(dev)).cpu())          # switches restored, run-to-run bitwise
         for name, o in outs.items():
             assert rel_err(o, ref) <= REL[prec], (name, prec, B, rel_err(o, ref))
