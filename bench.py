@@ -286,6 +286,8 @@ def main():
             # every image (the only row that reaches the embedding; same result as the reference, which computes and discards the other
             # 196 rows).  The fraction of peak below prices EXECUTED work; the model's nominal FLOPs are reported beside it.
             pruned = PRUNED_FLOP_PER_CROP.get(a.arch, 0.0) if "proj_mlp_cls" in table else 0.0
+            if pruned and "qkv_attn_fused" in table:        # ... and its q projection + attention rows (per-image kernel, class-token variant)
+                pruned += (197 - 32) * (2.0 * 384 * 384 + 4.0 * 197 * 384)      # (it computes one 32-token tile per image)
             line["encoder_mfma_frac_end_to_end"] = round(value / world * (FLOP_PER_CROP[a.arch] - pruned) / MFMA_PEAK[a.precision], 4)
             line["flop_per_crop"] = {"model": FLOP_PER_CROP[a.arch], "executed": FLOP_PER_CROP[a.arch] - pruned,
                                      "encoder_mfma_frac_at_model_flops": round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)}

@@ -424,7 +424,12 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         QkvAttnArgs q{};
         q.xn = xn; q.Wb = wb + L.qkvw_bv; q.bias = F(L.qkvb_v); q.out = att;
         q.B = B; q.T = T; q.D = D; q.rows_alloc = (int64_t)w.rows;
-        if ((rc = timed(e, "qkv_attn_fused", 2.0 * Md * 3.0 * Dd * Dd + 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return qkv_attn_fused(prec, q, s); }))) return rc;
+        q.cls_only = (i + 1 == e->vit.depth && e->cls_only_last && projf) ? 1 : 0;   // the rest of the last block runs on the class-token rows only
+        // work executed: the class-token variant projects q and runs the attention for ONE 32-token tile per image (where it exists: D = 384, 193..224 tokens)
+        const bool cls_k = q.cls_only && D == 384 && T > 192;
+        const double qa_work = cls_k ? 2.0 * Md * 2.0 * Dd * Dd + 2.0 * (32.0 * B) * Dd * Dd + 4.0 * B * e->vit.heads * 32.0 * T * 64.0
+                                     : 2.0 * Md * 3.0 * Dd * Dd + 4.0 * B * e->vit.heads * (double)T * T * 64.0;
+        if ((rc = timed(e, "qkv_attn_fused", qa_work, s, [&] { return qkv_attn_fused(prec, q, s); }))) return rc;
       } else {
       p.A = xs; p.lda = D; p.gamma = F(L.ln1w); p.beta = F(L.ln1b); p.eps = 1e-6f; p.W = wb + L.qkvw; p.bias = F(L.qkvb);
       p.out = qkv; p.ldo = 3 * D; p.M = M; p.N = 3 * D; p.K = D; p.rows_padded = 1; p.debug = e->debug; p.panel_rows = e->panel_rows; p.no_tail_split = !e->tail_split;

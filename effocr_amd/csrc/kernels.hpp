@@ -67,6 +67,8 @@ struct QkvAttnArgs {
   void* out;                        // attention output, 16-bit fragment-blocked [rows_alloc, D] (feature = head * 64 + dim)
   int B, T, D;                      // images, tokens per image, embed dim (heads = D / 64)
   int64_t rows_alloc;               // rows addressable in xn / out (multiple of 32, >= B * T)
+  int cls_only;                     // 1: only the attention rows of token tile 0 of every image are needed (last block); a hint — shapes
+                                    // without the specialised kernel compute every row
 };
 bool qkv_attn_supported(int prec, int D, int T);
 int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s);

@@ -70,7 +70,9 @@ __device__ unsigned long long qa_timeline[1024 * 32];    // [workgroup][stamp]: 
 constexpr int QA_STAGE = 16384;                          // bytes per ring stage: 2 row blocks x 16 k-chunks x 512 B
 constexpr int QA_RING = 6;
 
-template <typename E, int D, int NTT>
+// CLS: the LAST transformer block — only the class token's attention row reaches the output (the rest of the block then runs
+// on B gathered rows, api.hip): k and v of every token as usual, q and the attention only for token tile 0 (wave 0).
+template <typename E, int D, int NTT, bool CLS = false>
 __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   typedef typename Op16<E>::V8 V8;
   constexpr int HEADS = D / 64;
@@ -210,7 +212,12 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
 #endif
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-              if constexpr (sec < 2) {                   // q^T, k^T: rows = features, cols = tokens
+              if constexpr (CLS && sec == 0) {           // q only where the class token lives
+                if (w == 0 && tt == 0) {
+                  acc[tt][0] = Op16<E>::mfma(f0, xf[tt][kt * 8 + ks], acc[tt][0]);
+                  acc[tt][1] = Op16<E>::mfma(f1, xf[tt][kt * 8 + ks], acc[tt][1]);
+                }
+              } else if constexpr (sec < 2) {            // q^T, k^T: rows = features, cols = tokens
                 acc[tt][0] = Op16<E>::mfma(f0, xf[tt][kt * 8 + ks], acc[tt][0]);
                 acc[tt][1] = Op16<E>::mfma(f1, xf[tt][kt * 8 + ks], acc[tt][1]);
               } else {                                   // v: rows = tokens, cols = features
@@ -273,8 +280,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       const char* kb = sK + lane * 16;
       const char* vb = sV + lane * 16;
 #if !(QAX & 1)
-      qa_for<0, NT>([&](auto TT_) {
+      qa_for<0, (CLS ? 1 : NT)>([&](auto TT_) {
         constexpr int tt = decltype(TT_)::value;
+        if constexpr (CLS) { if (w != 0) return; }       // (wave-uniform; the other waves go on to the next head's weight stream)
         __builtin_amdgcn_sched_barrier(0);               // one query tile at a time (two score rows do not fit)
         const int tq = (2 * w + tt) * 32 + r31;
         f32x16 s[NTT];
@@ -423,7 +431,8 @@ int launch_qkvattn(const QkvAttnArgs& a, hipStream_t s) {
     cus = v;
   }
   const dim3 grid((unsigned)(a.B < cus ? a.B : cus)), blk(256);   // one persistent workgroup per CU (160 KB of LDS each)
-  if (a.D == 384 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7>), grid, blk, 0, s, a);
+  if (a.D == 384 && ntt == 7 && a.cls_only) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true>), grid, blk, 0, s, a);
+  else if (a.D == 384 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7>), grid, blk, 0, s, a);
   else if (a.D == 384 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 2>), grid, blk, 0, s, a);
   else if (a.D == 128 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 7>), grid, blk, 0, s, a);
   else if (a.D == 128 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 2>), grid, blk, 0, s, a);
