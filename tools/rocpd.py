@@ -14,7 +14,7 @@ CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "proj_mlp_main"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb0", "mlp_fused_main"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb0", "mlp_fused_main"),
-    ("mlp_reduce_kernel", "mlp_fused_reduce"),
+    ("mlp_reduce_kernel", "mlp_fused_reduce"), ("gather_cls", "gather_cls"),
     ("rowlin_kernel", "rowlin"), ("layernorm_blocked", "layernorm_blocked"),
     ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
     ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm3_kernelIDF16bLi3ELi4ELi2", "gemm_fc2_resid"),
