@@ -494,6 +494,28 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
       if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return lin(xn, D, L.qkvw_b, F(L.qkvb), qkv, 3 * D, EPI_BIAS); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, 1, s); }))) return rc;
+      const size_t Bp = align_up((size_t)B, 256);
+      if (i + 1 == e->vit.depth && e->cls_only_last && g3 && Bp <= w.rows) {
+        // last block: only the class-token rows reach the output (see the fused path above): proj, LayerNorm, fc1, fc2 on B gathered rows.
+        // Compact buffers: x and the attention rows in the qkv region (free after the attention), norm2 in xn, the hidden rows in hb.
+        float* xc = reinterpret_cast<float*>(qkv);
+        void* ac = static_cast<char*>(qkv) + Bp * D * 4;
+        if ((rc = timed(e, "gather_cls", 0.0, s, [&] { return gather_cls_rows_blocked(xs, att, B, T, D, xc, ac, s); }))) return rc;
+        auto linc = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi) {
+          GemmArgs q{};
+          q.X = X; q.ldx = K; q.Wblk = wb + wblk; q.bias = bias; q.out = out; q.ldo = N; q.M = B; q.N = N; q.K = K;
+          q.blk_x = 1; q.blk_out = 1; q.rows_alloc = (int)Bp; q.no_tail_split = !e->tail_split;
+          if (epi == EPI_BIAS_RESID) { q.resid = xc; q.ldr = N; }
+          return gemm3_nt(prec, epi, q, s);
+        };
+        const double Bd = B;
+        if ((rc = timed(e, "cls_proj_resid", 2.0 * Bd * Dd * Dd, s, [&] { return linc(ac, D, L.projw_b, F(L.projb), xc, D, EPI_BIAS_RESID); }))) return rc;
+        if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xc, B, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
+        if ((rc = timed(e, "cls_fc1_gelu", 2.0 * Bd * Hd * Dd, s, [&] { return linc(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;
+        if ((rc = timed(e, "cls_fc2_resid", 2.0 * Bd * Dd * Hd, s, [&] { return linc(hb, e->vit.mlp, L.fc2w_b, F(L.fc2b), xc, D, EPI_BIAS_RESID); }))) return rc;
+        cls_x = xc;
+        continue;
+      }
       if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return lin(att, D, L.projw_b, F(L.projb), xs, D, EPI_BIAS_RESID); }))) return rc;
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
       if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return lin(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;

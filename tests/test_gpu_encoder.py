@@ -199,3 +199,8 @@ def test_full_size_config4_encoder_properties(dev):
     sel = [0, 777, 1023]
     ref = l2_normalize(encoder_forward(arch, sd, x[sel].cpu()))
     assert rel_err(e1[sel].cpu(), ref) <= REL["bf16"]
+    # the default runs the last block's proj / LayerNorm / MLP on the class-token rows only; with every token it is the same embedding
+    enc.set_option("cls_only_last", 0)
+    e0 = enc.forward(x, normalize=True)
+    enc.set_option("cls_only_last", 1)
+    assert rel_err(e0.cpu(), e1.cpu()) <= 1e-5 and rel_err(e0[sel].cpu(), ref) <= REL["bf16"]
