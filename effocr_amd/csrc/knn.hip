@@ -31,6 +31,7 @@ namespace {
 
 using namespace tile128;
 
+int g_knn_wg_target = 1024;          // workgroups a launch aims for (2 resident per CU); knn_set_option("wg_target")
 bool g_knn_force_tile = false;        // A/B switch (tests): 1 = always the 128-query tile kernel
 constexpr int ID_NONE = INT_MAX;          // internal sentinel id (ranks after every real id)
 constexpr int MAX_CHUNKS = 256;
@@ -322,7 +323,7 @@ Plan make_plan(int64_t B, int64_t N, int k) {
   p.ntiles = (int)((N + 127) / 128);
   if (p.ntiles < 1) p.ntiles = 1;
   // aim for ~2 resident workgroups per CU (512) without making chunks shorter than one tile
-  int want = 512 / (p.nqt > 0 ? p.nqt : 1);
+  int want = g_knn_wg_target / (p.nqt > 0 ? p.nqt : 1);
   if (want < 1) want = 1;
   if (want > MAX_CHUNKS) want = MAX_CHUNKS;
   if (want > p.ntiles) want = p.ntiles;
@@ -690,6 +691,7 @@ size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   return screen_ws(B, N, D, k).total;
 }
 void knn_force_tile_kernel(int on) { g_knn_force_tile = on != 0; }
+void knn_set_wg_target(int n) { g_knn_wg_target = n < 1 ? 1 : n; }
 size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k) {
   if (B <= 0 || k <= 0) return 0;
   return screen_ws(B, N, D, k).flag;

@@ -139,7 +139,8 @@ int effocr_knn_ip_topk(const float* q_dev, int64_t nq, const float* xb_dev, int6
 size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k);
 /* Process-wide A/B switch of the exact search: "force_tile" [0] — 1 makes effocr_knn_ip_topk use the 128-query tile kernel
  * also for <= 32 queries (by default those go to the streaming kernel that reads the index at the HBM rate; results are
- * bit-identical either way). */
+ * bit-identical either way).  "wg_target" [1024] — workgroups a tile-kernel launch aims for when it cuts the index into chunks
+ * (set it before effocr_knn_workspace_bytes: the partial-list area follows the chunk count; results are bit-identical). */
 int effocr_knn_set_option(const char* name, int value);
 /* Byte offset, inside the screened search's workspace, of its int32 OVERFLOW FLAG: non-zero after a call in which some
  * query had more than 512 candidates within the error band, i.e. the call also ran the exact pass (results are
