@@ -43,7 +43,7 @@
 #define EFFOCR_EXP 0
 #endif
 // timing experiments (never shipped): -DEFFOCR_EXP=3000+bits; 1 no attention, 2 no projection MFMAs, 4 no x loads,
-// 8 no stage barrier, 16 no output stores, 32 no accumulator -> fragment conversion
+// 8 no stage barrier, 16 no output stores, 32 no accumulator -> fragment conversion, 128 no weight DMA, 256 no weight fragment reads
 #if EFFOCR_EXP >= 3000 && EFFOCR_EXP < 4000
 #define QAX (EFFOCR_EXP - 3000)
 #else
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     const int rb = (isec * D + ih * 64) / 32 + (w >> 1);
     const char* src = Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8 + 2 * p) * 512 + lane * 16;
     char* dst = sW + islot * QA_STAGE + ((w >> 1) * 16 + (w & 1) * 8 + 2 * p) * 512;
+#if (QAX & 128)
+    if (a.T < 0)
+#endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
@@ -200,6 +203,10 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               asm volatile("" ::: "memory");
             }
             V8 n0, n1;
+#if (QAX & 256)
+            n0 = f0; n1 = f1;
+            if (a.T < 0)
+#endif
             if constexpr (ks < 7) {
               n0 = *reinterpret_cast<const V8*>(st + (2 * (ks + 1)) * 512);
               n1 = *reinterpret_cast<const V8*>(st + (16 + 2 * (ks + 1)) * 512);
