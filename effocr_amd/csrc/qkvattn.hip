@@ -161,6 +161,12 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     int g = 0;                                           // its index in the workgroup's stream (used by the SMALL path only)
 
     const float cexp = 0.125f * 1.44269504088896340736f; // head_dim^-0.5 * log2(e)
+    // Padded keys (the last key tile of a 193..224-token image) are masked by STARTING their score accumulators at -inf: one
+    // per-lane initial tile, computed once, instead of a compare + select per score per query tile per head.
+    constexpr bool INITMASK = NTT > 2;
+    f32x16 sinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sinit[r] = ((NTT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) >= T) ? -INFINITY : 0.f;
 
     auto head = [&](auto LAST_, auto PRE_, int h, int hi, int img_next) __attribute__((always_inline)) {
       constexpr bool LAST = decltype(LAST_)::value;        // last head of the workgroup's last image: the ring runs dry
@@ -302,8 +308,11 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[nxt][ks] = *reinterpret_cast<const V8*>(kb + ((kt + 1) * 4 + ks) * 1024);
           }
+          if constexpr (INITMASK && kt == NTT - 1) s[kt] = sinit;
+          else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+          }
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) s[kt] = Op16<E>::mfma(kf[cur][ks], qf[tt][ks], s[kt]);
           __builtin_amdgcn_sched_barrier(0);
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         for (int kt = 0; kt < NTT; ++kt) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            if (kt == NTT - 1 || NTT <= 2) {             // tiles that may hold padded keys
+            if (!INITMASK) {                             // (<= 64 tokens: any tile may hold padded keys)
               const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
               if (key >= T) s[kt][r] = -INFINITY;
             }
