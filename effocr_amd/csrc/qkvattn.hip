@@ -351,14 +351,18 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         V8 pf[2];
         auto p_frag = [&](auto ST_) __attribute__((always_inline)) {
           constexpr int st = decltype(ST_)::value, kt = st >> 1, m = st & 1;
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          f32x2 av[4];
+          float ev[8];
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {               // exponent arguments two at a time (v_pk_fma_f32)
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x2 sv = {s[kt][8 * m + j], s[kt][8 * m + j + 1]};
-            const f32x2 av = __builtin_elementwise_fma(sv, f32x2{cexp, cexp}, f32x2{-mxc, -mxc});
-            pf[st & 1][j] = (E)__builtin_amdgcn_exp2f(av[0]);
-            pf[st & 1][j + 1] = (E)__builtin_amdgcn_exp2f(av[1]);
+          for (int j = 0; j < 4; ++j) {                  // exponent arguments two at a time (v_pk_fma_f32)
+            const f32x2 sv = {s[kt][8 * m + 2 * j], s[kt][8 * m + 2 * j + 1]};
+            av[j] = __builtin_elementwise_fma(sv, f32x2{cexp, cexp}, f32x2{-mxc, -mxc});
           }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ev[j] = __builtin_amdgcn_exp2f(av[j >> 1][j & 1]);   // all eight before the first is consumed:
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[st & 1][j] = (E)ev[j];                           // a transcendental result needs a wait state
         };
         p_frag(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
