@@ -208,3 +208,23 @@ def test_streaming_kernel_small_batches_bit_exact(hip_lib, dev, B, N, D, k):
         _lib.check(hip_lib.effocr_knn_set_option(b"force_tile", 0), "knn_set_option")
     assert torch.equal(It, Iv) and torch.equal(Dt.view(torch.int32), Dv.view(torch.int32))
     assert hip_lib.effocr_knn_set_option(b"nope", 1) == -1
+
+
+def test_chunk_plan_does_not_change_the_result(hip_lib, dev):
+    """The tile kernel cuts the index into chunks so that ~wg_target workgroups exist; every score is still one ascending-k
+    fp32 chain and the merge of the partial lists is exact: ids and score bits are the same for any chunking and equal the oracle."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator().manual_seed(77)
+    X = torch.nn.functional.normalize(torch.randn(10000, 384, generator=g), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(200, 384, generator=g), dim=1)
+    D_ref, I_ref = knn_ref.flat_ip_search(Q.numpy(), X.numpy(), 10)
+    try:
+        for target in (64, 512, 1024, 4096):
+            _lib.check(hip_lib.effocr_knn_set_option(b"wg_target", target), "knn_set_option")
+            idx = IndexFlatIP(384, device=dev, screen=False)
+            idx.add(X)
+            Dv, Iv = idx.search_device(Q.to(dev), 10)
+            assert np.array_equal(Iv.cpu().numpy(), I_ref), target
+            assert np.array_equal(Dv.cpu().numpy().view(np.uint32), D_ref.view(np.uint32)), target
+    finally:
+        _lib.check(hip_lib.effocr_knn_set_option(b"wg_target", 1024), "knn_set_option")
