@@ -488,29 +488,30 @@ def c5_extras(a, dev):
         res = loc(lines)                                   # one call: batched network, NMS launches back to back, one sync
         return res, time.perf_counter() - t0
 
-    def recognize(im, res):
+    def recognize(ims, ress):
+        """All lines of the call at once: boxes on the host (one D2H per line), crops per line on the device, ONE encoder +
+        k-NN call over the crops of every line (the reference batches crops across lines too: create_batches, 64 per batch)."""
         t1 = time.perf_counter()
-        chars = res[res[:, -1] == 0][:64, :4]
-        boxes = []
-        for bb in chars:
-            x0, x1 = int(round(float(torch.round(bb[0])) * W / 640)), int(round(float(torch.round(bb[2])) * W / 640))
-            if x1 > x0:
-                boxes.append((max(x0, 0), 0, min(x1, W), H))
-        n = len(boxes)
-        if n:
-            crops = tf.boxes(im, boxes, already_int=True)
-            ids = knn(enc.forward(crops, normalize=True), k=a.k)[1]
+        crops, n = [], 0
+        for im, res in zip(ims, ress):
+            r = res.cpu()
+            chars = r[r[:, -1] == 0][:64, :4].round()
+            x0 = (chars[:, 0] * W / 640).round().clamp(min=0).to(torch.int64).tolist()
+            x1 = (chars[:, 2] * W / 640).round().clamp(max=W).to(torch.int64).tolist()
+            boxes = [(u, 0, v, H) for u, v in zip(x0, x1) if v > u]
+            if boxes:
+                crops.append(tf.boxes(im, boxes, already_int=True))
+                n += len(boxes)
+        if crops:
+            ids = knn(enc.forward(torch.cat(crops), normalize=True), k=a.k)[1]
             ids.cpu()
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t1, n
 
     results, _ = localize()
-    recognize(lines[0], results[0])
+    recognize(lines, results)
     results, tl = localize()
-    tr = nb = 0
-    for im, res in zip(lines, results):
-        b_, n = recognize(im, res)
-        tr += b_; nb += n
+    tr, nb = recognize(lines, results)
     # the localizer network alone, batched, device-resident input
     x = torch.rand(16, 3, 640, 640, device=dev)
     tn = _time_gpu(lambda: loc._eng_net.forward(x), dev, 5)

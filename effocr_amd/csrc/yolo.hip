@@ -177,15 +177,30 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
                                                        const float* __restrict__ cs, const int* __restrict__ cc, int max_nms, float max_wh,
                                                        int agnostic, float* __restrict__ srt) {
   const int m = *counter;
+  if ((int)blockIdx.x * 256 >= m) return;
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= m) return;
-  const float s = cs[p]; const int i = ci[p];
+  const bool live = p < m;
+  const float s = live ? cs[p] : 0.f; const int i = live ? ci[p] : 0;
+  // every thread compares against every candidate: the candidates go through LDS in tiles (one broadcast read per compare
+  // instead of two global loads)
+  __shared__ float ts[1024];
+  __shared__ int ti[1024];
   int rank = 0;
-  for (int q = 0; q < m; ++q) {
-    const float sq = cs[q];
-    rank += (sq > s || (sq == s && ci[q] < i)) ? 1 : 0;
+  for (int q0 = 0; q0 < m; q0 += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) {
+      const int q = q0 + t;
+      ts[t] = q < m ? cs[q] : -INFINITY;                  // (-inf, INT_MAX) never outranks anything
+      ti[t] = q < m ? ci[q] : 0x7fffffff;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int t = 0; t < 1024; ++t) {
+      const float sq = ts[t];
+      rank += (sq > s || (sq == s && ti[t] < i)) ? 1 : 0;
+    }
   }
-  if (rank >= max_nms) return;
+  if (!live || rank >= max_nms) return;
   const float* b = pred + (int64_t)i * (5 + nc);
   const float x1 = b[0] - b[2] / 2, y1 = b[1] - b[3] / 2, x2 = b[0] + b[2] / 2, y2 = b[1] + b[3] / 2;   // xywh2xyxy
   const float off = agnostic ? 0.f : (float)cc[p] * max_wh;
@@ -218,8 +233,13 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
   mask[id] = bits;
 }
 
-// greedy scan in rank order by ONE wave: lane l holds the words l, l+64, ... of the `removed` bit set
+// greedy scan in rank order by ONE wave: lane l holds the words l, l+64, ... of the `removed` bit set.  Only the mask rows of
+// boxes that are still unsuppressed are ever loaded (a localizer that fires on every anchor ranks 25 200 boxes and keeps ~70:
+// reading all 25 200 rows of 3 KB cost 1.4 ms per image): the next NMS_G unsuppressed boxes under the current bit set are found
+// first, their rows requested together (one memory latency per group), then they are taken in order, each re-checked against
+// the rows OR-ed in by its predecessors in the group.
 constexpr int NMS_WPL = 8;                                // words per lane: up to 64 * 8 * 64 = 32768 ranked boxes
+constexpr int NMS_G = 4;
 __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ srt, const int* __restrict__ counter, int max_nms, int max_det,
                                                       const unsigned long long* __restrict__ mask, float* __restrict__ out, int* __restrict__ count) {
   int m = *counter; m = m < max_nms ? m : max_nms;
@@ -228,36 +248,59 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
   unsigned long long rem[NMS_WPL];
 #pragma unroll
   for (int t = 0; t < NMS_WPL; ++t) rem[t] = 0ull;
-  int kept = 0;
-  for (int i0 = 0; i0 < m && kept < max_det; i0 += 8) {
-    // the next 8 rows' masks are requested together (one memory latency per 8 boxes instead of one per box)
-    unsigned long long row[8][NMS_WPL];
+  auto word_of = [&](int w) -> unsigned long long {      // word w of the bit set, to every lane
+    const int t = w >> 6, src = w & 63;
+    unsigned long long word = 0ull;
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int tt = 0; tt < NMS_WPL; ++tt) if (tt == t) word = rem[tt];
+    const unsigned lo = __shfl((unsigned)(word & 0xffffffffull), src, 64), hi = __shfl((unsigned)(word >> 32), src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  int kept = 0, pos = 0;                                  // every box below pos is decided
+  while (pos < m && kept < max_det) {
+    // the next (up to) NMS_G boxes >= pos that are unsuppressed NOW
+    int cand[NMS_G], nc = 0, w = pos >> 6;
+    unsigned long long free_bits = ~word_of(w) & (~0ull << (pos & 63));
+#pragma unroll
+    for (int r = 0; r < NMS_G; ++r) {                     // (unrolled: cand[] stays in registers)
+      cand[r] = -1;
+      while (w < nw) {
+        if (w == nw - 1 && (m & 63)) free_bits &= (1ull << (m & 63)) - 1ull;   // bits past the last box
+        if (free_bits != 0ull) break;
+        if (++w < nw) free_bits = ~word_of(w);
+      }
+      if (w < nw) {
+        cand[r] = w * 64 + __builtin_ctzll(free_bits);
+        free_bits &= free_bits - 1ull;
+        nc = r + 1;
+      }
+    }
+    if (nc == 0) break;
+    unsigned long long row[NMS_G][NMS_WPL];
+#pragma unroll
+    for (int r = 0; r < NMS_G; ++r)
 #pragma unroll
       for (int t = 0; t < NMS_WPL; ++t) {
-        const int w = lane + 64 * t;
-        row[r][t] = (i0 + r < m && w < nw) ? mask[(int64_t)(i0 + r) * nw + w] : 0ull;
+        const int ww = lane + 64 * t;
+        row[r][t] = (cand[r] >= 0 && ww < nw) ? mask[(int64_t)cand[r] * nw + ww] : 0ull;
       }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int i = i0 + r;
-      if (i >= m || kept >= max_det) break;
-      const int w = i >> 6, t = w >> 6, src = w & 63;
-      unsigned long long word = 0ull;
-#pragma unroll
-      for (int tt = 0; tt < NMS_WPL; ++tt) if (tt == t) word = rem[tt];
-      const unsigned lo = __shfl((unsigned)(word & 0xffffffffull), src, 64), hi = __shfl((unsigned)(word >> 32), src, 64);
-      const unsigned long long ww = ((unsigned long long)hi << 32) | lo;
-      if ((ww >> (i & 63)) & 1ull) continue;              // suppressed by a kept, more confident box
+    for (int r = 0; r < NMS_G; ++r) {
+      const int i = cand[r];
+      if (i < 0 || kept >= max_det) break;
+      if ((word_of(i >> 6) >> (i & 63)) & 1ull) continue;  // suppressed by a predecessor of this group
       if (lane < 6) {
-        const float* s = srt + (int64_t)i * 10;
-        out[(int64_t)kept * 6 + lane] = lane < 4 ? s[6 + lane] : s[lane];
+        const float* sr = srt + (int64_t)i * 10;
+        out[(int64_t)kept * 6 + lane] = lane < 4 ? sr[6 + lane] : sr[lane];
       }
       ++kept;
 #pragma unroll
       for (int tt = 0; tt < NMS_WPL; ++tt) rem[tt] |= row[r][tt];
     }
+    int last = cand[0];
+#pragma unroll
+    for (int r = 1; r < NMS_G; ++r) last = cand[r] >= 0 ? cand[r] : last;
+    pos = last + 1;
   }
   if (lane == 0) *count = kept;
 }
