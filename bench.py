@@ -515,13 +515,17 @@ def c5_extras(a, dev):
     # the localizer network alone, batched, device-resident input
     x = torch.rand(16, 3, 640, 640, device=dev)
     tn = _time_gpu(lambda: loc._eng_net.forward(x), dev, 5)
+    loc._eng_net.set_option("bf16_operands", 1)            # the optional bf16-operand convolutions (EffLocalizer(precision="bf16"))
+    tn16 = _time_gpu(lambda: loc._eng_net.forward(x), dev, 5)
+    loc._eng_net.set_option("bf16_operands", 0)
     fl = yolov5s_flops(nc, 640, 640)
     return {"workload": "BASELINE configs[4] on 1 GPU: 4096x256 uint8 text-line images -> YOLOv5s localizer (640x640 letterbox, fp32 MFMA, device NMS) "
                         f"-> <=64 char boxes per line -> device crops -> {arch} ({a.precision}) -> {a.index_rows}-row IndexFlatIP, k={a.k}; seeded random weights",
             "lines_per_s": round(len(lines) / (tl + tr), 2), "boxes_per_line": round(nb / len(lines), 1),
             "localizer_ms_per_line": round(1e3 * tl / len(lines), 3), "recognizer_ms_per_line": round(1e3 * tr / len(lines), 3),
             "localizer_network_images_per_s_batch16": round(16 / tn, 1), "localizer_network_ms_per_image": round(1e3 * tn / 16, 3),
-            "localizer_GFLOP_per_image": round(fl / 1e9, 2), "localizer_mfma_fp32_frac": round(16 * fl / tn / 157.3e12, 4)}
+            "localizer_GFLOP_per_image": round(fl / 1e9, 2), "localizer_mfma_fp32_frac": round(16 * fl / tn / 157.3e12, 4),
+            "localizer_network_ms_per_image_bf16_operands": round(1e3 * tn16 / 16, 3)}
 
 
 if __name__ == "__main__":

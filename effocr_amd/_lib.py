@@ -80,6 +80,7 @@ def _declare(lib):
         "effocr_localizer_set_param": (i32, [vp, c.c_char_p, vp, i64]),
         "effocr_localizer_weights_bytes": (sz, [vp]),
         "effocr_localizer_upload": (i32, [vp, vp, sz]),
+        "effocr_localizer_set_option": (i32, [vp, c.c_char_p, i32]),
         "effocr_localizer_num_predictions": (i64, [vp]),
         "effocr_localizer_num_outputs": (i32, [vp]),
         "effocr_localizer_workspace_bytes": (sz, [vp, i32]),

@@ -154,6 +154,8 @@ struct ConvArgs {
   // concatenation buffer and consumers read one (YOLOv5 C3 / SPPF / neck concats never materialise a copy)
   int in_ld, in_off, out_ld, out_off, res_ld, res_off;
   int silu;             // epilogue x * sigmoid(x) (ultralytics Conv = Conv2d + BN + SiLU); relu and silu are exclusive
+  const void* w16;      // optional: the weights rounded to bf16, [Cout][ceil(KH*KW*Cin / 64) * 64] zero-padded -> bf16-operand MFMAs
+                        // (activations rounded in the stage loader, fp32 accumulation / epilogue); NULL = exact fp32 operands
 };
 int conv2d_nhwc(const ConvArgs& a, hipStream_t s);
 // conv1 7x7/2 pad 3 im2col straight from the NCHW input: rows [B*OH*OW][160] (147 taps (ky,kx,c) + zero pad)

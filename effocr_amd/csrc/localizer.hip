@@ -33,7 +33,7 @@ struct Op {
   int conv;                                              // index into convs
   int level;                                             // OP_DETECT
 };
-struct LConv { std::string w, bn, bias; int cin, cout, cout_pad, k, stride, pad, act; size_t w_off, b_off; int kpad; };
+struct LConv { std::string w, bn, bias; int cin, cout, cout_pad, k, stride, pad, act; size_t w_off, b_off; int kpad; size_t w16_off; };   // w16: the bf16 copy, rows padded to 64 k
 
 }  // namespace
 }  // namespace effocr
@@ -53,6 +53,7 @@ struct effocr_localizer {
   size_t wbytes = 0;
   const char* wdev = nullptr;
   int64_t npred = 0;
+  int bf16 = 0;                                          // 1: bf16-operand MFMAs for every convolution with an activation (Detect's 1x1 heads stay fp32)
 };
 
 namespace effocr {
@@ -164,6 +165,7 @@ void build_yolov5s(effocr_localizer* e) {
     const size_t K = c.kpad ? (size_t)c.kpad : (size_t)c.k * c.k * c.cin;
     c.w_off = off; off = align_up(off + (size_t)c.cout_pad * K * 4, 256);
     c.b_off = off; off = align_up(off + (size_t)c.cout_pad * 4, 256);
+    c.w16_off = off; off = align_up(off + (size_t)c.cout_pad * ((K + 63) / 64 * 64) * 2, 256);
   }
   e->wbytes = off;
 }
@@ -194,6 +196,19 @@ void pack_localizer(effocr_localizer* e, std::vector<char>& blob) {
           for (int ci = 0; ci < c.cin; ++ci)
             wd[(size_t)co * Kp + (ky * c.k + kx) * c.cin + ci] = (float)((double)w[(((size_t)co * c.cin + ci) * c.k + ky) * c.k + kx] * sc);
     }
+    // bf16 copy of the folded weights (round to nearest even), rows zero-padded to a multiple of 64 k
+    const int Kp64 = (Kp + 63) / 64 * 64;
+    uint16_t* w16 = reinterpret_cast<uint16_t*>(blob.data() + c.w16_off);
+    for (int co = 0; co < c.cout_pad; ++co)
+      for (int kk = 0; kk < Kp64; ++kk) {
+        uint32_t u = 0;
+        if (kk < Kp) {
+          const float f = wd[(size_t)co * Kp + kk];
+          memcpy(&u, &f, 4);
+          u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;    // finite values only (folded weights)
+        }
+        w16[(size_t)co * Kp64 + kk] = (uint16_t)u;
+      }
   }
   const auto& an = LP(e, "model.24.anchors");
   const float strides[3] = {8.f, 16.f, 32.f};
@@ -260,6 +275,11 @@ int effocr_localizer_upload(effocr_localizer_t* loc, void* weights_dev, size_t b
   loc->wdev = static_cast<const char*>(weights_dev);
   return EFFOCR_OK;
 }
+int effocr_localizer_set_option(effocr_localizer_t* loc, const char* name, int value) {
+  if (!loc || !name) return fail(EFFOCR_EINVAL, "localizer_set_option: NULL argument");
+  if (std::string(name) == "bf16_operands") { loc->bf16 = value != 0; return EFFOCR_OK; }
+  return fail(EFFOCR_EINVAL, std::string("localizer_set_option: unknown option '") + name + "'");
+}
 int64_t effocr_localizer_num_predictions(const effocr_localizer_t* loc) { return loc ? loc->npred : 0; }
 int effocr_localizer_num_outputs(const effocr_localizer_t* loc) { return loc ? loc->no : 0; }
 size_t effocr_localizer_workspace_bytes(const effocr_localizer_t* loc, int batch) {
@@ -292,6 +312,7 @@ int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int ba
         a.in = P(loc->stem_col); a.w = reinterpret_cast<const float*>(loc->wdev + c.w_off); a.bias = reinterpret_cast<const float*>(loc->wdev + c.b_off);
         a.out = P(op.out.buf); a.B = batch * o.H * o.W; a.H = 1; a.W = 1; a.Cin = c.kpad; a.Cout = c.cout_pad; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
         a.OH = 1; a.OW = 1; a.silu = c.act; a.out_ld = o.C; a.out_off = op.out.off;
+        if (loc->bf16 && c.act) a.w16 = loc->wdev + c.w16_off;
         if ((rc = conv2d_nhwc(a, s))) return rc;
         break;
       }
@@ -305,6 +326,7 @@ int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int ba
         if (op.res.buf >= 0) { a.resid = P(op.res.buf); a.res_ld = loc->bufs[op.res.buf].C; a.res_off = op.res.off; }
         a.B = batch; a.H = i.H; a.W = i.W; a.Cin = c.cin; a.Cout = c.cout_pad; a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
         a.OH = o.H; a.OW = o.W; a.silu = c.act;
+        if (loc->bf16 && c.act) a.w16 = loc->wdev + c.w16_off;
         if ((rc = conv2d_nhwc(a, s))) return rc;
         break;
       }

@@ -37,7 +37,32 @@ __device__ __forceinline__ void conv_stage_load(u32x4 (&r)[4], const ConvArgs& a
   }
 }
 
+// bf16-operand variant of the stage loader: a 128-byte stage row = 64 k values; chunk c (8 values = 16 bytes) is 8 consecutive
+// input channels of ONE tap (Cin % 8 == 0), read as 8 fp32 and rounded to bf16 on the way (k >= K: the zero padding of the
+// weight rows' last stage)
+__device__ __forceinline__ void conv_stage_load16(u32x4 (&r)[4], const ConvArgs& a, const RowCoord (&rc)[4], int ks, int K, int tid) {
+  const int k0 = ks * 64 + (tid & 7) * 8;
+  const int tap = k0 / a.Cin, ci0 = k0 - tap * a.Cin;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int iy = rc[i].iy0 + ky, ix = rc[i].ix0 + kx;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k0 < K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+      const float* p = a.in + (((int64_t)rc[i].b * a.H + iy) * a.W + ix) * a.in_ld + a.in_off + ci0;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+      const u32x2 l2 = pack4<__bf16>(lo[0], lo[1], lo[2], lo[3]), h2 = pack4<__bf16>(hi[0], hi[1], hi[2], hi[3]);
+      v = u32x4{l2[0], l2[1], h2[0], h2[1]};
+    }
+    r[i] = v;
+  }
+}
+
+// E = float: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products).  E = __bf16: operands rounded to bf16 (activations in the
+// stage loader, weights once at upload: a.w16 [Cout][ceil(K/64)*64]) on v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogue.
+template <typename E>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+  constexpr bool B16 = !tile128::is_f32<E>::value;
   __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id(), wn = w >> 1, wm = w & 1;
@@ -46,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int ntn = (a.Cout + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
-  const int nks = K / 32;
+  const int nks = B16 ? (K + 63) / 64 : K / 32;
+  const int Kp = nks * 64;                               // (bf16) padded weight row length
 
   RowCoord rc[4];
 #pragma unroll
@@ -69,23 +95,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   u32x4 rw[4], rx[4];
-  stage_load<float>(rw, a.w, K, n0, a.Cout, 0, tid);
-  conv_stage_load(rx, a, rc, 0, tid);
-  stage_store<float>(rw, smem, tid);
-  stage_store<float>(rx, smem + TILEB, tid);
+  auto load_stage = [&](int ks) __attribute__((always_inline)) {
+    if constexpr (B16) {
+      stage_load<__bf16>(rw, static_cast<const __bf16*>(a.w16), Kp, n0, a.Cout, ks * ROWB, tid);
+      conv_stage_load16(rx, a, rc, ks, K, tid);
+    } else {
+      stage_load<float>(rw, a.w, K, n0, a.Cout, ks * ROWB, tid);
+      conv_stage_load(rx, a, rc, ks, tid);
+    }
+  };
+  load_stage(0);
+  stage_store<E>(rw, smem, tid);
+  stage_store<E>(rx, smem + TILEB, tid);
   __syncthreads();
   for (int ks = 0; ks < nks; ++ks) {
     char* cur = smem + (ks & 1) * STAGEB;
     char* nxt = smem + ((ks & 1) ^ 1) * STAGEB;
     const bool more = (ks + 1) < nks;
+    if (more) load_stage(ks + 1);
+    stage_mma<E>(acc, cur, cur + TILEB, wn, wm, lane);
     if (more) {
-      stage_load<float>(rw, a.w, K, n0, a.Cout, (ks + 1) * ROWB, tid);
-      conv_stage_load(rx, a, rc, ks + 1, tid);
-    }
-    stage_mma<float>(acc, cur, cur + TILEB, wn, wm, lane);
-    if (more) {
-      stage_store<float>(rw, nxt, tid);
-      stage_store<float>(rx, nxt + TILEB, tid);
+      stage_store<E>(rw, nxt, tid);
+      stage_store<E>(rx, nxt + TILEB, tid);
     }
     __syncthreads();
   }
@@ -212,7 +243,8 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
   if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
   if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
   const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+  if (a.w16) hipLaunchKernelGGL(conv_igemm_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv_igemm_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
   return check_launch("conv2d_nhwc");
 }
 

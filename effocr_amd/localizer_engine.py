@@ -138,7 +138,10 @@ def _load_state_dict(model_path):
 class HipLocalizer:
     """Device-resident YOLOv5s: C-ABI handle + weight blob + per-stream workspaces."""
 
-    def __init__(self, state_dict, input_shape=(640, 640), device=None):
+    def __init__(self, state_dict, input_shape=(640, 640), device=None, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
         self.device = _lib.require_gpu(device)
@@ -165,9 +168,13 @@ class HipLocalizer:
         with torch.cuda.device(self.device):
             self._wblob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self._L.effocr_localizer_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_localizer_upload")
+        self.set_option("bf16_operands", 1 if precision == "bf16" else 0)
         self.num_predictions = int(self._L.effocr_localizer_num_predictions(self._h))
         self._ws = {}
         self._lock = threading.Lock()
+
+    def set_option(self, name, value):
+        _lib.check(self._L.effocr_localizer_set_option(self._h, name.encode(), int(value)), "effocr_localizer_set_option")
 
     def __del__(self):
         try:
@@ -246,7 +253,9 @@ class HipLocalizer:
 class EffLocalizer:
 
     def __init__(self, model_path, iou_thresh=0.01, conf_thresh=0.30, vertical=False, num_cores=None, providers=None,
-                 input_shape=(640, 640), model_backend='yolo', device=None):
+                 input_shape=(640, 640), model_backend='yolo', device=None, precision="fp32"):
+        # precision (extension): "fp32" = fp32 MFMA operands (the oracle's arithmetic), "bf16" = bf16-rounded operands for every
+        # convolution with an activation, fp32 accumulation and fp32 Detect heads (2-3x the network throughput)
         # num_cores / providers are ORT knobs (localizer_engine.py:17-23): accepted and ignored.
         if model_backend != 'yolo':
             raise NotImplementedError('Backend {} is not implemented'.format(model_backend))
@@ -254,7 +263,7 @@ class EffLocalizer:
         self._iou_thresh, self._conf_thresh, self._vertical = iou_thresh, conf_thresh, vertical
         self._input_shape = (int(input_shape[0]), int(input_shape[1]))
         self._model_backend = model_backend
-        self._eng_net = HipLocalizer(_load_state_dict(model_path), input_shape=self._input_shape, device=device)
+        self._eng_net = HipLocalizer(_load_state_dict(model_path), input_shape=self._input_shape, device=device, precision=precision)
 
     def __call__(self, imgs):
         return self.run(imgs)

@@ -192,6 +192,10 @@ int64_t effocr_localizer_param_numel(const effocr_localizer_t* loc, int i);
 int effocr_localizer_set_param(effocr_localizer_t* loc, const char* name, const float* host, int64_t numel);
 size_t effocr_localizer_weights_bytes(const effocr_localizer_t* loc);
 int effocr_localizer_upload(effocr_localizer_t* loc, void* weights_dev, size_t bytes);
+/* "bf16_operands" [0]: 1 = every convolution that carries an activation runs with bf16-rounded operands (weights rounded once at
+ * upload, activations in the stage loader) on v_mfma_f32_32x32x16_bf16, fp32 accumulation / bias / SiLU / residual; Detect's 1x1
+ * heads keep fp32 operands.  0 = fp32 operands everywhere (v_mfma_f32_32x32x2_f32: the oracle's arithmetic up to summation order). */
+int effocr_localizer_set_option(effocr_localizer_t* loc, const char* name, int value);
 int64_t effocr_localizer_num_predictions(const effocr_localizer_t* loc);
 int effocr_localizer_num_outputs(const effocr_localizer_t* loc);             /* 5 + num_classes */
 size_t effocr_localizer_workspace_bytes(const effocr_localizer_t* loc, int batch);

@@ -38,6 +38,27 @@ def test_network_matches_oracle(dev, shape, B):
     assert torch.equal(got, eng.forward(x.to(dev)).cpu())                 # deterministic
 
 
+@pytest.mark.parametrize("shape,B", [((640, 640), 1), ((64, 96), 3)])
+def test_network_bf16_operands(dev, shape, B):
+    """precision="bf16": the convolutions with an activation run on bf16-rounded operands (fp32 accumulation, fp32 Detect heads).
+    Against oracle A (fp32): boxes within a pixel, probabilities within 5e-3; deterministic; and it really is another path."""
+    sd = _busy_state_dict(2, seed=1)
+    eng = HipLocalizer(sd, input_shape=shape, device=dev, precision="bf16")
+    x = torch.rand(B, 3, *shape, generator=torch.Generator().manual_seed(3))
+    got = eng.forward(x.to(dev)).cpu()
+    ref = Y.yolov5s_forward(sd, x)
+    err = (got - ref).abs()
+    assert err[..., :4].max().item() < 1.0 and err[..., :4].mean().item() < 0.05
+    assert err[..., 4:].max().item() < 5e-3
+    assert torch.equal(got, eng.forward(x.to(dev)).cpu())
+    exact = HipLocalizer(sd, input_shape=shape, device=dev).forward(x.to(dev)).cpu()
+    assert not torch.equal(got, exact)
+    eng.set_option("bf16_operands", 0)                                    # the switch goes both ways on one handle
+    assert torch.equal(eng.forward(x.to(dev)).cpu(), exact)
+    with pytest.raises(ValueError):
+        HipLocalizer(sd, input_shape=shape, device=dev, precision="fp16")
+
+
 def test_single_class_model_and_validation(dev):
     sd = init_yolov5s_state_dict(1, seed=2)                               # 3 * 6 = 18 head channels -> padded to 20 inside
     eng = HipLocalizer(sd, input_shape=(64, 64), device=dev)
