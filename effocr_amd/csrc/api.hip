@@ -547,13 +547,15 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, blk, emb, s); });
 }
 
-struct ResWs { size_t col, a, b, c, total; };
+constexpr size_t CONV_SPLIT_BYTES = (size_t)16 << 20;  // split-K scratch of conv2d_nhwc: <= 256 partial tiles of 128 x 128 fp32
+struct ResWs { size_t col, a, b, c, split, total; };
 ResWs resnet_ws(const effocr_encoder* e, int B) {
   const size_t oh = (size_t)e->img / 2;
   Alloc al; ResWs w;
   w.col = al.take((size_t)B * oh * oh * CONV1_KPAD * 4);
   const size_t act = (size_t)B * oh * oh * 64 * 4;     // largest activation: conv1 output
   w.a = al.take(act); w.b = al.take(act); w.c = al.take(act);
+  w.split = al.take(CONV_SPLIT_BYTES);
   w.total = al.off;
   return w;
 }
@@ -574,6 +576,8 @@ int resnet_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2,
   a.in = col; a.w = WT(e->convs[0]); a.bias = BS(e->convs[0]); a.resid = nullptr; a.out = bufs[0];
   a.B = B * OH * OH; a.H = 1; a.W = 1; a.Cin = CONV1_KPAD; a.Cout = 64; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
   a.OH = 1; a.OW = 1; a.relu = 1;
+  float* split = reinterpret_cast<float*>(ws + w.split);
+  a.partial = split; a.partial_bytes = CONV_SPLIT_BYTES;
   if ((rc = conv2d_nhwc(a, s))) return rc;
   H = OH; OH = (H + 2 - 3) / 2 + 1;
   if ((rc = maxpool3x3s2_nhwc(bufs[0], bufs[1], B, H, H, 64, OH, OH, s))) return rc;
@@ -590,7 +594,7 @@ int resnet_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2,
       ConvArgs k1{};
       k1.in = bufs[cur]; k1.w = WT(c1); k1.bias = BS(c1); k1.out = bufs[t1];
       k1.B = B; k1.H = H; k1.W = H; k1.Cin = c1.cin; k1.Cout = c1.cout; k1.KH = 3; k1.KW = 3; k1.stride = c1.stride; k1.pad = 1;
-      k1.OH = OHb; k1.OW = OHb; k1.relu = 1;
+      k1.OH = OHb; k1.OW = OHb; k1.relu = 1; k1.partial = split; k1.partial_bytes = CONV_SPLIT_BYTES;
       if ((rc = conv2d_nhwc(k1, s))) return rc;
       const float* idt = bufs[cur];
       if (down) {
@@ -598,7 +602,7 @@ int resnet_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2,
         ConvArgs kd{};
         kd.in = bufs[cur]; kd.w = WT(cd); kd.bias = BS(cd); kd.out = bufs[t2];
         kd.B = B; kd.H = H; kd.W = H; kd.Cin = cd.cin; kd.Cout = cd.cout; kd.KH = 1; kd.KW = 1; kd.stride = cd.stride; kd.pad = 0;
-        kd.OH = OHb; kd.OW = OHb; kd.relu = 0;
+        kd.OH = OHb; kd.OW = OHb; kd.relu = 0; kd.partial = split; kd.partial_bytes = CONV_SPLIT_BYTES;
         if ((rc = conv2d_nhwc(kd, s))) return rc;
         idt = bufs[t2];
       }
@@ -607,7 +611,7 @@ int resnet_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2,
       ConvArgs k2{};
       k2.in = bufs[t1]; k2.w = WT(c2); k2.bias = BS(c2); k2.resid = idt; k2.out = outb;
       k2.B = B; k2.H = OHb; k2.W = OHb; k2.Cin = c2.cin; k2.Cout = c2.cout; k2.KH = 3; k2.KW = 3; k2.stride = 1; k2.pad = 1;
-      k2.OH = OHb; k2.OW = OHb; k2.relu = 1;
+      k2.OH = OHb; k2.OW = OHb; k2.relu = 1; k2.partial = split; k2.partial_bytes = CONV_SPLIT_BYTES;
       if ((rc = conv2d_nhwc(k2, s))) return rc;
       cur = down ? cur : t2;
       H = OHb;

@@ -154,6 +154,9 @@ struct ConvArgs {
   // concatenation buffer and consumers read one (YOLOv5 C3 / SPPF / neck concats never materialise a copy)
   int in_ld, in_off, out_ld, out_off, res_ld, res_off;
   int silu;             // epilogue x * sigmoid(x) (ultralytics Conv = Conv2d + BN + SiLU); relu and silu are exclusive
+  float* partial; size_t partial_bytes;   // optional scratch: a launch of few tiles and a long K is split over K (fp32 partial tiles
+                        // + a fixed-order reduction kernel that applies the epilogue); set by the caller, used by conv2d_nhwc when it pays
+  int ksplit;           // set by conv2d_nhwc
   const void* w16;      // optional: the weights rounded to bf16, [Cout][ceil(KH*KW*Cin / 64) * 64] zero-padded -> bf16-operand MFMAs
                         // (activations rounded in the stage loader, fp32 accumulation / epilogue); NULL = exact fp32 operands
 };

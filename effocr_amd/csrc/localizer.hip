@@ -216,10 +216,12 @@ void pack_localizer(effocr_localizer* e, std::vector<char>& blob) {
     for (int j = 0; j < 6; ++j) e->anchors[l][j] = an[l * 6 + j] * strides[l];      // anchor_grid = anchors * stride (pixels)
 }
 
-struct LWs { std::vector<size_t> off; size_t total; };
+constexpr size_t LOC_SPLIT_BYTES = (size_t)16 << 20;   // split-K scratch of conv2d_nhwc (the deep layers at small batches: few tiles, long K)
+struct LWs { std::vector<size_t> off; size_t split, total; };
 LWs localizer_ws(const effocr_localizer* e, int B) {
   LWs w; size_t off = 0;
   for (const Buf& b : e->bufs) { w.off.push_back(off); off = align_up(off + (size_t)B * b.H * b.W * b.C * 4, 256); }
+  w.split = off; off += LOC_SPLIT_BYTES;
   w.total = off;
   return w;
 }
@@ -313,6 +315,7 @@ int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int ba
         a.out = P(op.out.buf); a.B = batch * o.H * o.W; a.H = 1; a.W = 1; a.Cin = c.kpad; a.Cout = c.cout_pad; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
         a.OH = 1; a.OW = 1; a.silu = c.act; a.out_ld = o.C; a.out_off = op.out.off;
         if (loc->bf16 && c.act) a.w16 = loc->wdev + c.w16_off;
+        a.partial = reinterpret_cast<float*>(ws + w.split); a.partial_bytes = LOC_SPLIT_BYTES;
         if ((rc = conv2d_nhwc(a, s))) return rc;
         break;
       }
@@ -327,6 +330,7 @@ int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int ba
         a.B = batch; a.H = i.H; a.W = i.W; a.Cin = c.cin; a.Cout = c.cout_pad; a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
         a.OH = o.H; a.OW = o.W; a.silu = c.act;
         if (loc->bf16 && c.act) a.w16 = loc->wdev + c.w16_off;
+        a.partial = reinterpret_cast<float*>(ws + w.split); a.partial_bytes = LOC_SPLIT_BYTES;
         if ((rc = conv2d_nhwc(a, s))) return rc;
         break;
       }

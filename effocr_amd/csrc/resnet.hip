@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int ntn = (a.Cout + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
-  const int nks = B16 ? (K + 63) / 64 : K / 32;
-  const int Kp = nks * 64;                               // (bf16) padded weight row length
+  const int nks_all = B16 ? (K + 63) / 64 : K / 32;
+  const int Kp = nks_all * 64;                           // (bf16) padded weight row length
+  // split K: workgroup (x, y) runs the stages [y, y + 1) * nks_all / ksplit and writes its raw accumulators to the scratch
+  const int ksp = a.ksplit > 1 ? a.ksplit : 1, sp = ksp > 1 ? (int)blockIdx.y : 0;
+  const int ks_lo = (int)((int64_t)nks_all * sp / ksp), ks_hi = (int)((int64_t)nks_all * (sp + 1) / ksp);
 
   RowCoord rc[4];
 #pragma unroll
@@ -104,14 +107,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       conv_stage_load(rx, a, rc, ks, tid);
     }
   };
-  load_stage(0);
+  load_stage(ks_lo);
   stage_store<E>(rw, smem, tid);
   stage_store<E>(rx, smem + TILEB, tid);
   __syncthreads();
-  for (int ks = 0; ks < nks; ++ks) {
-    char* cur = smem + (ks & 1) * STAGEB;
-    char* nxt = smem + ((ks & 1) ^ 1) * STAGEB;
-    const bool more = (ks + 1) < nks;
+  for (int ks = ks_lo; ks < ks_hi; ++ks) {
+    char* cur = smem + ((ks - ks_lo) & 1) * STAGEB;
+    char* nxt = smem + (((ks - ks_lo) & 1) ^ 1) * STAGEB;
+    const bool more = (ks + 1) < ks_hi;
     if (more) load_stage(ks + 1);
     stage_mma<E>(acc, cur, cur + TILEB, wn, wm, lane);
     if (more) {
@@ -122,6 +125,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 
   const int half = lane >> 5;
+  if (ksp > 1) {                                         // raw partial sums [split][M][Cout]; conv_reduce_kernel finishes
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+          if (n >= a.Cout) continue;
+          const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(a.partial + ((int64_t)sp * M + m) * a.Cout + n) = v;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + wm * 64 + j * 32 + (lane & 31);
@@ -150,6 +170,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+}
+
+// split-K epilogue: out = act(sum over splits (fixed order) + bias) (+ residual) — one thread per (output pixel, 4 channels)
+__global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int64_t M) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nq = a.Cout / 4;
+  if (id >= M * nq) return;
+  const int64_t m = id / nq;
+  const int n = (int)(id - m * nq) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < a.ksplit; ++sp) v += *reinterpret_cast<const f32x4*>(a.partial + ((int64_t)sp * M + m) * a.Cout + n);
+  v += *reinterpret_cast<const f32x4*>(a.bias + n);
+  if (a.silu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+  }
+  if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + m * a.res_ld + a.res_off + n);
+  if (a.relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(a.out + m * a.out_ld + a.out_off + n) = v;
 }
 
 // conv1 im2col: col[(b,oy,ox)][(ky*7+kx)*3 + c] = x[b][c][2oy-3+ky][2ox-3+kx] (0 outside), cols 147..159 = 0
@@ -243,9 +285,24 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
   if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
   if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
   const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  if (a.w16) hipLaunchKernelGGL(conv_igemm_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv_igemm_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
-  return check_launch("conv2d_nhwc");
+  // few tiles and a long K (the deep layers at small inputs: 4 workgroups looping over 144 stages): split K over up to a round of CUs
+  const int nks = a.w16 ? (a.KH * a.KW * a.Cin + 63) / 64 : a.KH * a.KW * a.Cin / 32;
+  a.ksplit = 1;
+  if (a.partial && grid * 2 <= 256 && nks >= 8) {
+    int64_t sp = 256 / grid;
+    if (sp > nks / 2) sp = nks / 2;
+    if (sp > 32) sp = 32;
+    while (sp > 1 && (size_t)sp * M * a.Cout * 4 > a.partial_bytes) --sp;
+    a.ksplit = (int)sp;
+  }
+  const dim3 g((unsigned)grid, (unsigned)a.ksplit);
+  if (a.w16) hipLaunchKernelGGL(conv_igemm_kernel<__bf16>, g, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv_igemm_kernel<float>, g, dim3(256), 0, s, a);
+  int rc = check_launch("conv2d_nhwc");
+  if (rc || a.ksplit == 1) return rc;
+  const int64_t items = M * (a.Cout / 4);
+  hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a, M);
+  return check_launch("conv_reduce");
 }
 
 int im2col_conv1(const float* x, float* col, int B, int H, int W, int OH, int OW, hipStream_t s) {
