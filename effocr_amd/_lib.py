@@ -10,8 +10,10 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(_HERE, "libeffocr_hip.so")
+# EFFOCR_HIP_LIB: A/B experiments only (tools/): another build of the SAME library; the product default is the in-tree .so
+SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip.so")
 
+ABI_VERSION = 3          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
@@ -72,6 +74,8 @@ def _declare(lib):
         "effocr_gather_rows": (i32, [f32p, i64p, i64, i32, f32p, vp]),
         "effocr_crop_transform": (i32, [vp, i32, i32, i64, vp, i32, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),
                                         c.POINTER(c.c_float), f32p, vp]),
+        "effocr_crop_transform_batch": (i32, [vp, i32, i64, i32, i32, i64, vp, i64, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),
+                                              c.POINTER(c.c_float), f32p, vp]),
         "effocr_localizer_create": (i32, [c.c_char_p, i32, i32, i32, c.POINTER(vp)]),
         "effocr_localizer_destroy": (None, [vp]),
         "effocr_localizer_num_params": (i32, [vp]),
@@ -100,6 +104,8 @@ def _declare(lib):
         "effocr_op_layernorm_blocked": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
     }
     for name, (res, args) in sig.items():
+        if os.environ.get("EFFOCR_HIP_LIB") and not hasattr(lib, name):
+            continue                       # A/B against an older build (tools/ab_bench.sh): symbols added since are simply absent
         fn = getattr(lib, name)            # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
@@ -120,8 +126,8 @@ def lib():
                     "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C effocr_amd/csrc`.")
             handle = ctypes.CDLL(SO_PATH)
             EXPORTS = sorted(_declare(handle).keys())
-            if handle.effocr_abi_version() != 1:
-                raise EffOCRHipError("libeffocr_hip.so ABI version mismatch")
+            if handle.effocr_abi_version() != ABI_VERSION and not os.environ.get("EFFOCR_HIP_LIB"):
+                raise EffOCRHipError(f"libeffocr_hip.so ABI version {handle.effocr_abi_version()} != {ABI_VERSION} expected by this package: rebuild (make -C effocr_amd/csrc)")
             _lib = handle
     return _lib
 

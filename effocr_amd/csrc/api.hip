@@ -28,6 +28,18 @@ int check_launch(const char* what) {
   return EFFOCR_OK;
 }
 
+int device_cus() {
+  static int cache[64] = {0};                            // benign race: every thread computes the same value
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev] = v;
+  }
+  return cache[dev];
+}
+
 namespace {
 
 struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std::vector<float> data; bool set; };
@@ -65,6 +77,8 @@ struct effocr_encoder {
   int mlp_stagger = 3500;           // fused MLP: start spread of the first round of workgroups, clock ticks per step of 32 (0 = off; applies from 4 rounds of CUs on)
   int use_projf = 1;                // 1: attn.proj + residual fused in front of the fused MLP kernel (the new row stays in the accumulators: -0.9 ms and -0.6 GB of HBM traffic per forward vs the separate row-panel launch); 0: A/B switch
   int use_qkvattn = 1;              // fused norm1 + attn.qkv + attention kernel (qkvattn.hip): no qkv tensor in HBM (0: A/B switch)
+  int qa_min_batch = 1;             // fused qkv+attention from this many crops per call on (below: the token-panel LN+qkv kernel + attention kernel)
+  int qa_hsplit = 0;                // qkvattn head split: 0 = launcher's choice (small batches: several workgroups per image), 1 = never, n = at most n
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
@@ -393,7 +407,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool projf = mlpf && !rl && e->use_projf;
   // one image per workgroup at a time: worth it from ~3/4 of a round of CUs on; small batches (the reference's 64-crop calls)
   // keep the token-panel kernels, which spread 64 x 197 tokens over every CU.  use_qkvattn = 2 forces it (tests).
-  const bool qaf = blk && panel && !rl && mlpf && qkv_attn_supported(prec, D, T) && (e->use_qkvattn == 2 || (e->use_qkvattn == 1 && B >= 192));
+  const bool qaf = blk && panel && !rl && mlpf && qkv_attn_supported(prec, D, T) && (e->use_qkvattn == 2 || (e->use_qkvattn == 1 && B >= e->qa_min_batch));
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
@@ -423,7 +437,7 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         xn_ready = false;
         QkvAttnArgs q{};
         q.xn = xn; q.Wb = wb + L.qkvw_bv; q.bias = F(L.qkvb_v); q.out = att;
-        q.B = B; q.T = T; q.D = D; q.rows_alloc = (int64_t)w.rows;
+        q.B = B; q.T = T; q.D = D; q.rows_alloc = (int64_t)w.rows; q.hsplit = e->qa_hsplit;
         q.cls_only = (i + 1 == e->vit.depth && e->cls_only_last && projf) ? 1 : 0;   // the rest of the last block runs on the class-token rows only
         // work executed: the class-token variant projects q and runs the attention for ONE 32-token tile per image (where it exists: D = 384, 193..224 tokens)
         const bool cls_k = q.cls_only && D == 384 && T > 192;
@@ -719,6 +733,8 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
   if (n == "use_qkvattn") { enc->use_qkvattn = value; return EFFOCR_OK; }
+  if (n == "qa_min_batch") { enc->qa_min_batch = value; return EFFOCR_OK; }
+  if (n == "qa_hsplit") { enc->qa_hsplit = value; return EFFOCR_OK; }
   if (n == "use_projf") { enc->use_projf = value; return EFFOCR_OK; }
   if (n == "cls_only_last") { enc->cls_only_last = value; return EFFOCR_OK; }
   if (n == "mlp_stagger") { enc->mlp_stagger = value < 0 ? 0 : value; return EFFOCR_OK; }
@@ -839,7 +855,18 @@ int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64
   if (n > 0 && (!image_dev || !boxes_dev || !out_dev || !mean || !stdv || !fill)) return fail(EFFOCR_EINVAL, "crop_transform: NULL pointer");
   for (int c = 0; c < 3 && n > 0; ++c)
     if (!(stdv[c] != 0.f)) return fail(EFFOCR_EINVAL, "crop_transform: std must be non-zero");
-  return crop_transform(image_dev, height, width, row_stride, boxes_dev, n, size, antialias, mean, stdv, fill, out_dev, S(stream));
+  return crop_transform(image_dev, 1, 0, height, width, row_stride, boxes_dev, 4, n, size, antialias, mean, stdv, fill, out_dev, S(stream));
+}
+
+int effocr_crop_transform_batch(const uint8_t* images_dev, int n_images, int64_t image_stride, int height, int width, int64_t row_stride,
+                                const int32_t* boxes_dev, int64_t n, int size, int antialias, const float* mean, const float* stdv,
+                                const float* fill, float* out_dev, void* stream) {
+  if (n < 0 || n_images <= 0 || height <= 0 || width <= 0 || row_stride < (int64_t)3 * width || image_stride < row_stride * height)
+    return fail(EFFOCR_EINVAL, "crop_transform_batch: bad image geometry");
+  if (n > 0 && (!images_dev || !boxes_dev || !out_dev || !mean || !stdv || !fill)) return fail(EFFOCR_EINVAL, "crop_transform_batch: NULL pointer");
+  for (int c = 0; c < 3 && n > 0; ++c)
+    if (!(stdv[c] != 0.f)) return fail(EFFOCR_EINVAL, "crop_transform_batch: std must be non-zero");
+  return crop_transform(images_dev, n_images, image_stride, height, width, row_stride, boxes_dev, 5, n, size, antialias, mean, stdv, fill, out_dev, S(stream));
 }
 
 int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64_t n_keep, int d, float* dst_dev, void* stream) {

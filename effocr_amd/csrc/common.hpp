@@ -174,6 +174,9 @@ template <typename E> __device__ __forceinline__ u32x2 pack4(float a, float b, f
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 int check_launch(const char* what);
+// CU count of the CURRENT device (hipGetDevice), cached per device id: launch geometry follows the device a call runs on,
+// not the first device the process ever used (a process may drive several GPUs)
+int device_cus();
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
 #pragma unroll
       for (int i = 0; i < PP; ++i) issue_piece(s, i);
     }
+  // Steady state: the same piece as ONE inline-asm statement.  hipcc models __builtin_amdgcn_global_load_lds as an access to both
+  // address spaces ("pending flat") and makes its NEXT LDS wait s_waitcnt lgkmcnt(0): a DMA piece placed between two MFMAs
+  // drained the fragment reads issued around it (mlp_kernel.hpp: 70 of 73 LDS waits of the loop were full drains).  Completion
+  // is counted by hand either way (vmcnt at the stage barrier).  M0 = the piece's LDS address (saved / restored: the register is
+  // the compiler's), s_nop = the M0-write -> LDS-DMA wait state.
+  const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue_piece_asm = [&](int s, int i) {
+    const char* p = src[i] + (size_t)s * 2048;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_lds + (unsigned)((s & (G3RING - 1)) * STAGE) + (unsigned)((wv * PP + i) * 1024)));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+  };
 
   f32x16 acc[NT][JT];                                                  // [feature tile][token tile]
 #pragma unroll
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
     mma_step(fb, [&](auto N_) {
       constexpr int n = decltype(N_)::value;
 #if !(G3X & 4)
-      if constexpr (more && n < PP) issue_piece(s + 4, n);
+      if constexpr (more && n < PP) issue_piece_asm(s + 4, n);
 #endif
       if constexpr (next && n < NF) load_one(fa, stn, 0, N_);
     });
@@ -242,15 +259,6 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   }
 }
 
-int num_cus3() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n = v;
-  }
-  return n;
-}
 
 template <typename E, int NT, int JT>
 int launch3_tile(int epi, const GemmArgs& g, hipStream_t s) {
@@ -269,7 +277,7 @@ int launch3_tile(int epi, const GemmArgs& g, hipStream_t s) {
 // fraction of the time each): rows [0, main_rows) with the big tile, the rest with the small one.
 template <typename E, int NT>
 int launch3(int epi, const GemmArgs& g, hipStream_t s) {
-  const int ntn = g.N / (NT * 64), mtiles = (g.M + 255) / 256, slots = num_cus3();
+  const int ntn = g.N / (NT * 64), mtiles = (g.M + 255) / 256, slots = device_cus();
   const int full_rounds = (mtiles * ntn) / slots;
   int main_mt = g.no_tail_split ? mtiles : (full_rounds * slots) / ntn;   // whole token tiles inside the full rounds
   int tail_wgs = (mtiles - main_mt) * ntn;

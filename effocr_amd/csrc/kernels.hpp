@@ -69,6 +69,8 @@ struct QkvAttnArgs {
   int64_t rows_alloc;               // rows addressable in xn / out (multiple of 32, >= B * T)
   int cls_only;                     // 1: only the attention rows of token tile 0 of every image are needed (last block); a hint — shapes
                                     // without the specialised kernel compute every row
+  int hsplit;                       // workgroups per image (each runs heads / hsplit heads): 0 = chosen by the launcher (small batches
+                                    // spread over the CUs), 1 = never split, n = at most n
 };
 bool qkv_attn_supported(int prec, int D, int T);
 int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s);
@@ -139,8 +141,8 @@ int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s)
 int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);
 
 // transform.hip — create_paired_transform over a box list (crop, pad to square, /255, bilinear resize, normalise)
-int crop_transform(const uint8_t* img, int H, int W, int64_t stride, const int* boxes, int n, int S, int antialias,
-                   const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s);
+int crop_transform(const uint8_t* img, int n_img, int64_t img_stride, int H, int W, int64_t stride, const int* boxes, int box_ld, int64_t n, int S,
+                   int antialias, const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s);
 
 // resnet.hip
 struct ConvArgs {

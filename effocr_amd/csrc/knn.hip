@@ -70,12 +70,15 @@ struct KnnArgs {
   int* cand; int* cnt; int cap;     // candidate ids [B][cap], counters [B]
   const int* run_flag;              // non-NULL: the launch is a no-op unless *run_flag != 0 (fallback after an overflow)
   int ring;                         // knn_stream_kernel: LDS-DMA stages per wave
+  // k > 32: the result is produced 32 columns at a time.  Pass p writes columns [ocol, ocol + k) of the [B][ldo] outputs and
+  // (AFTER) only ranks rows that come strictly AFTER the previous pass's last result (after_col) in the (score desc, id asc) order.
+  int ldo, ocol, after_col;
 };
 
 // E = float: exact scores (the product's definition).  E = __bf16: screening scores s^ from bf16-rounded operands
 // (fp32 accumulation).  COLLECT: instead of keeping a top-k, append every row with s^ >= tau[q] to the query's
 // candidate list — same MFMA path as the top-k pass, so s^ is bit-identical between the two passes.
-template <int KMAX, typename E, bool COLLECT>
+template <int KMAX, typename E, bool COLLECT, bool AFTER = false>
 __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
   if (a.run_flag != nullptr && *a.run_flag == 0) return;
   constexpr int MERGEB = 128 * 4 * KMAX * 8;
@@ -160,12 +163,22 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
       for (int j = 0; j < 2; ++j) {
         uint32_t hits = 0;
         const float thr = ls[j][KMAX - 1];
+        float aS = 0.f; int aI = 0;
+        if constexpr (AFTER) {                               // last result of the previous pass for this lane's query
+          const int qg = q0 + wm * 64 + j * 32 + r31;
+          const int qc = qg < a.B ? qg : a.B - 1;
+          aS = a.dist[(int64_t)qc * a.ldo + a.after_col];
+          const int64_t ai = a.idx[(int64_t)qc * a.ldo + a.after_col];
+          aI = ai < 0 ? ID_NONE : (int)ai;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
-            hits |= (n < a.N && acc[i][j][r] > thr) ? (1u << (i * 16 + r)) : 0u;
+            bool ok = n < a.N && acc[i][j][r] > thr;
+            if constexpr (AFTER) ok = ok && before(aS, aI, acc[i][j][r], n);
+            hits |= ok ? (1u << (i * 16 + r)) : 0u;
           }
         if (__any(hits != 0)) {
           // wave-uniform walk over the 32 candidate slots (uniform index -> register-relative
@@ -230,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
           p0 += (bsrc == 0); p1 += (bsrc == 1); p2 += (bsrc == 2); p3 += (bsrc == 3);
         }
         if (a.nchunks == 1) {
-          a.dist[(int64_t)qg * a.k + o] = bs;
-          a.idx[(int64_t)qg * a.k + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
+          a.dist[(int64_t)qg * a.ldo + a.ocol + o] = bs;
+          a.idx[(int64_t)qg * a.ldo + a.ocol + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
         } else {
           const int64_t off = ((int64_t)chunk * a.B + qg) * KMAX + o;
           a.pdist[off] = bs;
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
 template <int KMAX>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
                                                         int B, int nchunks, int k, float* __restrict__ dist,
-                                                        int64_t* __restrict__ idx, const int* __restrict__ run_flag) {
+                                                        int64_t* __restrict__ idx, const int* __restrict__ run_flag, int ldo, int ocol) {
   if (run_flag != nullptr && *run_flag == 0) return;
   constexpr int LPL = MAX_CHUNKS / 64;
   const int lane = threadIdx.x & 63;
@@ -281,8 +294,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
       for (int c = 0; c < LPL; ++c) ptr[c] += (c == bc);
     }
     if (lane == 0) {
-      dist[(int64_t)qg * k + o] = ws;
-      idx[(int64_t)qg * k + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
+      dist[(int64_t)qg * ldo + ocol + o] = ws;
+      idx[(int64_t)qg * ldo + ocol + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
     }
   }
 }
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   dst[id] = src[rows[i] * D + d];
 }
 
-int pick_kmax(int k) { return k <= 1 ? 1 : (k <= 16 ? 16 : (k <= 32 ? 32 : 0)); }
+int pick_kmax(int k) { return k <= 1 ? 1 : (k <= 16 ? 16 : 32); }   // k > 32: 32 columns per pass (knn_ip_topk)
 
 struct Plan { int nqt, ntiles, tpc, nchunks, kmax; };
 
@@ -334,11 +347,13 @@ Plan make_plan(int64_t B, int64_t N, int k) {
 
 template <int KMAX, typename E>
 int launch_knn(const KnnArgs& a, hipStream_t s) {
+  if (a.after_col >= 0) hipLaunchKernelGGL((knn_partial_kernel<KMAX, E, false, true>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a);
+  else
   hipLaunchKernelGGL((knn_partial_kernel<KMAX, E, false>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a);
   int rc = check_launch("knn_partial");
   if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
   hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
-                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag);
+                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol);
   return check_launch("knn_merge");
 }
 template <typename E>
@@ -450,8 +465,12 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
 //     2 x D/4 MFMAs per block = 16 B/clk/CU of index at the MFMA rate, i.e. the matrix pipe is ~2/3 busy at the HBM rate;
 //   * per-lane sorted top-k lists as above; the 16 partial lists of a query (8 waves x 2 half-waves) merge through LDS,
 //     chunks through knn_merge_kernel.
+// NQT = 2 (33..64 queries; the ONNX driver's only call size is 64, infer_effocr_onnx_multi.py:157): two query column tiles share every
+// index fragment (one LDS read, two MFMA pairs), twice the MFMA work per byte — 64 queries against 1M x 384 is MFMA-bound at 0.31 ms
+// instead of 1.4 ms on the 128-query tile kernel.  The query images of both tiles (D * 256 bytes) leave room for ONE transpose
+// stage per wave instead of two (LDS operations of a wave execute in order, so re-writing the stage behind its reads is safe).
 constexpr int KS_THREADS = 512;
-template <int KMAX>
+template <int KMAX, int NQT>
 __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -461,19 +480,22 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   const int D = a.D, nm = D / 4;
   const float* Q = static_cast<const float*>(a.q);
   const float* X = static_cast<const float*>(a.xb);
-  f32x2* sQ = reinterpret_cast<f32x2*>(smem);                       // [nm][2][32]
-  for (int id = tid; id < nm * 64; id += KS_THREADS) {
-    const int q = id & 31, h = (id >> 5) & 1, m = id >> 6;
+  f32x2* sQ = reinterpret_cast<f32x2*>(smem);                       // [NQT][nm][2][32]
+  for (int id = tid; id < NQT * nm * 64; id += KS_THREADS) {
+    const int qt = id / (nm * 64), rem = id - qt * nm * 64;
+    const int q = qt * 32 + (rem & 31), h = (rem >> 5) & 1, m = rem >> 6;
     f32x2 v = {0.f, 0.f};
     if (q < a.B) { v[0] = Q[(int64_t)q * D + 4 * m + h]; v[1] = Q[(int64_t)q * D + 4 * m + 2 + h]; }
     sQ[id] = v;
   }
   __syncthreads();
 
-  float ls[KMAX];
-  int li[KMAX];
+  float ls[NQT][KMAX];
+  int li[NQT][KMAX];
 #pragma unroll
-  for (int t = 0; t < KMAX; ++t) { ls[t] = -FLT_MAX; li[t] = ID_NONE; }
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { ls[qt][t] = -FLT_MAX; li[qt][t] = ID_NONE; }
 
   const int row_lo = chunk * a.tiles_per_chunk * 128;
   int row_hi = row_lo + a.tiles_per_chunk * 128;
@@ -484,7 +506,8 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   constexpr int STG = 4096;                                         // one stage: 32 rows x 128 bytes (32 k)
   constexpr int P = 4;                                              // stages in flight per wave, in REGISTERS (16 KB per wave, 128 KB per CU)
   const int nsl = D / 32;                                           // stages (k slabs) per row block; D % 128 == 0 -> P divides it
-  char* stg = smem + (size_t)D * 128 + (size_t)w * 2 * STG;        // the wave's private transpose buffer (two stages)
+  constexpr int NBUF = NQT == 1 ? 2 : 1;                            // transpose stages per wave
+  char* stg = smem + (size_t)D * 128 * NQT + (size_t)w * NBUF * STG;   // the wave's private transpose buffer
   // stream of this wave: stage t = (block t / nsl, slab t % nsl).  A stage is fetched by 4 fully coalesced 16-byte loads per
   // lane (lane -> row 8i + lane / 8, chunk lane % 8: 8 rows x 128 contiguous bytes per instruction), parked in registers
   // while P - 1 older stages are consumed, then transposed through the wave's LDS buffer into the row-per-lane MFMA layout.
@@ -508,15 +531,17 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
     if (fb < nblk) fetch(rg[u], fb, fs);
     if (++fs == nsl) { fs = 0; ++fb; }
   }
-  f32x16 acc;
+  f32x16 acc[NQT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
   int sl = 0, r0 = row_lo + w * 32;
   const int wr = lane >> 3, wc = lane & 7;
   for (int t0 = 0; t0 < nst; t0 += P) {
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-      char* buf = stg + (u & 1) * STG;
+      char* buf = stg + (u % NBUF) * STG;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rl = 8 * i + wr;
@@ -529,37 +554,43 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
       for (int m = 0; m < 8; ++m) xv[m] = *reinterpret_cast<const f32x4*>(buf + r31 * 128 + ((m ^ (r31 & 7)) << 4));
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        const f32x2 qv = qp[((sl + u) * 8 + m) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][1] : xv[m][0], qv[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][3] : xv[m][2], qv[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+          const f32x2 qv = qp[(qt * nm + (sl + u) * 8 + m) * 64];
+          acc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][1] : xv[m][0], qv[0], acc[qt], 0, 0, 0);
+          acc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][3] : xv[m][2], qv[1], acc[qt], 0, 0, 0);
+        }
       }
     }
     sl += P;
     if (sl == nsl) {
       // C layout: col = query (r31), rows = index rows (r & 3) + 8 (r >> 2) + 4 half, ascending with r
-      uint32_t hits = 0;
-      const float thr = ls[KMAX - 1];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        hits |= (n < a.N && acc[r] > thr) ? (1u << r) : 0u;
-      }
-      if (__any(hits != 0)) {
-        float cand[16];
+      for (int qt = 0; qt < NQT; ++qt) {
+        uint32_t hits = 0;
+        const float thr = ls[qt][KMAX - 1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cand[r] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+          const int n = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          hits |= (n < a.N && acc[qt][r] > thr) ? (1u << r) : 0u;
+        }
+        if (__any(hits != 0)) {
+          float cand[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cand[r] = acc[qt][r];
 #pragma unroll 1
-        for (int bsel = 0; bsel < 16; ++bsel) {
-          const bool mine = (hits >> bsel) & 1u;
-          if (__any(mine)) {
-            const int n = r0 + (bsel & 3) + 8 * (bsel >> 2) + 4 * half;
-            const float sc = cand[bsel];
-            if (mine) topk_insert<KMAX>(ls, li, sc, n);
+          for (int bsel = 0; bsel < 16; ++bsel) {
+            const bool mine = (hits >> bsel) & 1u;
+            if (__any(mine)) {
+              const int n = r0 + (bsel & 3) + 8 * (bsel >> 2) + 4 * half;
+              const float sc = cand[bsel];
+              if (mine) topk_insert<KMAX>(ls[qt], li[qt], sc, n);
+            }
           }
         }
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
+      }
       sl = 0; r0 += WSTEP;
     }
   }
@@ -567,18 +598,20 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   // ---- merge the 16 partial lists of every query through LDS (the query image is dead)
   __syncthreads();
   constexpr int NSRC = (KS_THREADS / 64) * 2;
-  float* mS = reinterpret_cast<float*>(smem);                       // [32][NSRC][KMAX]
-  int* mI = reinterpret_cast<int*>(smem + 32 * NSRC * KMAX * 4);
+  float* mS = reinterpret_cast<float*>(smem);                       // [32 * NQT][NSRC][KMAX]
+  int* mI = reinterpret_cast<int*>(smem + 32 * NQT * NSRC * KMAX * 4);
   {
     const int src = w * 2 + half;
 #pragma unroll
-    for (int t = 0; t < KMAX; ++t) {
-      mS[(r31 * NSRC + src) * KMAX + t] = ls[t];
-      mI[(r31 * NSRC + src) * KMAX + t] = li[t];
-    }
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        mS[((qt * 32 + r31) * NSRC + src) * KMAX + t] = ls[qt][t];
+        mI[((qt * 32 + r31) * NSRC + src) * KMAX + t] = li[qt][t];
+      }
   }
   __syncthreads();
-  if (tid < 32 && tid < a.B) {
+  if (tid < 32 * NQT && tid < a.B) {
     const float* s0 = mS + tid * NSRC * KMAX;
     const int* i0 = mI + tid * NSRC * KMAX;
     int ptr[NSRC];
@@ -599,8 +632,8 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
         for (int c = 0; c < NSRC; ++c) ptr[c] += (c == bsrc);
       }
       if (a.nchunks == 1) {
-        a.dist[(int64_t)tid * a.k + o] = bs;
-        a.idx[(int64_t)tid * a.k + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
+        a.dist[(int64_t)tid * a.ldo + a.ocol + o] = bs;
+        a.idx[(int64_t)tid * a.ldo + a.ocol + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
       } else {
         const int64_t off = ((int64_t)chunk * a.B + tid) * KMAX + o;
         a.pdist[off] = bs;
@@ -610,33 +643,41 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   }
 }
 
-template <int KMAX>
+template <int KMAX, int NQT>
 int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   KnnArgs a = a_in;
-  const size_t q_bytes = (size_t)a.D * 128, m_bytes = (size_t)32 * (KS_THREADS / 64) * 2 * KMAX * 8;
-  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * 2 * 4096;
-  if (s_bytes > 160 * 1024) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim too large for the LDS image");
+  constexpr int NBUF = NQT == 1 ? 2 : 1;
+  const size_t q_bytes = (size_t)a.D * 128 * NQT, m_bytes = (size_t)32 * NQT * (KS_THREADS / 64) * 2 * KMAX * 8;
+  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * NBUF * 4096;
+  if (s_bytes > 160 * 1024 || m_bytes > 160 * 1024) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim / k too large for the LDS image");
   const size_t lds = s_bytes > m_bytes ? s_bytes : m_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((knn_stream_kernel<KMAX>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
+  // per launch: the attribute belongs to the (function, device) pair and a process may search on several GPUs; the call is cheap
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX, NQT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return fail(EFFOCR_EHIP, "knn(stream): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  hipLaunchKernelGGL((knn_stream_kernel<KMAX, NQT>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
   int rc = check_launch("knn_stream");
   if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
   hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
-                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag);
+                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol);
   return check_launch("knn_merge");
 }
-int launch_knn_stream_k(int kmax, const KnnArgs& a, hipStream_t s) {
+int launch_knn_stream_k(int kmax, int nqt, const KnnArgs& a, hipStream_t s) {
+  if (nqt == 2) {
+    switch (kmax) {
+      case 1: return launch_knn_stream<1, 2>(a, s);
+      case 16: return launch_knn_stream<16, 2>(a, s);
+    }
+    return fail(EFFOCR_EINVAL, "knn: internal");
+  }
   switch (kmax) {
-    case 1: return launch_knn_stream<1>(a, s);
-    case 16: return launch_knn_stream<16>(a, s);
-    case 32: return launch_knn_stream<32>(a, s);
+    case 1: return launch_knn_stream<1, 1>(a, s);
+    case 16: return launch_knn_stream<16, 1>(a, s);
+    case 32: return launch_knn_stream<32, 1>(a, s);
   }
   return fail(EFFOCR_EINVAL, "knn: internal");
 }
+// how many queries one streaming launch takes at (D, kmax): 64 where both query images and the merge lists fit the LDS, else 32
+int stream_queries(int D, int kmax) { return (D <= 384 && kmax <= 16) ? 64 : 32; }
 
 }  // namespace
 
@@ -655,17 +696,40 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
   if (D % 32 != 0) return fail(EFFOCR_EUNSUPPORTED, "knn: embedding dim must be a multiple of 32");
   if (N >= (int64_t)INT_MAX - 256 || B >= (int64_t)INT_MAX - 256) return fail(EFFOCR_EUNSUPPORTED, "knn: index or batch too large");
   const Plan p = make_plan(B, N, k);
-  if (p.kmax == 0) return fail(EFFOCR_EUNSUPPORTED, "knn: k > 32 is not supported by the fused top-k kernel");
   if (ws_bytes < knn_workspace_bytes(B, N, D, k)) return fail(EFFOCR_EWORKSPACE, "knn: workspace too small");
   KnnArgs a{};
-  a.q = q; a.B = (int)B; a.xb = (N > 0) ? xb : q; a.N = (int)N; a.D = D; a.k = k;
+  a.q = q; a.B = (int)B; a.xb = (N > 0) ? xb : q; a.N = (int)N; a.D = D; a.k = k; a.ldo = k; a.ocol = 0; a.after_col = -1;
   a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
   a.pdist = static_cast<float*>(ws);
   a.pidx = reinterpret_cast<int*>(static_cast<char*>(ws) + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
   a.dist = dist; a.idx = idx;
   if (N == 0) { a.tiles_per_chunk = 0; a.nchunks = 1; }
-  // up to 32 queries against a large index: the streaming kernel (HBM-bound); same chunking, same merge, same bits
-  if (B <= 32 && N >= 4096 && D % 128 == 0 && D <= 768 && !g_knn_force_tile) return launch_knn_stream_k(p.kmax, a, s);
+  if (k > 32) {
+    // faiss / PML accept any k (infer_effocr.py:317, viz_effocr_recognizer.py:78).  The register-resident lists hold 32 entries, so the
+    // result is produced 32 columns per pass: pass p ranks only the rows that come strictly after pass p-1's last result in the
+    // (score desc, id asc) order — every pass is the same exact scan, the concatenation is the exact sorted top-k.
+    for (int done = 0; done < k; done += 32) {
+      KnnArgs b = a;
+      b.k = k - done < 32 ? k - done : 32;
+      b.ocol = done; b.after_col = done > 0 ? done - 1 : -1;
+      const int rc = launch_knn_k<float>(pick_kmax(b.k), b, s);
+      if (rc) return rc;
+    }
+    return EFFOCR_OK;
+  }
+  // up to 128 queries against a large index: the streaming kernel (HBM / fp32-MFMA bound) in slices of 32 or 64 queries; same
+  // chunking, same merge, same bits.  (Above that the 128-query tile kernel amortises the index traffic better.)
+  const int sq = stream_queries(D, p.kmax);
+  if (B <= 2 * sq && N >= 4096 && D % 128 == 0 && D <= 768 && !g_knn_force_tile) {
+    for (int64_t q0 = 0; q0 < B; q0 += sq) {
+      KnnArgs b = a;
+      b.B = (int)(B - q0 < sq ? B - q0 : sq);
+      b.q = q + q0 * D; b.dist = dist + q0 * k; b.idx = idx + q0 * k;
+      const int rc = launch_knn_stream_k(p.kmax, b.B > 32 ? 2 : 1, b, s);   // (the partial lists are re-used: launches are stream-ordered)
+      if (rc) return rc;
+    }
+    return EFFOCR_OK;
+  }
   return launch_knn_k<float>(p.kmax, a, s);
 }
 
@@ -711,7 +775,7 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   if (N < k) return fail(EFFOCR_EUNSUPPORTED, "knn(screened): needs at least k index rows (use the exact entry point)");
   if (N >= (int64_t)INT_MAX - 256 || B >= (int64_t)INT_MAX - 256) return fail(EFFOCR_EUNSUPPORTED, "knn: index or batch too large");
   const Plan p = make_plan(B, N, k);
-  if (p.kmax == 0) return fail(EFFOCR_EUNSUPPORTED, "knn: k > 32 is not supported by the fused top-k kernel");
+  if (k > 32) return fail(EFFOCR_EUNSUPPORTED, "knn(screened): k > 32 runs on the exact multi-pass search (knn_ip_topk)");
   const ScreenWs w = screen_ws(B, N, D, k);
   if (ws_bytes < w.total) return fail(EFFOCR_EWORKSPACE, "knn(screened): workspace too small");
   char* W = static_cast<char*>(ws);
@@ -726,7 +790,7 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   int rc = check_launch("knn_prep");
   if (rc) return rc;
   KnnArgs a{};
-  a.B = (int)B; a.N = (int)N; a.D = D; a.k = k;
+  a.B = (int)B; a.N = (int)N; a.D = D; a.k = k; a.ldo = k; a.ocol = 0; a.after_col = -1;
   a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
   a.pdist = reinterpret_cast<float*>(W + w.part);
   a.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
@@ -749,7 +813,7 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   if ((rc = check_launch("knn_rerank"))) return rc;
   // fallback, gated on the device: the exact search over everything if any query overflowed its candidate list
   KnnArgs e{};
-  e.q = q; e.B = (int)B; e.xb = xb; e.N = (int)N; e.D = D; e.k = k;
+  e.q = q; e.B = (int)B; e.xb = xb; e.N = (int)N; e.D = D; e.k = k; e.ldo = k; e.ocol = 0; e.after_col = -1;
   e.nqt = p.nqt; e.tiles_per_chunk = p.tpc; e.nchunks = p.nchunks;
   e.pdist = a.pdist; e.pidx = a.pidx; e.dist = dist; e.idx = idx; e.run_flag = flag;
   return launch_knn_k<float>(p.kmax, e, s);

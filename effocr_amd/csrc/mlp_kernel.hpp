@@ -33,6 +33,9 @@
 #ifndef EFFOCR_EXP
 #define EFFOCR_EXP 0
 #endif
+#ifndef MLP_BARRIER_DRAIN
+#define MLP_BARRIER_DRAIN 0
+#endif
 // timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
 // the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 (unused),
 // 256 no stores of the second output, 512 second output skipped altogether, 4096 weight stream from 128 KB only (L2-hot),
@@ -208,15 +211,40 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     const int g = r >> 1, kh = r & 1;
     return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * (c0 + c) + 8 * kh) * 512;
   };
-  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS
-#if (MLX & 4096)
-    const char* src = stage_src(s & 7) + lane * 16;      // experiment: the whole stream re-reads the first 8 stages (128 KB: always L2-hot)
-#else
-    const char* src = stage_src(s) + lane * 16;
-#endif
-    char* dst = sW + (s & (R - 1)) * MLP_STAGE + w * 4096;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  // The four 1 KB pieces of a wave's share of a stage use ONE source address and ONE LDS base (M0): the piece index is the
+  // instruction's immediate offset, which the hardware adds on both sides (7 address / M0 instructions per piece before: a
+  // quarter of the loop's non-MFMA issue slots).
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS; i = 0..3 (constant after inlining)
+    const __attribute__((address_space(1))) void* src = (const __attribute__((address_space(1))) void*)(stage_src(s) + lane16);
+    __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(sW + (s & (R - 1)) * MLP_STAGE + w * 4096);
+    switch (i) {
+      case 0: __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0); break;
+      case 1: __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0); break;
+      case 2: __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0); break;
+      default: __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0); break;
+    }
+  };
+  // Steady state: the wave's four pieces of a stage in ONE inline-asm statement.  hipcc models __builtin_amdgcn_global_load_lds as an
+  // access to BOTH address spaces ("pending flat"): after every such instruction its next LDS wait is s_waitcnt lgkmcnt(0) instead
+  // of a counted one, i.e. the W-fragment read issued a moment earlier is drained on the spot — 58 full LDS drains per 192 MFMAs
+  // in this loop (70 of its 73 lgkmcnt waits were (0)), each exposing ~100 cycles of LDS latency at one wave per SIMD.  Hidden in
+  // asm the DMA costs the compiler nothing; its completion is counted by hand anyway (stage_mid: vmcnt).  M0 = LDS base of the
+  // pieces (saved / restored: the register is the compiler's), the s_nop is the M0-write -> LDS-DMA wait state.
+  const unsigned sW_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sW;
+  auto issue_stage_asm = [&](int s) __attribute__((always_inline)) {                     // caller guarantees s < NS
+    const char* src = stage_src(s) + lane16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)((s & (R - 1)) * MLP_STAGE) + (unsigned)w * 4096u));   // (wave-uniform)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
 #pragma unroll
   for (int s0 = 0; s0 < R - 1; ++s0)
@@ -328,7 +356,9 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   auto stage_mid = [&](auto STEADY) __attribute__((always_inline)) {
     if constexpr (decltype(STEADY)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if MLP_BARRIER_DRAIN
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind this barrier is stage s-1's, whose fragment
+#endif                                                  // reads were all consumed by MFMAs before stage s began; the reads in flight here are stage s's
 #if !(MLX & 16)
     __builtin_amdgcn_s_barrier();
 #endif
@@ -344,8 +374,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // pre-activations (bias added, rounded to the operand type: "parked"), then GELU'd IN PLACE, 4 values at a time.
   // (Two alternating sets, with the GELU spread over both phases, do not fit next to the 96 VGPRs of xn: spills.)
   struct HSet { u32x4 u[8]; };
-  // unit q (0..7) = 8 values = four independent v_pk_fma_f32 Horner chains: a packed FMA needs a wait state before a dependent
-  // packed FMA, and with two chains (4 values at a time) every one of the 224 was followed by an s_nop
+  // unit q (0..7) = 8 values = four independent v_pk_fma_f32 Horner chains kept in lock step (gelu_fold_n, common.hpp)
   auto gelu_unit = [&](HSet& hs, auto Q) __attribute__((always_inline)) {     // Q: compile-time -> static register indices
     typedef __attribute__((__vector_size__(8 * sizeof(E)))) E E8;
     constexpr int u = decltype(Q)::value;
@@ -353,9 +382,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)pv[e];
-#if !(MLX & 4)
     gelu_fold_n<E, 8>(v);
-#endif
     const u32x2 o0 = pack4<E>(v[0], v[1], v[2], v[3]);
     const u32x2 o1 = pack4<E>(v[4], v[5], v[6], v[7]);
     hs.u[u] = u32x4{o0[0], o0[1], o1[0], o1[1]};
@@ -405,7 +432,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
         else if constexpr (next) wf.w[i] = *reinterpret_cast<const V8*>(stn + wo + (i * 8) * 512);
-        if constexpr (more && c4 >= 2 && i < 2) issue_piece(s + R - 1, (c4 - 2) * 2 + i);
+        if constexpr (more && c4 == 2 && i == 0) issue_stage_asm(s + R - 1);   // right behind the barrier: slot of stage s-1 is free
       });
     });
     ++s;
@@ -427,11 +454,15 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
 #endif
         if constexpr (nu > 0) {
-          constexpr int n = ks * 16 + c4 * 4 + i;        // MFMA index within the phase; half-unit k goes after MFMA ceil(k*NMM/nu)
-          constexpr int k = (n * nu) / NMM;
-          if constexpr ((k * NMM + nu - 1) / nu == n && k < nu) {
+          static_assert(NMM % nu == 0, "mlp: GELU units must divide the phase's MFMAs");
+          constexpr int n = ks * 16 + c4 * 4 + i;        // MFMA index within the phase: unit n / SPU, slice n % SPU of it
+          constexpr int SPU = NMM / nu;
+          // The whole unit behind ONE MFMA.  (Spread over the unit's 12 MFMA gaps in steps of 4-8 VALU instructions — same
+          // arithmetic, no bursts — the launch was 1-2 % SLOWER, same-box A/B: the compiler scalarises most of the packed FMAs
+          // once the chains are cut by scheduling barriers, and pinning them as register pairs costs an s_nop per asm boundary.)
+          if constexpr (n % SPU == 0) {
             __builtin_amdgcn_sched_barrier(0);
-            gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
+            gelu_unit(*gs, std::integral_constant<int, u0 + n / SPU>{});
           }
         }
       }, std::false_type{});
@@ -638,16 +669,6 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* 
   *xp = v;
 }
 
-int num_cus_mlp() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n = v;
-  }
-  return n;
-}
-
 template <typename E, bool PROJ>
 int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   MlpArgs a = a_in;
@@ -660,7 +681,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   if (!(a.D == 384 && a.H == 1536)) return fail(EFFOCR_EUNSUPPORTED, "mlp_fused: (D, H) must be (384, 1536) or (128, 512)");
   // One workgroup per CU: the panels of the last, partially filled round are cut along the hidden dimension into
   // 4 (or 2) workgroups each, which write partial outputs to the caller's scratch; a small kernel reduces them.
-  const int slots = num_cus_mlp();
+  const int slots = device_cus();
   const int tail = a.no_tail_split ? 0 : npanels % slots;
   int split = 1;
   if (tail > 0 && tail * 4 <= slots) split = 4;

@@ -489,21 +489,12 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
 #endif
 }
 
-int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n = v;
-  }
-  return n;
-}
 
 template <typename E, int KD, bool FULL, int BMT>
 int launch_panel(int pro, int epi, const PanelArgs& a_in, hipStream_t s) {
   PanelArgs a = a_in;
   const int npanels = (a.M + BMT - 1) / BMT, niter = a.N / PNT;
-  const int slots = num_cus() * (BMT == 128 ? 1 : 2);    // resident workgroups (LDS-limited)
+  const int slots = device_cus() * (BMT == 128 ? 1 : 2);    // resident workgroups (LDS-limited)
   const int tail = npanels % slots;
   a.tail_first = npanels;
   a.tail_split = 1;

@@ -42,6 +42,9 @@
 #ifndef EFFOCR_EXP
 #define EFFOCR_EXP 0
 #endif
+#ifndef QA_BARRIER_DRAIN
+#define QA_BARRIER_DRAIN 0
+#endif
 // timing experiments (never shipped): -DEFFOCR_EXP=3000+bits; 1 no attention, 2 no projection MFMAs, 4 no x loads,
 // 8 no stage barrier, 16 no output stores, 32 no accumulator -> fragment conversion, 128 no weight DMA, 256 no weight fragment reads
 #if EFFOCR_EXP >= 3000 && EFFOCR_EXP < 4000
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   constexpr int NXF = D / 16;                            // LayerNorm(x) fragments per token tile
   constexpr int R = QA_RING;
   constexpr bool SMALL = NSH < R - 1;                    // miniature test width: a head is shorter than the prefetch distance
-  static_assert(D % 128 == 0 && NS >= R - 1, "qkvattn: embed dim must be a multiple of 128");
+  static_assert(D % 128 == 0 && NS >= R - 1, "qkvattn: embed dim must be a multiple of 128");   // (hsplit > 1 needs NSH >= R - 1: launcher)
   __shared__ __attribute__((aligned(16))) char smem[R * QA_STAGE + NTT * 8192 + 3 * D * 4];
   // K / V and the parameters sit in the first 64 KB so that every access is one base register + a 16-bit immediate
   char* sK = smem;                                       // [key tile][k-step 0..3][lane] 16 B
@@ -108,27 +111,61 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   // image is cyclic over the heads, and workgroup b starts its cycle at head h0(b): co-resident workgroups then read
   // DIFFERENT parts of Wqkv at any moment (all of them starting at head 0 in lock step serialised on the same L2
   // channels: the first head's projection took 8x as long as the others), and the ring never drains between images.
-  const int h0 = ((int)blockIdx.x >> 3) % HEADS;         // blocks b, b+8, ... share an XCD (and its L2)
+  // Head split (small batches): HS workgroups share an image, workgroup (slot, grp) runs heads [grp*NH, grp*NH + NH) of the
+  // images slot, slot + nslots, ... — every workgroup still holds the image's whole rows (k and v need every token), so a
+  // batch of 64 images occupies 192 CUs with 2 heads each instead of 64 CUs with 6.
+  const int HS = a.hsplit > 1 ? a.hsplit : 1, NH = HEADS / HS;
+  const int grp = (int)blockIdx.x % HS, slot0 = (int)blockIdx.x / HS, nslots = (int)gridDim.x / HS;
+  const int hb = grp * NH;                               // first head of this workgroup
+  const int h0 = ((int)blockIdx.x >> 3) % NH;            // blocks b, b+8, ... share an XCD (and its L2)
   const char* Wb = static_cast<const char*>(a.Wb);
 
   for (int n = tid; n < 3 * D; n += 256) sBias[n] = a.bias[n];
 
   // ---- ring: global stage g = (head, q|k|v, k slice).  Wave w copies row block w>>1, k chunks (w&1)*8..+8 of the
   // stage: 4 pieces of 1 KB (two adjacent 512-byte cells each).  (ih, isec, ikt) = the next stage to be issued.
-  int ih = h0, isec = 0, ikt = 0, islot = 0;
-  auto issue_piece = [&](int p) __attribute__((always_inline)) {
+  int ih = hb + h0, isec = 0, ikt = 0, islot = 0;
+  // the four 1 KB pieces of a wave's share of a stage: ONE source address and ONE LDS base, the piece index is the instruction's
+  // immediate offset (added on both sides by the hardware) — a quarter of the address / M0 arithmetic of separate pointers
+  const unsigned lane16 = (unsigned)(tid & 63) * 16u;
+  auto issue_piece = [&](int p) __attribute__((always_inline)) {              // p = 0..3, a constant after inlining
     const int rb = (isec * D + ih * 64) / 32 + (w >> 1);
-    const char* src = Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8 + 2 * p) * 512 + lane * 16;
-    char* dst = sW + islot * QA_STAGE + ((w >> 1) * 16 + (w & 1) * 8 + 2 * p) * 512;
+    const __attribute__((address_space(1))) void* src =
+        (const __attribute__((address_space(1))) void*)(Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8) * 512 + lane16);
+    __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(sW + islot * QA_STAGE + ((w >> 1) * 16 + (w & 1) * 8) * 512);
 #if (QAX & 128)
     if (a.T < 0)
 #endif
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    switch (p) {
+      case 0: __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0); break;
+      case 1: __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0); break;
+      case 2: __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0); break;
+      default: __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0); break;
+    }
+  };
+  // Steady state: the four pieces in ONE inline-asm statement.  hipcc treats __builtin_amdgcn_global_load_lds as an access to both
+  // address spaces ("pending flat") and turns its next LDS wait into s_waitcnt lgkmcnt(0): every piece issued between two MFMAs
+  // drained the weight-fragment read issued a moment earlier (mlp_kernel.hpp has the numbers).  Completion is counted by hand
+  // (vmcnt at the stage barrier) either way.  M0 = LDS base (saved / restored), s_nop = the M0-write -> LDS-DMA wait state.
+  const unsigned sW_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sW;
+  auto issue_stage_asm = [&]() __attribute__((always_inline)) {
+    const int rb = (isec * D + ih * 64) / 32 + (w >> 1);
+    const char* src = Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8) * 512 + lane16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)(islot * QA_STAGE) + (unsigned)(((w >> 1) * 16 + (w & 1) * 8) * 512)));   // (wave-uniform; the compiler may keep the ring counters in VGPRs)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
   auto issue_advance = [&]() __attribute__((always_inline)) {
     islot = islot + 1 == R ? 0 : islot + 1;
-    if (++ikt == KT) { ikt = 0; if (++isec == 3) { isec = 0; ih = ih + 1 == HEADS ? 0 : ih + 1; } }
+    if (++ikt == KT) { ikt = 0; if (++isec == 3) { isec = 0; ih = ih + 1 == hb + NH ? hb : ih + 1; } }
   };
 
   auto run = [&](auto NT_) __attribute__((always_inline)) {
@@ -155,8 +192,8 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         }
       }
     };
-    const int nimg = (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // images of this workgroup (>= 1)
-    const int gtotal = nimg * NS;                        // ring stages of this workgroup
+    const int nimg = (a.B - slot0 + nslots - 1) / nslots;   // images of this workgroup (>= 1)
+    const int gtotal = nimg * NH * NSH;                  // ring stages of this workgroup
     int slot = 0;                                        // ring slot of the stage being consumed
     int g = 0;                                           // its index in the workgroup's stream (used by the SMALL path only)
 
@@ -202,7 +239,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               if constexpr (SMALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               else if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
               else if constexpr (ft >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((ft < R - 2 ? ft : R - 2) - 1) * 4) : "memory");
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if QA_BARRIER_DRAIN
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind the barrier is stage g-1's, fully consumed
+#endif
 #if !(QAX & 8)
               __builtin_amdgcn_s_barrier();
 #endif
@@ -238,9 +277,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
                 acc[tt][1] = Op16<E>::mfma(xf[tt][kt * 8 + ks], f1, acc[tt][1]);
               }
             }
-            if constexpr (ks >= 4) {
-              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_piece(ks - 4); }
-              else if constexpr (!LAST || ft >= R - 1) issue_piece(ks - 4);
+            if constexpr (ks == 4) {                     // right behind the stage barrier: the slot of stage g-1 is free
+              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_stage_asm(); }
+              else if constexpr (!LAST || ft >= R - 1) issue_stage_asm();
             }
             if constexpr (ks < 7 || sl + 1 < NSH) { f0 = n0; f1 = n1; }
           });
@@ -408,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     };
 
     __syncthreads();                                     // parameters visible before the ring starts filling
-    load_frags((int)blockIdx.x);                         // oldest in the in-order VM queue
+    load_frags(slot0);                                   // oldest in the in-order VM queue
 #pragma unroll
     for (int s0 = 0; s0 < R - 1; ++s0) {
 #pragma unroll
@@ -420,17 +459,17 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     asm volatile("" ::: "memory");
 #pragma unroll 1
     for (int ii = 0; ii < nimg; ++ii) {
-      const int img = (int)blockIdx.x + ii * (int)gridDim.x;
+      const int img = slot0 + ii * nslots;
       tok0 = (int64_t)img * T;
       refresh_lane();
       QA_STAMP(0);
 #pragma unroll 1
-      for (int i = 0; i < HEADS - 1; ++i) {
-        const int h = h0 + i < HEADS ? h0 + i : h0 + i - HEADS;
+      for (int i = 0; i < NH - 1; ++i) {
+        const int h = hb + (h0 + i < NH ? h0 + i : h0 + i - NH);
         head(std::false_type{}, std::false_type{}, h, i, 0);
       }
-      const int hl = h0 == 0 ? HEADS - 1 : h0 - 1;
-      if (ii + 1 < nimg) head(std::false_type{}, std::true_type{}, hl, HEADS - 1, img + (int)gridDim.x);
+      const int hl = hb + (h0 == 0 ? NH - 1 : h0 - 1);
+      if (ii + 1 < nimg) head(std::false_type{}, std::true_type{}, hl, HEADS - 1, img + nslots);
       else head(std::true_type{}, std::false_type{}, hl, HEADS - 1, 0);
     }
   };
@@ -444,18 +483,25 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
 template <typename E>
 int launch_qkvattn(const QkvAttnArgs& a, hipStream_t s) {
   const int ntt = (a.T + 31) / 32;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cus = v;
+  const int cus = device_cus();
+  // one persistent workgroup per CU (160 KB of LDS each); batches of less than half a round of CUs split every image's heads
+  // over hs workgroups (hs = the largest divisor of the head count with B * hs <= CUs; D = 384 only: a head must be at least
+  // as long as the ring's prefetch distance)
+  int hs = 1;
+  if (a.hsplit != 1 && a.D == 384) {
+    const int heads = a.D / 64;
+    for (int c = heads; c >= 2; --c)
+      if (heads % c == 0 && (int64_t)a.B * c <= cus && (a.hsplit <= 0 || c <= a.hsplit)) { hs = c; break; }
   }
-  const dim3 grid((unsigned)(a.B < cus ? a.B : cus)), blk(256);   // one persistent workgroup per CU (160 KB of LDS each)
-  if (a.D == 384 && ntt == 7 && a.cls_only) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true>), grid, blk, 0, s, a);
-  else if (a.D == 384 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7>), grid, blk, 0, s, a);
-  else if (a.D == 384 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 2>), grid, blk, 0, s, a);
-  else if (a.D == 128 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 7>), grid, blk, 0, s, a);
-  else if (a.D == 128 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 2>), grid, blk, 0, s, a);
+  QkvAttnArgs ah = a;
+  ah.hsplit = hs;
+  const QkvAttnArgs& a2 = ah;
+  const dim3 grid((unsigned)(hs > 1 ? a.B * hs : (a.B < cus ? a.B : cus))), blk(256);
+  if (a.D == 384 && ntt == 7 && a.cls_only) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true>), grid, blk, 0, s, a2);
+  else if (a.D == 384 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7>), grid, blk, 0, s, a2);
+  else if (a.D == 384 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 2>), grid, blk, 0, s, a2);
+  else if (a.D == 128 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 7>), grid, blk, 0, s, a2);
+  else if (a.D == 128 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 2>), grid, blk, 0, s, a2);
   else return fail(EFFOCR_EUNSUPPORTED, "qkv_attn_fused: (embed dim, tokens) must be (128|384, <=64 or 193..224)");
   return check_launch("qkv_attn_fused");
 }

@@ -288,8 +288,9 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
   // few tiles and a long K (the deep layers at small inputs: 4 workgroups looping over 144 stages): split K over up to a round of CUs
   const int nks = a.w16 ? (a.KH * a.KW * a.Cin + 63) / 64 : a.KH * a.KW * a.Cin / 32;
   a.ksplit = 1;
-  if (a.partial && grid * 2 <= 256 && nks >= 8) {
-    int64_t sp = 256 / grid;
+  const int cus = device_cus();
+  if (a.partial && grid * 2 <= cus && nks >= 8) {
+    int64_t sp = cus / grid;
     if (sp > nks / 2) sp = nks / 2;
     if (sp > 32) sp = 32;
     while (sp > 1 && (size_t)sp * M * a.Cout * 4 > a.partial_bytes) --sp;

@@ -58,6 +58,7 @@ __device__ __forceinline__ void lin_taps(int i, float scale, int in_size, int& i
 
 struct CropArgs {
   const uint8_t* img; int H, W; int64_t stride;
+  int64_t img_stride; int n_img, box_ld;                 // batch form: box_ld = 5, column 4 = image index, images img_stride bytes apart
   const int* boxes; int n; int S;
   float* out;
   float mean[3], std[3], fill[3];
@@ -70,10 +71,13 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= S * S4) return;
   const int oy = p / S4, ox = (p - oy * S4) * 4;
-  int x0 = a.boxes[4 * b], y0 = a.boxes[4 * b + 1], x1 = a.boxes[4 * b + 2], y1 = a.boxes[4 * b + 3];
+  const int* bx = a.boxes + (size_t)a.box_ld * b;
+  int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+  const int im = a.box_ld > 4 ? bx[4] : 0;
   x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
   x1 = x1 > a.W ? a.W : x1; y1 = y1 > a.H ? a.H : y1;
-  const int w = x1 - x0, h = y1 - y0;
+  const bool im_ok = im >= 0 && im < a.n_img;
+  const int w = im_ok ? x1 - x0 : 0, h = y1 - y0;
   float* o = a.out + (size_t)b * 3 * S * S + (size_t)oy * S + ox;
   if (w <= 0 || h <= 0) {                                 // host rejects empty boxes; never read out of bounds
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
   }
   const int L = w > h ? w : h;
   const float scale = (float)L / (float)S;
-  const uint8_t* base = a.img + (size_t)y0 * a.stride + (size_t)x0 * 3;
+  const uint8_t* base = a.img + (size_t)im * a.img_stride + (size_t)y0 * a.stride + (size_t)x0 * 3;
 
   float acc[4][3];
 #pragma unroll
@@ -146,18 +150,26 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
 
 }  // namespace
 
-int crop_transform(const uint8_t* img, int H, int W, int64_t stride, const int* boxes, int n, int S, int antialias,
-                   const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s) {
+// n_img images of one geometry, img_stride bytes apart; boxes [n, box_ld] int32 (box_ld 4: every box cuts image 0; 5: column 4 =
+// image index; a box that names no image yields a zero crop).  Any n: launched in slices of 65535 boxes.
+int crop_transform(const uint8_t* img, int n_img, int64_t img_stride, int H, int W, int64_t stride, const int* boxes, int box_ld, int64_t n, int S,
+                   int antialias, const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s) {
   if (n <= 0) return EFFOCR_OK;
   if (S <= 0 || (S & 3)) return fail(EFFOCR_EUNSUPPORTED, "crop_transform: output size must be a positive multiple of 4");
-  if (n > 65535) return fail(EFFOCR_EUNSUPPORTED, "crop_transform: at most 65535 boxes per call");
-  CropArgs a;
-  a.img = img; a.H = H; a.W = W; a.stride = stride; a.boxes = boxes; a.n = n; a.S = S; a.out = out;
-  for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = stdv[c]; a.fill[c] = fill[c]; }
-  const dim3 grid((unsigned)((S * (S / 4) + 255) / 256), (unsigned)n);
-  if (antialias) hipLaunchKernelGGL(crop_transform_kernel<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(crop_transform_kernel<false>, grid, dim3(256), 0, s, a);
-  return check_launch("crop_transform");
+  if (box_ld != 4 && box_ld != 5) return fail(EFFOCR_EINVAL, "crop_transform: boxes must have 4 or 5 columns");
+  for (int64_t lo = 0; lo < n; lo += 65535) {
+    const int m = (int)(n - lo < 65535 ? n - lo : 65535);
+    CropArgs a;
+    a.img = img; a.H = H; a.W = W; a.stride = stride; a.img_stride = img_stride; a.n_img = n_img; a.box_ld = box_ld;
+    a.boxes = boxes + lo * box_ld; a.n = m; a.S = S; a.out = out + lo * 3 * S * S;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = stdv[c]; a.fill[c] = fill[c]; }
+    const dim3 grid((unsigned)((S * (S / 4) + 255) / 256), (unsigned)m);
+    if (antialias) hipLaunchKernelGGL(crop_transform_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(crop_transform_kernel<false>, grid, dim3(256), 0, s, a);
+    const int rc = check_launch("crop_transform");
+    if (rc) return rc;
+  }
+  return EFFOCR_OK;
 }
 
 }  // namespace effocr

@@ -81,3 +81,46 @@ class ShardedRecognizer:
             local = crops[lo:hi]
         d, i = self.neighbors_fn(local)
         return all_gather_rows(d, n_total, self.group), all_gather_rows(i, n_total, self.group)
+
+
+def all_gather_texts(local_pairs, group=None):
+    """All-gather of the per-rank transcriptions: ``local_pairs`` = list of (key, text) -> the concatenation over ranks in rank
+    order, on every rank.  One collective (torch's object all-gather: the pickled strings travel as byte tensors over RCCL when
+    the backend is "nccl", over gloo in the CPU tests); a few hundred bytes per text line — latency-bound, like the id gather."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(local_pairs)
+    world = dist.get_world_size(group)
+    out = [None] * world
+    dist.all_gather_object(out, list(local_pairs), group=group)
+    return [p for part in out for p in part]
+
+
+class ShardedPipeline:
+    """BASELINE configs[4] on N GPUs: text-LINE images are the independent units of ``run_effocr`` (a line's boxes, crops and
+    characters depend on nothing else), so rank r runs the whole pipeline — localizer, crops, recognizer, k-NN, post-processing —
+    on the contiguous slice ``shard_bounds(n_lines, r, N)`` of the line list with every model and the glyph index replicated,
+    and ONE all-gather of the transcriptions (strings) gives every rank the full result.  No other collective.
+
+    ``run_fn(images) -> (inference_results dict, anything)`` is a per-rank closure over ``effocr_amd.pipeline.run_effocr``
+    (engines on this rank's device).  In-memory images are keyed by their GLOBAL position in the input list."""
+
+    def __init__(self, run_fn, group=None):
+        self.run_fn = run_fn
+        self.group = group
+
+    def __call__(self, coco_images):
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        else:
+            rank, world = 0, 1
+        lo, hi = shard_bounds(len(coco_images), rank, world)
+        local = list(coco_images[lo:hi])
+        results = self.run_fn(local)[0] if local else {}
+        pairs = []
+        for j, img in enumerate(local):
+            key = img if isinstance(img, str) else j             # run_effocr keys arrays by LOCAL position
+            pairs.append((img if isinstance(img, str) else lo + j, results[key]))
+        merged = {}
+        for k, v in all_gather_texts(pairs, self.group):
+            merged[k] = v
+        return merged

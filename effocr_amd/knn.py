@@ -32,6 +32,7 @@ class IndexFlatIP:
     metric_type = 0          # faiss.METRIC_INNER_PRODUCT
     is_trained = True
 
+    SCREEN_MIN_QUERIES = 129  # ... and from this many queries per call on (below: the exact streaming kernel is faster, measured)
     SCREEN_MIN_ROWS = 65536   # from this size on `search` uses the screened entry point (bit-identical results, ~4x faster at 1M rows)
 
     def __init__(self, d, device="cuda:0", screen="auto"):
@@ -98,8 +99,9 @@ class IndexFlatIP:
             return False
         if self.screen is True:
             return True
-        # up to 32 queries (one text line) the exact search streams the fp32 rows once at the HBM rate: nothing to screen
-        return self.ntotal >= self.SCREEN_MIN_ROWS and (nq is None or nq > 32)
+        # up to 128 queries (one text line: tens; the ONNX driver's calls: 64) the exact search streams the fp32 rows through the
+        # MFMA operands once or twice at the HBM / fp32-MFMA rate (knn.hip streaming kernel): faster than two bf16 screening passes
+        return self.ntotal >= self.SCREEN_MIN_ROWS and (nq is None or nq > self.SCREEN_MIN_QUERIES - 1)
 
     def _screen_copy(self):
         if self._xb16 is None:

@@ -210,35 +210,42 @@ class HipLocalizer:
                                                         _lib.current_stream(self.device)), "effocr_localizer_forward")
         return pred
 
-    def letterbox(self, image, bgr=False):
+    def letterbox(self, image, bgr=False, out=None):
         """HWC uint8 image (numpy / tensor; ``bgr=True`` for cv2.imread order) -> [1,3,H,W] float32 on the device
-        (load_localizer_img, localizer_engine.py:75-85)."""
+        (load_localizer_img, localizer_engine.py:75-85).  ``out``: an existing [1,3,H,W] slice of a batch tensor to fill."""
         t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
         if t.dim() != 3 or t.shape[2] != 3 or t.dtype != torch.uint8:
             raise ValueError("image must be HWC uint8 with 3 channels")
         t = t.to(self.device).contiguous()
         H, W = int(t.shape[0]), int(t.shape[1])
         nh, nw, top, _, left, _, _, _ = letterbox_geometry((H, W), self.input_shape, auto=False, stride=32)
-        out = torch.empty((1, 3) + self.input_shape, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((1, 3) + self.input_shape, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (1, 3) + self.input_shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float32 [1,3,H,W] tensor on the localizer's device")
         with torch.cuda.device(self.device):
             _lib.check(self._L.effocr_letterbox(_lib.ptr(t), H, W, 3 * W, 1 if bgr else 0, self.input_shape[0], self.input_shape[1], nh, nw, top, left,
                                                 _lib.ptr(out), _lib.current_stream(self.device)), "effocr_letterbox")
         return out
 
-    def nms_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False):
-        """pred [n, 5 + nc] (one image) -> (rows [max_det,6], count [1] int32), both on the device, no synchronisation."""
+    def nms_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False, out=None, cnt=None):
+        """pred [n, 5 + nc] (one image) -> (rows [max_det,6], count [1] int32), both on the device, no synchronisation.
+        ``out`` / ``cnt``: rows of a caller's batch result to fill instead of fresh tensors (cnt must be zeroed by the caller)."""
         if not (0 <= conf_thres <= 1):
             raise AssertionError(f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0")
         if not (0 <= iou_thres <= 1):
             raise AssertionError(f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0")
         pred = pred.to(self.device, torch.float32).contiguous()
         n = int(pred.shape[0])
-        out = torch.empty((max_det, 6), dtype=torch.float32, device=self.device)
-        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if out is None:
+            out = torch.empty((max_det, 6), dtype=torch.float32, device=self.device)
+        if cnt is None:
+            cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
         need = int(self._L.effocr_nms_workspace_bytes(n, MAX_NMS))
         with self._lock, torch.cuda.device(self.device):
-            # one scratch per call in flight: successive images of a batch must not share the candidate lists
-            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            # ONE scratch per stream, reused by every image: the launches of successive images are ordered on the stream, so the
+            # candidate lists of image i are dead when image i+1's kernels start (up to ~80 MB at 25 200 candidates: not per image)
+            ws = self._workspace("nms", need)
             _lib.check(self._L.effocr_nms(_lib.ptr(pred), n, self.nc, float(conf_thres), float(iou_thres), int(max_det), MAX_NMS, MAX_WH,
                                           1 if agnostic else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(),
                                           _lib.current_stream(self.device)), "effocr_nms")
@@ -274,35 +281,55 @@ class EffLocalizer:
         im0 = np.array(Image.open(input_path).convert("RGB"))
         return self._eng_net.letterbox(im0, bgr=False)
 
-    def run(self, imgs):
-        """imgs: list of image paths, of HWC uint8 arrays (RGB), or of already letterboxed float32 [1,3,H,W] arrays (what
-        ``load_localizer_img`` returns in the reference) -> list of CPU tensors [n,6] (x1, y1, x2, y2, conf, cls)."""
+    def _letterboxed(self, imgs):
+        """list entries -> one [n,3,H,W] float32 device tensor (one image per ENTRY).  A pre-letterboxed float entry may carry a
+        batch: like the reference, whose ``_postprocess`` keeps ``non_max_suppression(pred)[0]`` per entry
+        (localizer_engine.py:58-60), only its first image is used, so results always line up with the input list."""
+        eng = self._eng_net
+        x = torch.empty((len(imgs), 3) + self._input_shape, dtype=torch.float32, device=eng.device)
+        for i, img in enumerate(imgs):
+            if isinstance(img, str):
+                from PIL import Image
+                img = np.array(Image.open(img).convert("RGB"))    # load_localizer_img (:75-85), PIL instead of cv2: RGB in, no channel swap
+            if (isinstance(img, np.ndarray) and img.dtype == np.uint8) or (isinstance(img, torch.Tensor) and img.dtype == torch.uint8):
+                eng.letterbox(img, bgr=False, out=x[i:i + 1])
+            else:
+                t = torch.as_tensor(img)
+                if t.dtype != torch.float32:
+                    raise ValueError(f"Unexpected input data type. Actual: {t.dtype}, expected: float32")
+                if t.dim() == 3:
+                    t = t.unsqueeze(0)
+                if t.dim() != 4 or t.shape[0] < 1 or tuple(t.shape[1:]) != (3,) + self._input_shape:
+                    raise ValueError(f"expected a letterboxed [k,3,{self._input_shape[0]},{self._input_shape[1]}] array, got {tuple(t.shape)}")
+                x[i].copy_(t[0], non_blocking=True)
+        return x
+
+    def run_device(self, imgs, max_det=1000):
+        """``run`` without the download: -> (rows [n, max_det, 6] float32, counts [n] int32), both on the device, nothing
+        synchronised — rows[i, :counts[i]] = (x1, y1, x2, y2, conf, cls) of entry i.  The letterboxed images go through the network
+        in sub-batches of 16 and the per-image NMS launches are queued back to back on the current stream."""
         eng = self._eng_net
         if not isinstance(imgs, (list, tuple)):
             imgs = [imgs]
-        xs = []
-        for img in imgs:
-            if isinstance(img, str):
-                xs.append(self.load_localizer_img(img))
-            elif isinstance(img, np.ndarray) and img.dtype == np.uint8:
-                xs.append(eng.letterbox(img, bgr=False))
-            else:
-                x = torch.as_tensor(img)
-                if x.dtype != torch.float32:
-                    raise ValueError(f"Unexpected input data type. Actual: {x.dtype}, expected: float32")
-                if x.dim() == 3:
-                    x = x.unsqueeze(0)
-                xs.append(x.to(eng.device))
-        # the reference runs the session image by image (localizer_engine.py:52); here the letterboxed images go through the
-        # network in batches of up to 16 and the per-image NMS launches are queued back to back: ONE synchronisation per call
-        rows, cnts = [], []
-        for b0 in range(0, len(xs), 16):
-            pred = eng.forward(torch.cat(xs[b0:b0 + 16], dim=0))
+        n = len(imgs)
+        rows = torch.empty((n, max_det, 6), dtype=torch.float32, device=eng.device)
+        counts = torch.zeros(n, dtype=torch.int32, device=eng.device)
+        if n == 0:
+            return rows, counts
+        x = self._letterboxed(imgs)
+        for b0 in range(0, n, 16):
+            pred = eng.forward(x[b0:b0 + 16])
             for i in range(pred.shape[0]):
-                r, c = eng.nms_async(pred[i], self._conf_thresh, self._iou_thresh, max_det=1000)
-                rows.append(r)
-                cnts.append(c)
-        if not rows:
+                eng.nms_async(pred[i], self._conf_thresh, self._iou_thresh, max_det=max_det, out=rows[b0 + i], cnt=counts[b0 + i:b0 + i + 1])
+        return rows, counts
+
+    def run(self, imgs):
+        """imgs: list of image paths, of HWC uint8 arrays (RGB), or of already letterboxed float32 [1,3,H,W] arrays (what
+        ``load_localizer_img`` returns in the reference) -> list (one per entry) of CPU tensors [n,6] (x1, y1, x2, y2, conf, cls).
+        (The reference runs the session image by image, localizer_engine.py:52; here: batched network, ONE synchronisation.)"""
+        rows, counts = self.run_device(imgs)
+        if rows.shape[0] == 0:
             return []
-        counts = torch.cat(cnts).cpu().tolist()
-        return [r[:n].cpu() for r, n in zip(rows, counts)]
+        counts = counts.cpu().tolist()
+        rows = rows[:, : max(counts + [0])].cpu()
+        return [rows[i, :c].clone() for i, c in enumerate(counts)]

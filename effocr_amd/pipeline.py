@@ -190,3 +190,149 @@ def run_recognizer_batches(char_crops, recognizer_engine, knn_func, candidate_ch
     index_list = [ix.squeeze(-1).tolist() for ix in indices]
     flat = [item for sub in index_list for item in sub]
     return [candidate_chars[i] for i in flat], flat
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# run_effocr: the whole ONNX driver (infer_effocr_onnx_multi.py:227-397) with every array-sized step on the device
+
+COCO_JSON_SKELETON = {"info": {"": ""}, "licenses": [{"": ""}], "images": [], "annotations": [],
+                      "categories": [{"id": 0, "name": "char"}]}          # utils/coco_utils.py:3-9
+
+
+def word_end_indices(char_rights, word_lefts):
+    """``en_preprocess`` of the ONNX driver (infer_effocr_onnx_multi.py:70-90) after the two sorts: for every word box (left to
+    right) the index of the character whose RIGHT edge lies right of the word's LEFT edge and closest to it; the strict ``<``
+    keeps the first minimum and ``closest_idx`` is NOT reset between words (a word without a candidate repeats the previous
+    index) — both quirks kept."""
+    rights = np.asarray(char_rights, dtype=np.float64)
+    out, closest = [], 0
+    for wl in word_lefts:
+        cand = np.nonzero(rights > wl)[0]
+        if cand.size:
+            d = np.abs(wl - rights[cand])
+            if d.min() < 1_000_000:                                          # LARGE_NUMBER (:38)
+                closest = int(cand[int(np.argmin(d))])
+        out.append(closest)
+    return out
+
+
+def _load_rgb(p):
+    if isinstance(p, str):
+        from PIL import Image
+        return np.array(Image.open(p).convert("RGB"))                       # :311
+    a = np.asarray(p)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+        raise ValueError("run_effocr takes image paths or HWC uint8 RGB arrays")
+    return a
+
+
+def _resolve_slice(v, size):
+    """numpy slice bounds on the device: a negative bound counts from the end, everything is clipped to [0, size]."""
+    v = torch.where(v < 0, v + size, v)
+    return v.clamp(0, size)
+
+
+def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform, lang, num_streams=4, vertical=False,
+               localizer_output=None, conf_thres=0.5, *, knn_func, candidate_chars, anchor_margin=None, max_det=1000):
+    """``run_effocr`` of infer_effocr_onnx_multi.py:227-397: text-line images -> {image key: transcription}.
+
+    Same stages, same arithmetic, but the arrays never leave the GPU between them:
+      localizer   every line image is uploaded ONCE (uint8), letterboxed, run through the YOLOv5s network in sub-batches and
+                  NMS'd on the device (``EffLocalizer.run_device``; the reference: one ORT call per image on ``num_streams`` threads);
+      boxes       class 0 = characters, class 1 = words (:252-256,275); characters sorted along the reading direction with a
+                  STABLE sort in NMS order (``sorted(..., key=x[0])`` :72); every box rounded, scaled by size/640 — the literal
+                  640 of :315-318 — rounded again (both half-to-even, like ``torch.round`` and Python's ``round``) and widened to
+                  the full line height (width when ``vertical``), then resolved like the numpy slice ``im[y0:y1, x0:x1]`` (:320);
+      crops       ONE ``effocr_crop_transform_batch`` launch over all boxes of all lines from the uploaded images (the reference
+                  re-reads every image with PIL and transforms crop by crop on threads); an empty slice gives the zero image
+                  ``create_batches`` substitutes for a failed transform (:145-147,196-200);
+      recognizer  encoder + fused L2 normalise + k-NN (k = 1) over all crops (:347-375; the reference's zero padding of the
+                  last batch of 64 produces rows nobody reads and is skipped);
+      post        per line: characters joined (:384-385) and, for ``lang == "en"``, ``en_postprocess`` with the heights /
+                  bottoms of the 640-space boxes (:323-325,387-392).
+    Two host synchronisations per call (character counts; ids + boxes), whatever the number of lines.
+
+    Differences from the reference signature: ``knn_func`` / ``candidate_chars`` are module globals there (:372,375) and
+    keyword arguments here; ``anchor_margin`` is exposed (the reference call leaves ``en_postprocess``'s default None);
+    ``num_streams`` / ``conf_thres`` are accepted and unused (HIP streams are ordered by the device; ``conf_thres`` only feeds the
+    detectron2 / mmdetection branches); ``localizer_output`` (debug drawings) raises NotImplementedError.  Results are keyed by
+    the path (or by position for in-memory arrays) in INPUT order — the reference's order is thread-completion order.
+    Images of different sizes are processed in groups of one geometry."""
+    import copy
+    from .postprocess import LinePostprocessor
+    if lang not in ("en", "jp"):
+        raise ValueError("lang must be 'en' or 'jp'")
+    if localizer_output:
+        raise NotImplementedError("localizer_output (debug drawings of the localizer boxes) is not part of the hot path")
+    if getattr(localizer_engine, "_model_backend", "yolo") != "yolo":
+        raise NotImplementedError("only the yolo localizer backend exists")
+    keys = [p if isinstance(p, str) else i for i, p in enumerate(coco_images)]
+    inference_results, inference_coco = {}, copy.deepcopy(COCO_JSON_SKELETON)
+    if not coco_images:
+        return inference_results, inference_coco
+    if not hasattr(recognizer_engine, "encode_device"):
+        raise TypeError("recognizer_engine must be an effocr_amd EffRecognizer (device-resident crops are handed to encode_device)")
+    dev = recognizer_engine.device
+    images = [_load_rgb(p) for p in coco_images]
+    groups = {}
+    for i, im in enumerate(images):
+        groups.setdefault(im.shape[:2], []).append(i)
+    post = LinePostprocessor(lang=lang, vertical=vertical, anchor_margin=anchor_margin)
+    # en_preprocess is called WITHOUT the vertical flag (:277: always sorts by x0); jp_preprocess gets it (:288)
+    axis = 1 if (vertical and lang == "jp") else 0
+    per_line = {}                                                            # line index -> (ids, sorted char boxes, word boxes)
+    for (H, W), members in groups.items():
+        stack = torch.from_numpy(np.stack([images[i] for i in members])).to(dev, non_blocking=True)    # [L,H,W,3] uint8: the one upload
+        L = len(members)
+        rows, counts = localizer_engine.run_device([stack[j] for j in range(L)], max_det=max_det)
+        valid = torch.arange(max_det, device=dev)[None, :] < counts[:, None]
+        labels = rows[..., 5]
+        is_char = valid & (labels == 0)
+        key = torch.where(is_char, rows[..., axis], torch.full_like(rows[..., axis], float("inf")))
+        order = torch.sort(key, dim=1, stable=True).indices                  # sorted(bboxes_char, key=x[0] | x[1]) (:72,134): stable
+        boxes = torch.gather(rows[..., :4], 1, order[..., None].expand(-1, -1, 4))     # [L,max_det,4], the first n_chars rows are characters
+        n_chars = is_char.sum(1)
+        r = torch.round(boxes).double()                                      # torch.round(bbox) (:313)
+        sel = torch.arange(max_det, device=dev)[None, :] < n_chars[:, None]
+        line_idx = torch.arange(L, device=dev, dtype=torch.int64)[:, None].expand(-1, max_det)
+        if vertical:                                                         # (:315-316)
+            lo = torch.round(r[..., 1] * H / 640).to(torch.int64)
+            hi = torch.round(r[..., 3] * H / 640).to(torch.int64)
+            y0, y1 = _resolve_slice(lo, H), _resolve_slice(hi, H)
+            x0, x1 = torch.zeros_like(y0), torch.full_like(y0, W)
+        else:                                                                # (:317-318)
+            lo = torch.round(r[..., 0] * W / 640).to(torch.int64)
+            hi = torch.round(r[..., 2] * W / 640).to(torch.int64)
+            x0, x1 = _resolve_slice(lo, W), _resolve_slice(hi, W)
+            y0, y1 = torch.zeros_like(x0), torch.full_like(x0, H)
+        boxes5 = torch.stack((x0, y0, x1, y1, line_idx), dim=-1)[sel].to(torch.int32)      # [total,5]; boolean indexing = sync 1
+        if boxes5.shape[0]:
+            crops = char_transform.boxes_batch(stack, boxes5)
+            emb = recognizer_engine.encode_device(crops, normalize=True)
+            ids = knn_func(emb, k=1)[1][:, 0]
+        else:
+            ids = torch.empty(0, dtype=torch.int64, device=dev)
+        # sync 2: everything the string stage needs, in one go
+        is_word = valid & (labels == 1)
+        ids_h, boxes_h, n_h = ids.cpu().tolist(), boxes.cpu(), n_chars.cpu().tolist()
+        rows_h, word_h = (rows.cpu(), is_word.cpu()) if lang == "en" else (None, None)
+        off = 0
+        for j, li in enumerate(members):
+            n = n_h[j]
+            wb = rows_h[j][word_h[j]][:, :4] if lang == "en" else None
+            per_line[li] = (ids_h[off:off + n], boxes_h[j, :n], wb)
+            off += n
+    for li, key_ in enumerate(keys):
+        ids_l, cb, wb = per_line[li]
+        out = "".join(candidate_chars[i][0] for i in ids_l).strip()           # "".join(x[0] for x in textline).strip() (:385), k = 1
+        if lang == "en":
+            if len(ids_l):
+                wl = sorted(float(v) for v in wb[:, 0])                      # sorted(bboxes_word, key=x[0]) lefts (:73,78)
+                wei = word_end_indices(cb[:, 2].tolist(), wl)
+            else:
+                wei = []                                                     # (:283-285)
+            heights = [float(b[3] - b[1]) for b in cb]                       # (:323-325)
+            bottoms = [float(b[3]) for b in cb]
+            out = post.en_postprocess(out, wei, heights, bottoms)
+        inference_results[key_] = out
+    return inference_results, inference_coco

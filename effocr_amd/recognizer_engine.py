@@ -61,6 +61,22 @@ class EffRecognizer:
     def __call__(self, imgs):
         return self.run(imgs)
 
+    @property
+    def device(self):
+        return self._eng_net.device
+
+    @property
+    def img_size(self):
+        return self._eng_net.img_size
+
+    def encode_device(self, x, normalize=False, chunk=2048):
+        """Device-resident twin of ``run`` for callers whose crops are already in HBM (effocr_amd.pipeline.run_effocr):
+        x [B,3,S,S] float32 on the engine's device -> [B,D] float32 on the device, asynchronous on the current stream.
+        Calls of more than ``chunk`` crops are encoded in slices (bounds the activation workspace: ~1.6 MB per ViT-S crop)."""
+        if x.shape[0] <= chunk:
+            return self._eng_net.forward(x, normalize=normalize)
+        return torch.cat([self._eng_net.forward(x[i:i + chunk], normalize=normalize) for i in range(0, x.shape[0], chunk)])
+
     def run(self, imgs):
         """imgs: np.ndarray[B,3,H,W] float32 -> [np.ndarray[B,D] float32] (ORT ``session.run`` shape)."""
         if isinstance(imgs, torch.Tensor):

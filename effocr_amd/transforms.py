@@ -109,6 +109,31 @@ class PairedTransform:
             # bx is freed by the caching allocator in stream order: safe without a sync
         return out
 
+    def boxes_batch(self, images, boxes5, out=None):
+        """The crops of SEVERAL images of one geometry in one launch (effocr_crop_transform_batch): ``images`` = uint8 device tensor
+        [L,H,W,3] (contiguous), ``boxes5`` = int32 device tensor [n,5] = x0,y0,x1,y1,image index, coordinates already resolved the
+        way numpy slicing does (``slice_boxes`` semantics).  An EMPTY box gives a zero crop — what the reference's
+        ``create_batches`` substitutes for a crop whose transform raised (infer_effocr_onnx_multi.py:145-147,196-200).
+        -> Tensor[n,3,S,S] fp32 on the device, nothing synchronised."""
+        if images.dim() != 4 or images.shape[3] != 3 or images.dtype != torch.uint8 or not images.is_cuda:
+            raise ValueError("images must be a uint8 device tensor [L,H,W,3]")
+        if boxes5.dim() != 2 or boxes5.shape[1] != 5 or boxes5.dtype != torch.int32 or boxes5.device != images.device:
+            raise ValueError("boxes5 must be an int32 [n,5] tensor on the images' device")
+        images, boxes5 = images.contiguous(), boxes5.contiguous()
+        Lc, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        n, S, dev = int(boxes5.shape[0]), self.size, images.device
+        if out is None:
+            out = torch.empty((n, 3, S, S), dtype=torch.float32, device=dev)
+        elif tuple(out.shape) != (n, 3, S, S) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out must be a contiguous float32 [n,3,size,size] tensor on the images' device")
+        if n == 0:
+            return out
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().effocr_crop_transform_batch(_lib.ptr(images), Lc, H * W * 3, H, W, W * 3, _lib.ptr(boxes5), n, S, int(self.antialias),
+                                                              _f3(self.mean), _f3(self.std), _f3(self.fill), _lib.ptr(out),
+                                                              _lib.current_stream(dev)), "crop_transform_batch")
+        return out
+
     def __call__(self, crop):
         """Reference per-crop convention: one HWC uint8 crop -> Tensor[3,S,S] (on the device)."""
         arr = np.asarray(crop)

@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define EFFOCR_ABI_VERSION 1
+/* bumped whenever an exported signature or the meaning of an argument changes (round 1: 1; round 2 added
+ * arguments to effocr_op_mlp_blocked without a bump — callers must treat 1 as "unknown layout"); a caller built
+ * against another value must refuse to call into the library (effocr_amd/_lib.py does) */
+#define EFFOCR_ABI_VERSION 3
 
 enum effocr_status {
   EFFOCR_OK = 0,
@@ -167,11 +170,21 @@ int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64
  *              with ValueError like PIL does); an invalid box yields a zero crop, never a bad read
  *   antialias  torchvision's tensor Resize default: 1 from 0.17 on, 0 before
  *   mean/std/fill  3 host floats each (ImageNet mean/std, pad colour on the 0..255 scale)
- *   out_dev    fp32 [n,3,size,size] (the encoder's input layout); size % 4 == 0, n <= 65535
+ *   out_dev    fp32 [n,3,size,size] (the encoder's input layout); size % 4 == 0; any n (launched in slices of 65535 boxes)
  * ------------------------------------------------------------------------------------------ */
 int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64_t row_stride,
                           const int32_t* boxes_dev, int n, int size, int antialias, const float* mean,
                           const float* std, const float* fill, float* out_dev, void* stream);
+
+/* The same over the boxes of SEVERAL images of one geometry in one launch — the crops of a whole run_effocr call
+ * (infer_effocr_onnx_multi.py:313-345 cuts every line image's boxes on the host, one PIL read per line):
+ *   images_dev  n_images uint8 HWC images, `image_stride` bytes apart
+ *   boxes_dev   int32 [n,5] = x0,y0,x1,y1,image index; a box naming no image, or an empty one, yields a ZERO crop — what
+ *               create_batches substitutes for a crop whose transform failed (:145-147, TransformationThread :196-200)
+ *   n           any count (launched in slices of 65535 boxes) */
+int effocr_crop_transform_batch(const uint8_t* images_dev, int n_images, int64_t image_stride, int height, int width,
+                                int64_t row_stride, const int32_t* boxes_dev, int64_t n, int size, int antialias,
+                                const float* mean, const float* std, const float* fill, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Localizer engine: the YOLOv5 character / word detector the reference runs through ONNXRuntime

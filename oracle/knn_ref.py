@@ -104,3 +104,64 @@ def remove_ids(xb, ids):
     keep = np.ones(xb.shape[0], bool)
     keep[np.asarray(ids, np.int64)] = False
     return xb[keep]
+
+
+# ------------------------------------------------------------------------------------------------
+# Summation orders faiss is free to use.  IndexFlatIP.search computes Q X^T with an sgemm for >= 20 queries and a SIMD scan
+# below; neither pins the order in which the D products of a score are added (BLAS blocks K by its micro-kernel's unroll and
+# vector width; the scan keeps 4-16 lane partial sums), and whether a product is fused into the add (FMA) depends on the build.
+# ``scores_in_order`` restates those families in true fp32 so that a test can ask: for which top-1 margin does the id depend
+# on the order?  (tests/test_gpu_knn.py::test_top1_is_invariant_under_summation_order)
+SUM_ORDERS = ("ascending_fma", "ascending", "reversed", "blocked8", "blocked16", "blocked32", "lanes8", "lanes16", "pairwise", "fp64")
+
+
+def _pairwise_sum(parts):
+    """Balanced binary tree over axis 0 in fp32."""
+    parts = list(parts)
+    while len(parts) > 1:
+        nxt = [parts[i] + parts[i + 1] for i in range(0, len(parts) - 1, 2)]
+        if len(parts) & 1:
+            nxt.append(parts[-1])
+        parts = nxt
+    return parts[0]
+
+
+def scores_in_order(q, xb, order):
+    """[B,N] inner products accumulated in fp32 in the named order (``fp64``: float64, rounded once at the end)."""
+    q, xb = _f32(q), _f32(xb)
+    B, D = q.shape
+    N = xb.shape[0]
+    if order == "ascending_fma":
+        return flat_ip_scores(q, xb)                       # the C oracle: fmaf chain, k ascending (what the HIP kernel is bit-exact with)
+    if order == "fp64":
+        return (q.astype(np.float64) @ xb.astype(np.float64).T).astype(np.float32)
+    prod = lambda kk: q[:, kk, None] * xb[None, :, kk]     # fp32 product, rounded (no FMA)
+    if order in ("ascending", "reversed"):
+        acc = np.zeros((B, N), np.float32)
+        for kk in (range(D) if order == "ascending" else range(D - 1, -1, -1)):
+            acc = acc + prod(kk)
+        return acc
+    if order.startswith("blocked"):                        # sgemm-like: K cut into blocks, a block summed sequentially, block sums added in order
+        w = int(order[7:])
+        acc = np.zeros((B, N), np.float32)
+        for k0 in range(0, D, w):
+            part = np.zeros((B, N), np.float32)
+            for kk in range(k0, min(D, k0 + w)):
+                part = part + prod(kk)
+            acc = acc + part
+        return acc
+    if order.startswith("lanes"):                          # SIMD scan: w lane accumulators (k mod w), reduced by a tree at the end
+        w = int(order[5:])
+        lanes = [np.zeros((B, N), np.float32) for _ in range(w)]
+        for kk in range(D):
+            lanes[kk % w] = lanes[kk % w] + prod(kk)
+        return _pairwise_sum(lanes)
+    if order == "pairwise":
+        return _pairwise_sum([prod(kk) for kk in range(D)])
+    raise ValueError(order)
+
+
+def top1_in_order(q, xb, order):
+    """argmax per query with the lowest-id tie rule, scores accumulated in ``order``."""
+    s = scores_in_order(q, xb, order)
+    return np.argmax(s, axis=1).astype(np.int64), s

@@ -25,7 +25,9 @@ def test_every_declared_symbol_is_exported_and_bound(hip_lib):
     for n in names:
         assert hasattr(raw, n), f"{n} declared in effocr_hip.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert hip_lib.effocr_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "effocr_hip.h")).read()
+    declared = int(re.search(r"#define\s+EFFOCR_ABI_VERSION\s+(\d+)", header).group(1))
+    assert hip_lib.effocr_abi_version() == declared == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("arch,img,D", [("vit_small_patch16_224", 224, 384), ("vit_base_patch16_224", 224, 768),
@@ -77,7 +79,9 @@ def test_knn_workspace_and_argument_checks(hip_lib):
     assert L.effocr_knn_workspace_bytes(64, 96, 512, 10) <= 512                 # single chunk: no partial lists
     assert L.effocr_knn_workspace_bytes(0, 100, 64, 1) == 0
     p = ctypes.c_void_p(16)
-    assert L.effocr_knn_ip_topk(p, 4, p, 10, 384, 33, p, p, p, 1 << 30, None) == -2     # k > 32
+    # k > 32: the exact search runs in passes of 32 columns (GPU tests); the screened entry point refuses and names the exact one
+    assert L.effocr_knn_ip_topk_screened(p, 4, p, p, 100000, 384, 33, ctypes.c_float(1.0), p, p, p, 1 << 40, None) == -2
+    assert b"exact multi-pass" in L.effocr_last_error()
     assert L.effocr_knn_ip_topk(p, 4, p, 10, 100, 5, p, p, p, 1 << 30, None) == -2      # d % 32 != 0
     assert L.effocr_knn_ip_topk(p, 4, p, 10, 384, 0, p, p, p, 1 << 30, None) == -1
     assert L.effocr_knn_ip_topk(p, 1024, p, 10000, 384, 10, p, p, p, 16, None) == -3    # workspace too small
@@ -98,7 +102,13 @@ def test_fast_path_operator_argument_checks(hip_lib):
     assert L.effocr_crop_transform(None, 10, 10, 30, p, 1, 224, 1, f3, f3, f3, p, None) == -1
     assert L.effocr_crop_transform(p, 10, 10, 30, p, 1, 224, 1, f3, z3, f3, p, None) == -1
     assert L.effocr_crop_transform(p, 10, 10, 30, p, 1, 30, 1, f3, f3, f3, p, None) == -2             # size % 4
-    assert L.effocr_crop_transform(p, 10, 10, 30, p, 70000, 224, 1, f3, f3, f3, p, None) == -2
+    # the batch form: image count / strides, NULLs, std == 0, size % 4
+    assert L.effocr_crop_transform_batch(p, 0, 300, 10, 10, 30, p, 1, 224, 1, f3, f3, f3, p, None) == -1
+    assert L.effocr_crop_transform_batch(p, 2, 299, 10, 10, 30, p, 1, 224, 1, f3, f3, f3, p, None) == -1     # image stride < rows * row stride
+    assert L.effocr_crop_transform_batch(p, 2, 300, 10, 10, 30, None, 1, 224, 1, f3, f3, f3, p, None) == -1
+    assert L.effocr_crop_transform_batch(p, 2, 300, 10, 10, 30, p, 1, 224, 1, f3, z3, f3, p, None) == -1
+    assert L.effocr_crop_transform_batch(p, 2, 300, 10, 10, 30, p, 1, 30, 1, f3, f3, f3, p, None) == -2
+    assert L.effocr_crop_transform_batch(p, 2, 300, 10, 10, 30, p, 0, 224, 1, f3, f3, f3, p, None) == 0
     assert L.effocr_crop_transform(p, 10, 10, 30, p, 0, 224, 1, f3, f3, f3, p, None) == 0
     # gemm3 / blocked LayerNorm
     assert L.effocr_op_linear_blocked(0, 0, p, p, p, None, p, 32, 128, 128, 32, None) == -2            # N % 192 / 256

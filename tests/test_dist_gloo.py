@@ -63,3 +63,50 @@ def test_single_process_passthrough():
     assert all_gather_rows(t, 4) is t
     d, i = ShardedRecognizer(lambda x: (x.float(), x))(t)
     assert torch.equal(i, t)
+
+
+def _pipeline_worker(rank, world, port, n_lines, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from effocr_amd.dist import ShardedPipeline
+        lines = [np.full((4, 8, 3), i, np.uint8) if i % 3 else f"/data/line_{i}.png" for i in range(n_lines)]
+        calls = []
+
+        def run_fn(images):                        # stands in for run_effocr on this rank's GPU: text = f(pixel) / f(path)
+            calls.append(len(images))
+            res = {}
+            for j, im in enumerate(images):
+                res[im if isinstance(im, str) else j] = f"<{im}>" if isinstance(im, str) else f"text{int(im[0, 0, 0])}"
+            return res, None
+
+        merged = ShardedPipeline(run_fn)(lines)
+        assert sum(calls) <= (n_lines + world - 1) // world
+        with open(os.path.join(out_dir, f"m{rank}.json"), "w") as f:
+            json.dump({str(k): v for k, v in merged.items()}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_lines", [8, 5, 1])
+def test_sharded_pipeline_world_size_2(tmp_path, n_lines):
+    """BASELINE configs[4], N > 1: line images sharded over ranks, ONE all-gather of the transcriptions; every rank ends with
+    every line's text under the right key (paths for paths, global positions for in-memory arrays), ragged and 1-line cases."""
+    import json
+    world, port = 2, _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, n_lines, str(tmp_path)), nprocs=world, join=True)
+    want = {}
+    for i in range(n_lines):
+        if i % 3:
+            want[str(i)] = f"text{i}"
+        else:
+            want[f"/data/line_{i}.png"] = f"</data/line_{i}.png>"
+    for r in range(world):
+        assert json.load(open(tmp_path / f"m{r}.json")) == want
+
+
+def test_sharded_pipeline_single_process():
+    from effocr_amd.dist import ShardedPipeline
+    out = ShardedPipeline(lambda ims: ({j: f"t{int(im[0, 0, 0])}" for j, im in enumerate(ims)}, None))([np.full((1, 1, 3), 7, np.uint8)])
+    assert out == {0: "t7"}

@@ -204,3 +204,45 @@ def test_full_size_config4_encoder_properties(dev):
     e0 = enc.forward(x, normalize=True)
     enc.set_option("cls_only_last", 1)
     assert rel_err(e0.cpu(), e1.cpu()) <= 1e-5 and rel_err(e0[sel].cpu(), ref) <= REL["bf16"]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+def test_embedding_does_not_depend_on_the_call_size(dev, prec):
+    """Kernel SELECTION depends on the call size (head split of the fused qkv+attention kernel for < a round of CUs of images,
+    hidden-dimension split of the fused MLP's partially filled round, split-K of the deep resnet convolutions), never the
+    arithmetic per crop except for the fp32 summation ORDER of split partial sums.  The same 6 crops alone, inside a
+    64-crop call (the ONNX driver's size) and inside a 300-crop call: embeddings agree to the bound below (identical kernels
+    -> usually bit-identical; a reordered fp32 sum can flip one 16-bit operand rounding), top-1 against a 2 000-row index identical."""
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import IndexFlatIP
+    arch = "vit_small_patch16_224"
+    sd = init_state_dict(arch, seed=3, img_size=224)
+    enc = HipEncoder(arch, sd, precision=prec, device=dev)
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(300, 3, 224, 224, generator=g, device=dev)
+    big = enc.forward(x, normalize=True)
+    mid = enc.forward(x[:64].contiguous(), normalize=True)
+    small = enc.forward(x[:6].contiguous(), normalize=True)
+    bound = {"fp32": 2e-6, "fp16": 5e-4, "bf16": 4e-3}[prec]
+    e1, e2 = rel_err(mid[:6].cpu(), small.cpu()), rel_err(big[:64].cpu(), mid.cpu())
+    print(f"{arch} {prec}: 6 vs 64 crops {e1:.2e}, 64 vs 300 crops {e2:.2e}")
+    assert e1 <= bound and e2 <= bound
+    idx = IndexFlatIP(384, device=dev)
+    idx.add(torch.nn.functional.normalize(torch.randn(2000, 384, generator=torch.Generator().manual_seed(1)), dim=1))
+    assert torch.equal(idx.search_device(big[:64], 1)[1], idx.search_device(mid, 1)[1])
+
+
+def test_resnet_and_localizer_do_not_depend_on_the_call_size(dev):
+    """resnet18 (split-K convolutions for launches of few tiles) and the YOLOv5s localizer at 1 vs 16 images per call: exact-fp32
+    MFMA operands either way, only the order of the split partial sums moves: <= 2e-6 relative."""
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.localizer_engine import HipLocalizer, init_yolov5s_state_dict
+    sd = init_state_dict("resnet18", seed=3, img_size=32)
+    enc = HipEncoder("resnet18", sd, img_size=32, precision="fp32", device=dev)
+    x = torch.randn(1024, 3, 32, 32, generator=torch.Generator(device=dev).manual_seed(2), device=dev)
+    big, small = enc.forward(x), enc.forward(x[:64].contiguous())
+    assert rel_err(big[:64].cpu(), small.cpu()) <= 2e-6
+    loc = HipLocalizer(init_yolov5s_state_dict(2, seed=0), input_shape=(640, 640), device=dev)
+    im = torch.rand(16, 3, 640, 640, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    p16, p1 = loc.forward(im), loc.forward(im[:1].contiguous())
+    assert ((p16[:1] - p1).abs().max() / p1.abs().max()).item() <= 2e-6

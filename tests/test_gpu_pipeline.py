@@ -1,0 +1,144 @@
+"""-m gpu: the product-level ``run_effocr`` (effocr_amd/pipeline.py; infer_effocr_onnx_multi.py:227-397) — BASELINE configs[4]
+on one GPU at its own line size (4096 x 256) — against the CPU restatement of the whole driver (oracle/run_effocr_ref.py:
+yolo_ref -> box parsing -> crop_transform_ref -> encoders_ref -> flat_ip.c -> postprocess_ref)."""
+import numpy as np
+import pytest
+import torch
+
+from effocr_amd.knn import FaissKNN, IndexFlatIP
+from effocr_amd.localizer_engine import EffLocalizer, init_yolov5s_state_dict
+from effocr_amd.pipeline import run_effocr, word_end_indices
+from effocr_amd.recognizer_engine import EffRecognizer
+from effocr_amd.transforms import PairedTransform
+from effocr_amd.weights import init_state_dict
+from oracle import run_effocr_ref as R
+
+pytestmark = pytest.mark.gpu
+
+CHARS = list("aenrwuosvcxzTHEQUICKBROWN-") + [chr(0x4E00 + i) for i in range(200)]
+
+
+def _busy(nc=2, seed=0, obj=5.5, cls=(2.5, 2.4)):        # ~50 character boxes and a few word boxes per 4096 x 256 line at conf 0.5
+    sd = init_yolov5s_state_dict(nc, seed=seed)
+    for l in range(3):
+        b = sd[f"model.24.m.{l}.bias"].view(3, nc + 5)
+        b[:, 4] += obj
+        b[:, 5] += cls[0]
+        b[:, 6] += cls[1]
+    return sd
+
+
+def _lines(n, H, W, seed):
+    rng = np.random.default_rng(seed)
+    return [(rng.integers(0, 256, (H, W, 3)) // 32 * 32).astype(np.uint8) for _ in range(n)]
+
+
+def _setup(dev, arch="vit_small_patch16_224", size=224, precision="fp32", conf=0.5, iou=0.05, seed=0):
+    loc_sd = _busy(2, seed=seed)
+    loc = EffLocalizer(loc_sd, iou_thresh=iou, conf_thresh=conf, device=dev)
+    enc_sd = init_state_dict(arch, seed=1, img_size=size)
+    rec = EffRecognizer(enc_sd, arch=arch, precision=precision, img_size=size, device=dev)
+    tf = PairedTransform(size=size, device=dev)
+    return loc_sd, loc, enc_sd, rec, tf
+
+
+def _match_boxes(got, ref, tol=0.05):
+    """Device localizer vs the CPU oracle: the networks differ by fp32 summation order, so compare as sets with a tolerance."""
+    assert abs(got.shape[0] - ref.shape[0]) <= max(2, ref.shape[0] // 50), (got.shape, ref.shape)
+    matched = 0
+    for r in ref:
+        d = (got[:, :4] - r[:4]).abs().max(1)[0] + (got[:, 5] != r[5]).float() * 1e3
+        matched += int(d.min().item() < tol)
+    assert matched >= ref.shape[0] - max(2, ref.shape[0] // 50)
+
+
+@pytest.mark.parametrize("lang", ["en", "jp"])
+def test_run_effocr_c5_lines_against_the_oracle_chain(dev, lang):
+    """Three 4096 x 256 line images (BASELINE configs[4]) through the product function and through the CPU driver restatement.
+    Stage 1 (localizer): box sets agree within 0.05 px (set comparison: a box on a threshold may differ).  Stages 2-5 (box parsing,
+    scaling / double clipping / numpy-slice semantics, crop transform, encoder (fp32 mode), k-NN, line assembly, en_postprocess):
+    fed with the device localizer's own boxes, the oracle must produce the SAME strings, character for character.  The index is
+    built from the oracle's embeddings of these very crops plus distractors, so every top-1 has a margin."""
+    loc_sd, loc, enc_sd, rec, tf = _setup(dev, seed=2)
+    lines = _lines(3, 256, 4096, seed=11)
+    dev_results = loc.run(lines)                                            # CPU tensors [n,6] per line
+    ora_results = R.localize(lines[:1], loc_sd, 0.5, 0.05)
+    _match_boxes(dev_results[0], ora_results[0])
+    n_char = [int((r[:, 5] == 0).sum()) for r in dev_results]
+    assert all(5 <= n <= 400 for n in n_char), n_char
+    # the oracle's embeddings of the crops the reference would cut -> glyph index (self-retrieval + distractors)
+    crops = []
+    for im, res in zip(lines, dev_results):
+        cb = sorted(res[res[:, 5] == 0][:, :4], key=lambda x: x[0])
+        for bb in cb:
+            x0, _, x1, _ = torch.round(bb)
+            x0, x1 = int(round(x0.item() * 4096 / 640)), int(round(x1.item() * 4096 / 640))
+            c = im[0:256, x0:x1, :]
+            crops.append(c if c.shape[1] > 0 else None)
+    keep = [c for c in crops if c is not None][:48]
+    from oracle.crop_transform_ref import paired_transform
+    from oracle.encoders_ref import encoder_forward, l2_normalize
+    xs = torch.stack([torch.from_numpy(np.asarray(paired_transform(c, size=224), dtype=np.float32)) for c in keep])
+    emb = l2_normalize(encoder_forward("vit_small_patch16_224", enc_sd, xs)).numpy()
+    rng = np.random.default_rng(5)
+    distract = rng.standard_normal((len(CHARS) - emb.shape[0], emb.shape[1])).astype(np.float32)
+    distract /= np.linalg.norm(distract, axis=1, keepdims=True)
+    index = np.concatenate([emb, distract]).astype(np.float32)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.train(torch.from_numpy(index))
+    got, coco = run_effocr(lines, loc, rec, tf, lang, knn_func=knn, candidate_chars=CHARS, anchor_margin=0.15 if lang == "en" else None)
+    assert coco == {"info": {"": ""}, "licenses": [{"": ""}], "images": [], "annotations": [], "categories": [{"id": 0, "name": "char"}]}
+    want, _ = R.run_effocr_ref(lines, loc_sd, "vit_small_patch16_224", enc_sd, index, CHARS, lang, localizer_results=dev_results,
+                               anchor_margin=0.15 if lang == "en" else None)
+    assert list(got.keys()) == [0, 1, 2]
+    for i in range(3):
+        assert got[i] == want[i], (i, got[i], want[i])
+    assert sum(len(w) for w in want if w) >= 15                             # the lines really carry text
+    # second call, other dtype path (bf16 encoder): same strings here because every top-1 is a self-retrieval with a wide margin
+    rec16 = EffRecognizer(enc_sd, arch="vit_small_patch16_224", precision="bf16", device=dev)
+    got16, _ = run_effocr(lines, loc, rec16, tf, lang, knn_func=knn, candidate_chars=CHARS, anchor_margin=0.15 if lang == "en" else None)
+    assert got16 == got
+
+
+def test_run_effocr_edge_cases(dev, tmp_path):
+    """Mixed geometries (grouped), a path entry, a line without any box (en -> None as en_postprocess returns, jp -> ""),
+    vertical text, the empty list, argument errors."""
+    from PIL import Image
+    loc_sd, loc, enc_sd, rec, tf = _setup(dev, arch="resnet18", size=32, precision="fp32", seed=3)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    g = torch.Generator().manual_seed(0)
+    index = torch.nn.functional.normalize(torch.randn(len(CHARS), 512, generator=g), dim=1)
+    knn.train(index)
+    lines = _lines(2, 64, 640, seed=1) + _lines(1, 48, 400, seed=2)
+    png = tmp_path / "l.png"
+    Image.fromarray(lines[2]).save(png)
+    mixed = [lines[0], str(png), lines[1]]
+    got, _ = run_effocr(mixed, loc, rec, tf, "jp", knn_func=knn, candidate_chars=CHARS)
+    want, _ = R.run_effocr_ref([lines[0], lines[2], lines[1]], loc_sd, "resnet18", enc_sd, index.numpy(), CHARS, "jp",
+                               localizer_results=loc.run([lines[0], lines[2], lines[1]]), size=32)
+    assert list(got.keys()) == [0, str(png), 2]
+    assert [got[0], got[str(png)], got[2]] == want
+    # vertical: sorted by y0, crops span the full width
+    gotv, _ = run_effocr(lines[:2], loc, rec, tf, "jp", vertical=True, knn_func=knn, candidate_chars=CHARS)
+    wantv, _ = R.run_effocr_ref(lines[:2], loc_sd, "resnet18", enc_sd, index.numpy(), CHARS, "jp", vertical=True,
+                                localizer_results=loc.run(lines[:2]), size=32)
+    assert [gotv[0], gotv[1]] == wantv
+    # no detections at all
+    quiet = EffLocalizer(init_yolov5s_state_dict(2, seed=0), iou_thresh=0.05, conf_thresh=0.99, device=dev)
+    g0, _ = run_effocr(lines[:1], quiet, rec, tf, "en", knn_func=knn, candidate_chars=CHARS)
+    g1, _ = run_effocr(lines[:1], quiet, rec, tf, "jp", knn_func=knn, candidate_chars=CHARS)
+    assert g0 == {0: None} and g1 == {0: ""}
+    assert run_effocr([], loc, rec, tf, "en", knn_func=knn, candidate_chars=CHARS)[0] == {}
+    with pytest.raises(ValueError):
+        run_effocr(lines[:1], loc, rec, tf, "fr", knn_func=knn, candidate_chars=CHARS)
+    with pytest.raises(NotImplementedError):
+        run_effocr(lines[:1], loc, rec, tf, "en", localizer_output=str(tmp_path), knn_func=knn, candidate_chars=CHARS)
+
+
+def test_word_end_indices_keeps_the_reference_quirks():
+    # word lefts 5 and 100: first word -> char whose right edge (10) is the closest one right of 5; second word has no candidate
+    # right of 100 -> repeats the previous index (closest_idx is not reset, infer_effocr_onnx_multi.py:75-87)
+    assert word_end_indices([10.0, 20.0, 30.0], [5.0, 100.0]) == [0, 0]
+    assert word_end_indices([10.0, 20.0, 30.0], [15.0, 25.0]) == [1, 2]
+    assert R.en_preprocess([torch.tensor([0., 0, 10, 5]), torch.tensor([12., 0, 20, 5]), torch.tensor([22., 0, 30, 5])],
+                           [torch.tensor([15., 0, 40, 5]), torch.tensor([25., 0, 40, 5])])[1] == [1, 2]
