@@ -99,7 +99,6 @@ def _declare(lib):
         "effocr_op_mlp_blocked": (i32, [i32, f32p, f32p, f32p, c.c_float, vp, f32p, vp, f32p, f32p, i32, i32, i32, i32, vp, sz, vp]),
         "effocr_op_mlp_ln_blocked": (i32, [i32, f32p, f32p, f32p, c.c_float, vp, f32p, vp, f32p, f32p, f32p, f32p, vp, i32, i32, i32, i32, vp, sz, vp]),
         "effocr_op_proj_mlp_blocked": (i32, [i32, f32p, vp, vp, f32p, f32p, f32p, c.c_float, vp, f32p, vp, f32p, f32p, i32, i32, i32, i32, vp, sz, vp]),
-        "effocr_op_rowlin_blocked": (i32, [i32, i32, f32p, vp, f32p, f32p, c.c_float, vp, f32p, vp, i32, i32, i32, i32, vp]),
         "effocr_op_qkv_attn_blocked": (i32, [i32, vp, vp, f32p, vp, i32, i32, i32, i32, vp]),
         "effocr_op_layernorm_blocked": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
     }

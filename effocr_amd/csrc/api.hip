@@ -5,9 +5,6 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
 
 #include <math.h>
 #include <string.h>
@@ -63,7 +60,7 @@ struct effocr_encoder {
   // ViT
   VitCfg vit{};
   int T = 0, P = 0;
-  size_t off_clspos0 = 0, off_pos = 0, off_patchb = 0, off_normw = 0, off_normb = 0, off_patchw = 0;
+  size_t off_clspos0 = 0, off_pos = 0, off_patchb = 0, off_normw = 0, off_normb = 0, off_patchw = 0, off_patchw_b = 0;   // _b: fragment-blocked copy (patch.hip)
   std::vector<VitLayerOff> layers;
   // resnet18
   std::vector<ConvSpec> convs;      // conv1, then per block conv1, conv2, (downsample)
@@ -72,13 +69,13 @@ struct effocr_encoder {
   // optional HIP-event profiler (effocr_encoder_profile_*): one event pair per launch of the
   // selected kernel classes, recorded on the forward's own stream
   int debug = 0;
-  int use_rowlin = 0;               // 1: register-resident-input kernels (rowlin.hip) for LN1+qkv and proj+residual instead of the row-panel ones (measured 7 % slower: A/B switch)
   int cls_only_last = 1;            // last block: attn.proj + MLP only on the class-token rows (the only rows that reach the output); 0: all tokens (A/B switch)
   int mlp_stagger = 3500;           // fused MLP: start spread of the first round of workgroups, clock ticks per step of 32 (0 = off; applies from 4 rounds of CUs on)
   int use_projf = 1;                // 1: attn.proj + residual fused in front of the fused MLP kernel (the new row stays in the accumulators: -0.9 ms and -0.6 GB of HBM traffic per forward vs the separate row-panel launch); 0: A/B switch
   int use_qkvattn = 1;              // fused norm1 + attn.qkv + attention kernel (qkvattn.hip): no qkv tensor in HBM (0: A/B switch)
   int qa_min_batch = 1;             // fused qkv+attention from this many crops per call on (below: the token-panel LN+qkv kernel + attention kernel)
   int qa_hsplit = 0;                // qkvattn head split: 0 = launcher's choice (small batches: several workgroups per image), 1 = never, n = at most n
+  int use_patchf = 1;               // fused im2col + patch-embed GEMM (patch.hip) on the blocked path (0: im2col kernel + gemm2, A/B switch)
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
@@ -164,6 +161,7 @@ void build_vit(effocr_encoder* e) {
     L.fc2w = a.take((size_t)D * mlp * es);
   }
   if (e->prec != PREC_FP32) {
+    e->off_patchw_b = a.take((size_t)D * 768 * es);
     for (int i = 0; i < depth; ++i) {
       VitLayerOff& L = e->layers[i];
       L.fc2w_b = a.take((size_t)D * mlp * es);
@@ -279,6 +277,7 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
   put_f32(blob, e->off_pos, pos.data(), pos.size());
   put_f32(blob, e->off_patchb, P(e, "patch_embed.proj.bias").data(), D);
   put_op(blob, e->off_patchw, P(e, "patch_embed.proj.weight").data(), (size_t)D * 768, e->prec);
+  if (e->prec != PREC_FP32 && D % 32 == 0) put_op_blocked(blob, e->off_patchw_b, P(e, "patch_embed.proj.weight").data(), D, 768, e->prec);
   for (int i = 0; i < e->vit.depth; ++i) {
     const std::string p = "blocks." + std::to_string(i) + ".";
     const VitLayerOff& L = e->layers[i];
@@ -402,35 +401,33 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool g3all = !panel && e->use_gemm3 && gemm3_supported(prec, 3 * D, D) && gemm3_supported(prec, D, D) &&
                      gemm3_supported(prec, e->vit.mlp, D) && gemm3_supported(prec, D, e->vit.mlp);
   const int blk = (e->use_blocked && g2p && ((panel && g2) || g3all)) ? 1 : 0;
-  const bool rl = blk && panel && e->use_rowlin && rowlin_supported(prec, D, 3 * D) && rowlin_supported(prec, D, D);
   const bool mlpf = blk && panel && e->use_mlp && mlp_fused_supported(prec, D, e->vit.mlp);
-  const bool projf = mlpf && !rl && e->use_projf;
+  const bool projf = mlpf && e->use_projf;
   // one image per workgroup at a time: worth it from ~3/4 of a round of CUs on; small batches (the reference's 64-crop calls)
   // keep the token-panel kernels, which spread 64 x 197 tokens over every CU.  use_qkvattn = 2 forces it (tests).
-  const bool qaf = blk && panel && !rl && mlpf && qkv_attn_supported(prec, D, T) && (e->use_qkvattn == 2 || (e->use_qkvattn == 1 && B >= e->qa_min_batch));
+  const bool qaf = blk && panel && mlpf && qkv_attn_supported(prec, D, T) && (e->use_qkvattn == 2 || (e->use_qkvattn == 1 && B >= e->qa_min_batch));
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
-  if ((rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
+  const bool patchf = blk && e->use_patchf && patch_embed_fused_supported(prec, D);
+  if (!patchf && (rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
   if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
   GemmArgs g{};
+  if (patchf) {                                          // pixels -> tokens in one kernel: the patch rows never exist in HBM
+    PatchArgs pa{};
+    pa.x = x; pa.B = B; pa.H = e->img; pa.W = e->img; pa.Wb = wb + e->off_patchw_b; pa.bias = F(e->off_patchb); pa.pos = F(e->off_pos);
+    pa.out = xs; pa.D = D; pa.P = Pn;
+    if ((rc = timed(e, "patch_embed_fused", 2.0 * B * Pn * Dd * 768.0, s, [&] { return patch_embed_fused(prec, pa, s); }))) return rc;
+  } else {
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);
   g.out = xs; g.ldo = D; g.pos = F(e->off_pos); g.M = B * Pn; g.N = D; g.K = 768; g.P = Pn; g.blk_out = blk;
   if ((rc = timed(e, "gemm_patch_embed", 2.0 * B * Pn * Dd * 768.0, s, [&] { return g2p ? gemm2_nt(prec, EPI_PATCH, g, s) : gemm_nt(prec, EPI_PATCH, g, s); }))) return rc;
+  }
   const float* cls_x = nullptr;                        // compact class-token rows after the last block (cls_only_last)
   bool xn_ready = false;                               // xn holds norm1(x) of the coming block (written by the previous block's MLP epilogue)
   for (int i = 0; i < e->vit.depth; ++i) {
     const VitLayerOff& L = e->layers[i];
     if (panel) {
       // row-panel kernels: LayerNorm fused into the A-panel load, no xn buffer, no LayerNorm launches
-      if (rl) {
-        RowLinArgs q{};
-        q.x = xs; q.gamma = F(L.ln1w); q.beta = F(L.ln1b); q.eps = 1e-6f; q.Wb = wb + L.qkvw_b; q.bias = F(L.qkvb); q.out = qkv;
-        q.M = M; q.D = D; q.N = 3 * D; q.rows_alloc = (int)w.rows;
-        if ((rc = timed(e, "rowlin_ln_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return rowlin(prec, ROWLIN_LN, q, s); }))) return rc;
-        if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, blk, s); }))) return rc;
-        q = RowLinArgs{};
-        q.x = xs; q.A = att; q.Wb = wb + L.projw_b; q.bias = F(L.projb); q.M = M; q.D = D; q.N = D; q.rows_alloc = (int)w.rows;
-        if ((rc = timed(e, "rowlin_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return rowlin(prec, ROWLIN_RESID, q, s); }))) return rc;
-      } else {
+      {
       PanelArgs p{};
       if (qaf) {                                         // qkv + attention in one kernel, one image per workgroup at a time
         if (!xn_ready && (rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
@@ -735,10 +732,10 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "use_qkvattn") { enc->use_qkvattn = value; return EFFOCR_OK; }
   if (n == "qa_min_batch") { enc->qa_min_batch = value; return EFFOCR_OK; }
   if (n == "qa_hsplit") { enc->qa_hsplit = value; return EFFOCR_OK; }
+  if (n == "use_patchf") { enc->use_patchf = value; return EFFOCR_OK; }
   if (n == "use_projf") { enc->use_projf = value; return EFFOCR_OK; }
   if (n == "cls_only_last") { enc->cls_only_last = value; return EFFOCR_OK; }
   if (n == "mlp_stagger") { enc->mlp_stagger = value < 0 ? 0 : value; return EFFOCR_OK; }
-  if (n == "use_rowlin") { enc->use_rowlin = value; return EFFOCR_OK; }
   if (n == "panel_rows") { if (value != 64 && value != 128) return fail(EFFOCR_EINVAL, "set_option: panel_rows must be 64 or 128"); enc->panel_rows = value; return EFFOCR_OK; }
   if (n == "chunk") { if (value < 0) return fail(EFFOCR_EINVAL, "set_option: chunk < 0"); enc->chunk = value; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, "set_option: unknown option '" + n + "'");
@@ -900,17 +897,6 @@ int effocr_op_ln_linear(int precision, int epilogue, const float* x_dev, const f
   return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
 }
 
-#if EFFOCR_EXP != 0
-// experiment hook: LN-fused linear with an in-kernel timeline buffer (2 x 512 x 4 u64, device)
-int effocr_dbg_ln_linear(int precision, int epilogue, const float* x_dev, const float* gamma_dev, const float* beta_dev,
-                         const void* w_dev, const float* bias_dev, void* out_dev, int m, int n, int k, int debug,
-                         unsigned long long* dbg_dev, void* stream) {
-  PanelArgs p{};
-  p.A = x_dev; p.lda = k; p.gamma = gamma_dev; p.beta = beta_dev; p.eps = 1e-6f; p.W = w_dev; p.bias = bias_dev;
-  p.out = out_dev; p.ldo = n; p.M = m; p.N = n; p.K = k; p.debug = debug & 0xff; p.panel_rows = (debug >> 8) & 0xff; p.dbg = dbg_dev;
-  return panel_gemm(precision, PRO_LN, epilogue, p, S(stream));
-}
-#endif   // experiment builds only (make EXP=n): not part of the shipped ABI
 
 int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev, const void* w_blk_dev, const float* bias_dev,
                              const float* resid_blk_dev, void* out_blk_dev, int m, int n, int k, int rows_alloc, void* stream) {
@@ -960,18 +946,6 @@ int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_bl
   a.b2_logical = b2_dev; a.A = a_blk_dev; a.Wpp = wp_perm_dev; a.bp = bp_perm_dev;
   a.M = m; a.D = d; a.H = h; a.rows_alloc = rows_alloc; a.partial = static_cast<float*>(scratch_dev); a.partial_bytes = scratch_bytes;
   return mlp_fused(precision, a, S(stream));
-}
-
-int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const void* a_blk_dev, const float* gamma_dev,
-                             const float* beta_dev, float eps, const void* w_blk_dev, const float* bias_dev, void* out_blk_dev,
-                             int m, int d, int n, int rows_alloc, void* stream) {
-  if (mode != ROWLIN_LN && mode != ROWLIN_RESID) return fail(EFFOCR_EINVAL, "op_rowlin_blocked: mode must be 0 (LN + linear) or 1 (linear + residual)");
-  if (m > 0 && (!x_blk_dev || !w_blk_dev || !bias_dev || (mode == ROWLIN_LN && (!gamma_dev || !beta_dev || !out_blk_dev)) || (mode == ROWLIN_RESID && !a_blk_dev)))
-    return fail(EFFOCR_EINVAL, "op_rowlin_blocked: NULL device pointer");
-  RowLinArgs q{};
-  q.x = x_blk_dev; q.A = a_blk_dev; q.gamma = gamma_dev; q.beta = beta_dev; q.eps = eps; q.Wb = w_blk_dev; q.bias = bias_dev; q.out = out_blk_dev;
-  q.M = m; q.D = d; q.N = n; q.rows_alloc = rows_alloc;
-  return rowlin(precision, mode, q, S(stream));
 }
 
 int effocr_op_qkv_attn_blocked(int precision, const void* xn_blk_dev, const void* wqkv_blk_dev, const float* bias_dev,

@@ -18,9 +18,6 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
 
 namespace effocr {
 namespace {
@@ -55,9 +52,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
     if (piece < 32) {
       int m = m0 + row;
       m = m < g.M ? m : g.M - 1;
-#if EFFOCR_EXP == 13
-      m = m & 1023;                      // experiment: X rows from a 3 MB window (L2 / MALL resident)
-#endif
       if (g.blk_x) { src[i] = Xb + blk_off(m, ch, (int)(g.ldx / 8)); sinc[i] = 8 * 512; }
       else { src[i] = Xb + ((size_t)m * g.ldx) * sizeof(E) + ch * 16; sinc[i] = 128; }
     } else {
@@ -160,18 +154,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-#if EFFOCR_EXP == 11
-          acc[i][j][c4] += (float)cw[i][0] * (float)cx[j][0];
-#else
           acc[i][j] = Op16<E>::mfma(cw[i], cx[j], acc[i][j]);
-#endif
         }
     }
   }
 
-#if EFFOCR_EXP == 12
-  if (acc[0][0][0] != 12345.f) return;     // experiment: no epilogue traffic
-#endif
   // ---- epilogue (every load was issued in fetch_epilogue, before the first store: out may alias resid)
   TO* out = static_cast<TO*>(g.out);
   if constexpr (kAdd) {

@@ -19,16 +19,6 @@
 #include "kernels.hpp"
 #include <type_traits>
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
-// timing experiments (never shipped): -DEFFOCR_EXP=1000+bits; 1 no epilogue, 2 no MFMA, 4 no DMA after the prologue,
-// 8 X from an L2-resident window, 16 no barrier, 32 no vmcnt wait, 64 no fragment reads
-#if EFFOCR_EXP >= 1000
-#define G3X (EFFOCR_EXP - 1000)
-#else
-#define G3X 0
-#endif
 
 namespace effocr {
 namespace {
@@ -62,12 +52,6 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   const int kch = g.K >> 3;                                            // 16-byte chunks per operand row
   const int last_rb = (g.rows_alloc >> 5) - 1;                         // last addressable X row block
 
-#if EFFOCR_EXP >= 26 && EFFOCR_EXP <= 28
-  // experiment: stagger half of the first round's workgroups by ~(EXP-25)/4 of a tile
-  if (JT == 4 && blockIdx.x < 256 && (blockIdx.x & 8)) {
-    for (int i = 0; i < (EFFOCR_EXP - 25) * 3; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   // per-lane DMA sources; piece q (1 KB = two adjacent 16-B chunk cells of one 32-row block) lands at q KB
   const char* src[PP];
 #pragma unroll
@@ -76,9 +60,6 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
     if (q < PX) {
       int rb = (m0 >> 5) + (q >> 1);
       rb = rb < last_rb ? rb : last_rb;                                // rows past the buffer: any valid block
-#if (G3X & 8)
-      rb &= 31;                                                        // experiment: X from a 3 MB window (L2 resident)
-#endif
       src[i] = static_cast<const char*>(g.X) + ((size_t)rb * kch + 2 * (q & 1)) * 512 + lane * 16;
     } else {
       const int qq = q - PX;
@@ -129,9 +110,6 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   // fragment n of a k16 step: n < NT -> W tile n, else token tile n - NT
   auto load_one = [&](Frags& f, const char* st, int c4, auto N_) {
     constexpr int n = decltype(N_)::value;
-#if (G3X & 64)
-    if (st == nullptr)
-#endif
     if constexpr (n < NT) f.w[n] = *reinterpret_cast<const V8*>(st + wo + (n * 4 + 2 * c4) * 512);
     else f.x[n - NT] = *reinterpret_cast<const V8*>(st + xo + ((n - NT) * 4 + 2 * c4) * 512);
   };
@@ -141,11 +119,7 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
     static_for<0, NMM>([&](auto N_) {
       constexpr int n = decltype(N_)::value;
       constexpr int i = n / JT, j = n % JT;
-#if (G3X & 2)
-      acc[i][j][n & 15] += (float)f.w[i][0] * (float)f.x[j][0];
-#else
       acc[i][j] = Op16<E>::mfma(f.w[i], f.x[j], acc[i][j]);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       between(N_);
       __builtin_amdgcn_sched_barrier(0);
@@ -174,21 +148,15 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
     });
     // stage s+1 landed (own pieces; s+2, s+3 may stay in flight), every wave holds its stage-s fragments
     // in registers -> past the barrier slot s&3 is free for stage s+4
-#if !(G3X & 32)
     if constexpr (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !(G3X & 16)
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
     // k16 step 1; in its shadow: DMA of stage s+4 and the fragments of stage s+1, step 0
     mma_step(fb, [&](auto N_) {
       constexpr int n = decltype(N_)::value;
-#if !(G3X & 4)
       if constexpr (more && n < PP) issue_piece_asm(s + 4, n);
-#endif
       if constexpr (next && n < NF) load_one(fa, stn, 0, N_);
     });
   };
@@ -199,9 +167,6 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
     stage(s, std::false_type{}, std::false_type{});
   }
 
-#if (G3X & 1)
-  if (acc[0][0][0] != 12345.f) return;
-#endif
   // ---- epilogue: lane = token (m0 + (wm*JT + j)*32 + r31), 4 consecutive features per (i, q)
   TO* out = static_cast<TO*>(g.out);
   constexpr int CH = 16 / (int)sizeof(TO);                             // elements per 16-byte output chunk
@@ -283,9 +248,6 @@ int launch3(int epi, const GemmArgs& g, hipStream_t s) {
   int tail_wgs = (mtiles - main_mt) * ntn;
   if (tail_wgs * 2 > slots) { main_mt = mtiles; tail_wgs = 0; }            // tail already fills most CUs
   int rc = EFFOCR_OK;
-#if EFFOCR_EXP == 29
-  return launch3_tile<E, NT, 2>(epi, g, s);               // experiment: 128-token tiles, two workgroups per CU
-#endif
   if (main_mt > 0) {
     GemmArgs m = g;
     m.M = main_mt * 256 < g.M ? main_mt * 256 : g.M;

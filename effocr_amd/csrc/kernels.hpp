@@ -75,19 +75,16 @@ struct QkvAttnArgs {
 bool qkv_attn_supported(int prec, int D, int T);
 int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s);
 
-// rowlin.hip — LN + linear (16-bit out) / linear + residual over the blocked layout, input fragments in registers
-enum { ROWLIN_LN = 0, ROWLIN_RESID = 1 };
-struct RowLinArgs {
-  float* x;                         // ROWLIN_LN: fp32 blocked input of the LayerNorm; ROWLIN_RESID: fp32 blocked residual, updated in place
-  const void* A;                    // ROWLIN_RESID: 16-bit blocked input [M, D]
-  const float* gamma; const float* beta; float eps;
-  const void* Wb; const float* bias;   // weight [N, D] fragment-blocked, bias [N]
-  void* out;                        // ROWLIN_LN: 16-bit blocked output [M, N]
-  int M, D, N;
-  int rows_alloc;                   // rows addressable in x / A / out: a multiple of 128 >= M (padding rows are written)
+// patch.hip — fused im2col + patch-embedding GEMM (+ bias + pos_embed) straight from the NCHW fp32 crops into the blocked residual stream
+struct PatchArgs {
+  const float* x; int B, H, W;      // crops [B,3,H,W] fp32 (H, W multiples of 16)
+  const void* Wb;                   // patch_embed.proj.weight [D, 768] fragment-blocked (16-bit), k = (c, py, px)
+  const float* bias; const float* pos;   // [D]; pos_embed rows [1 + P, D] fp32
+  float* out;                       // fp32 residual stream, fragment-blocked: row img * (P + 1) + 1 + p
+  int D, P;                         // embed dim, patches per image
 };
-bool rowlin_supported(int prec, int D, int N);
-int rowlin(int prec, int mode, const RowLinArgs& a, hipStream_t s);
+bool patch_embed_fused_supported(int prec, int D);
+int patch_embed_fused(int prec, const PatchArgs& a, hipStream_t s);
 
 // panel.hip — row-panel GEMM with optional fused LayerNorm prologue (K = embed dim)
 enum { PRO_COPY = 0, PRO_LN = 1 };

@@ -3,8 +3,3 @@
 namespace effocr {
 int mlp_launch_bf16p(const MlpArgs& a, hipStream_t s) { return launch_mlp<__bf16, true>(a, s); }
 }  // namespace effocr
-#if (MLX & 1024)
-extern "C" int effocr_exp_mlp_timeline(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(effocr::mlp_timeline), (size_t)n * 8);
-}
-#endif

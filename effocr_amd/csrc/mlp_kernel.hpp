@@ -30,20 +30,8 @@
 #include "kernels.hpp"
 #include <type_traits>
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
 #ifndef MLP_BARRIER_DRAIN
 #define MLP_BARRIER_DRAIN 0
-#endif
-// timing experiments (never shipped): -DEFFOCR_EXP=2000+bits; 1 no epilogue, 2 no x loads, 4 no GELU, 8 no DMA after
-// the prologue, 16 no barrier, 32 no MFMA, 64 no fragment reads in the loop, 128 (unused),
-// 256 no stores of the second output, 512 second output skipped altogether, 4096 weight stream from 128 KB only (L2-hot),
-// 1024 s_memtime stamps of wave 0 per panel (effocr_exp_mlp_timeline in mlp_bf16p.hip, tools/mlp_timeline.py)
-#if (EFFOCR_EXP >= 2000 && EFFOCR_EXP < 3000) || (EFFOCR_EXP >= 4000 && EFFOCR_EXP < 12000)
-#define MLX (EFFOCR_EXP - 2000)
-#else
-#define MLX 0
 #endif
 
 namespace effocr {
@@ -56,14 +44,6 @@ template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) 
   }
 }
 
-#if (MLX & 1024)
-__device__ unsigned long long mlp_timeline[2049 * 16];   // [panel][stamp] (experiments only); the last row is a dump for the other lanes
-// branch-free (a branch between the phases splits the basic blocks and makes the compiler spill hundreds of registers)
-#define MLP_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-    mlp_timeline[((threadIdx.x == 0 && blockIdx.x < 2048) ? (int)blockIdx.x : 2048) * 16 + (i)] = t_; } while (0)
-#else
-#define MLP_STAMP(i) do {} while (0)
-#endif
 
 constexpr int MLP_PT = 128;                              // tokens per workgroup
 constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
@@ -116,7 +96,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((bid >> 3) & 31) * a.stagger);
     while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
   }
-  MLP_STAMP(0);
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
   const int panel = (PARTIAL ? a.panel0 : 0) + bid / SPLIT;
   const int c0 = (bid % SPLIT) * NCW;        // first hidden chunk of this workgroup
@@ -173,11 +152,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   } else {
 #pragma unroll
     for (int t = 0; t < NXF; ++t) {
-#if (MLX & 2)
-      const f32x4 cst = {1.f + t, 2.f, 3.f * half, 4.f};
-      xv[2 * t] = cst; xv[2 * t + 1] = cst;
-      if (a.M < 0)
-#endif
       {
       xv[2 * t] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half) * 512);
       xv[2 * t + 1] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half + 1) * 512);
@@ -265,7 +239,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     }
   }
   __syncthreads();                                       // parameters visible
-  MLP_STAMP(1);
 
   if constexpr (PARTIAL && !PROJ) {
 #pragma unroll
@@ -359,9 +332,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #if MLP_BARRIER_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind this barrier is stage s-1's, whose fragment
 #endif                                                  // reads were all consumed by MFMAs before stage s began; the reads in flight here are stage s's
-#if !(MLX & 16)
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
   };
   WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
@@ -408,11 +379,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
   // is one basic block (a scalar branch between two MFMAs is a bubble with one wave per SIMD; see gemm3.hip).
   auto ring_stage = [&](auto REM, auto&& mfma1, auto NOPF) __attribute__((always_inline)) {   // NOPF: do not prefetch stage s+1's first fragments
-#if (MLX & 8)
-    constexpr bool more = false, next = decltype(REM)::value >= 1 && !decltype(NOPF)::value;
-#else
     constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1 && !decltype(NOPF)::value;
-#endif
     const char* st = sW + (s & (R - 1)) * MLP_STAGE;
     const char* stn = sW + ((s + 1) & (R - 1)) * MLP_STAGE;
     // ONE fragment set, refilled in a rolling fashion: right after MFMA (c4, i) has consumed wf.w[i], the same
@@ -420,11 +387,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     sfor<0, 4>([&](auto C4) {
       constexpr int c4 = decltype(C4)::value;
       if constexpr (c4 == 2) {
-#if (MLX & 8)
-        stage_mid(std::false_type{});
-#else
         stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
-#endif
       }
       sfor<0, 4>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -448,11 +411,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
-#if (MLX & 32)
-        acc1[i][c4] += (float)wfrag[0] * (float)xf[ks * 4 + c4][1];
-#else
         acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
-#endif
         if constexpr (nu > 0) {
           static_assert(NMM % nu == 0, "mlp: GELU units must divide the phase's MFMAs");
           constexpr int n = ks * 16 + c4 * 4 + i;        // MFMA index within the phase: unit n / SPU, slice n % SPU of it
@@ -478,11 +437,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
         const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
-#if (MLX & 32)
-        acc2[4 * g + i][c4] += (float)wfrag[0] * (float)hb[1];
-#else
         acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
-#endif
         if constexpr (nu > 0) {
           constexpr int n = sb * 16 + c4 * 4 + i;
           constexpr int k = (n * nu) / NMM;
@@ -511,7 +466,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         }, std::integral_constant<bool, (g == OG - 1 && ks == SA - 1)>{});   // nothing of the ring held in registers across the LayerNorm
       });
     });
-    MLP_STAMP(2);
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
@@ -521,14 +475,12 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += bv[e];
       }
     });
-    MLP_STAMP(3);
     layernorm_to_xf();
     load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)                          // (not before: the 64 registers are free for the compiler up to here)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
-    MLP_STAMP(4);
     if constexpr (PARTIAL) {                             // straight-line (a branch over 192 accumulators makes the compiler spill them)
       const float kf = c0 == 0 ? 1.f : 0.f;
 #pragma unroll
@@ -547,24 +499,18 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   HSet S;
   phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
   park(S, 0);
-  MLP_STAMP(5);
 #pragma unroll 1
   for (int c = 1; c < NC - 1; ++c) {
     phase_a(Far{}, &S, U0_{}, U16_{});                    // A(c) + gelu(c-1)
     phase_b(Far{}, S, nullptr, U0_{}, U0_{});             // B(c-1)
     park(S, c);
   }
-  MLP_STAMP(6);
   phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
   phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
   park(S, NC - 1);
   sfor<0, 8>([&](auto Q) { gelu_unit(S, Q); });
   phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
-  MLP_STAMP(7);
 
-#if (MLX & 1)
-  if (acc2[0][0] != 12345.f && acc2[OT - 1][3] != 54321.f) return;
-#endif
   // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row (W2's
   // rows are permuted per 32: api.hip rowperm32).  Whole panels: acc2 already holds x + bias2 + fc2 — nothing is re-read.
   int hf = half;
@@ -594,7 +540,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
       }
     });
-    if (a.xn_out && !(MLX & 512)) {
+    if (a.xn_out) {
       // ---- second output.  The lane pair (r31, half 0 / 1) holds the whole new row: two-pass statistics (one cross-half
       // exchange each) and the next block's norm1 applied on the way out, rounded to the operand type (same arithmetic as
       // layernorm_blocked_kernel).  Registers 8p..8p+7 of tile t = 16-bit chunk 4t + 2p + half: one 16-byte store.
@@ -623,15 +569,11 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
                              (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
           }
           const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
-#if (MLX & 256)
-          if (mean == 12345.f)
-#endif
           *reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512) = o;
         }
       });
     }
   }
-  MLP_STAMP(8);
 }
 
 // One launch for the whole panels (workgroups [0, main_wgs)) AND the split parts of the tail panels (TNCW hidden chunks each; TNCW = 0:

@@ -33,9 +33,6 @@
 #include "ln.hpp"
 #include <type_traits>
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0     // compile-time ablation switches for timing experiments (0 = product)
-#endif
 
 namespace effocr {
 namespace {
@@ -136,11 +133,6 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wsrc[i]),
                                        (__attribute__((address_space(3))) void*)(dst + (wv * 2 + i) * 1024), 16, 0, 0);
   };
-#if EFFOCR_EXP == 9
-  const bool stamp = (a.dbg != nullptr) && (blockIdx.x == 300 || blockIdx.x == 1300) && lane == 0 && (wv == 0 || wv == 5);
-  unsigned long long* dbgw = a.dbg + ((blockIdx.x == 300 ? 0 : 2) + (wv == 0 ? 0 : 1)) * 2048;
-  if (stamp) dbgw[2040] = __builtin_amdgcn_s_memtime();
-#endif
   issue_w(0, 0);
   issue_w(1, 1);
   for (int n = tid; n < niter * PNT; n += NT) sBias[n] = a.bias[nlo + n];
@@ -230,13 +222,7 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
       *reinterpret_cast<u32x4*>(sA + row * APITCH + c * 16) = v[i];
     }
   }
-#if EFFOCR_EXP == 9
-  if (stamp) dbgw[2041] = __builtin_amdgcn_s_memtime();
-#endif
   __syncthreads();                                       // panel visible; also drains stages 0,1 (prologue only)
-#if EFFOCR_EXP == 9
-  if (stamp) dbgw[2042] = __builtin_amdgcn_s_memtime();
-#endif
   issue_w(2, 2);
 
   constexpr bool DEFER = (EPI != EPI_BIAS_RESID);        // residual loads would stall the W stream: see below
@@ -296,9 +282,6 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
   };
   auto store_group = [&](int g, int n0, u32x2 v) {
     TO* p = group_ptr(g, n0);
-#if EFFOCR_EXP == 5
-    if (v[0] != 0x12345678u) return;
-#endif
     if constexpr (FULL) *reinterpret_cast<u32x2*>(p) = v;
     else if (mok[g >> 2]) *reinterpret_cast<u32x2*>(p) = v;
   };
@@ -360,31 +343,16 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
     constexpr int ks = decltype(KS)::value;
     constexpr bool with_epi = decltype(WITH_EPI)::value;
     constexpr int extra = (FULL && DEFER && with_epi) ? stores_at(ks - 1) + stores_at(ks - 2) : 0;
-#if EFFOCR_EXP == 9
-    if (stamp) dbgw[s * 4 + 0] = __builtin_amdgcn_s_memtime();
-#endif
     if (s + 2 >= S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (extra > 0 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + extra) : "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-#if EFFOCR_EXP == 9
-    if (stamp) dbgw[s * 4 + 1] = __builtin_amdgcn_s_memtime();
-#endif
-#if EFFOCR_EXP != 3
     __builtin_amdgcn_s_barrier();
-#endif
-#if EFFOCR_EXP == 9
-    if (stamp) dbgw[s * 4 + 2] = __builtin_amdgcn_s_memtime();
-#endif
     asm volatile("" ::: "memory");
-#if EFFOCR_EXP != 4
     issue_w(s + 3, slot);
-#endif
     const int nslot = (slot + 1 == RING) ? 0 : slot + 1;
     WFrags& cur = (ks & 1) ? wb : wa;
     WFrags& nxt = (ks & 1) ? wa : wb;
-#if EFFOCR_EXP != 1
     load_w(nxt, nslot);                                  // stage s+1 (garbage after the last stage: never consumed)
-#endif
     // MFMA n of the stage = (k16 step c4 = n>>1, token tile j = n&1); token fragments ping-pong between
     // x0 (even steps) and x1 (odd steps), each fetched while the other one is being consumed
     auto mma1 = [&](int n) {
@@ -484,9 +452,6 @@ __global__ __launch_bounds__(Geo<BMT>::THREADS, 2) void panel_gemm_kernel(PanelA
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     }
   }
-#if EFFOCR_EXP == 9
-  if (stamp) dbgw[2043] = __builtin_amdgcn_s_memtime();
-#endif
 }
 
 

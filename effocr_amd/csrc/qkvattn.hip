@@ -39,18 +39,8 @@
 #include <math.h>
 #include <type_traits>
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
 #ifndef QA_BARRIER_DRAIN
 #define QA_BARRIER_DRAIN 0
-#endif
-// timing experiments (never shipped): -DEFFOCR_EXP=3000+bits; 1 no attention, 2 no projection MFMAs, 4 no x loads,
-// 8 no stage barrier, 16 no output stores, 32 no accumulator -> fragment conversion, 128 no weight DMA, 256 no weight fragment reads
-#if EFFOCR_EXP >= 3000 && EFFOCR_EXP < 4000
-#define QAX (EFFOCR_EXP - 3000)
-#else
-#define QAX 0
 #endif
 
 namespace effocr {
@@ -63,12 +53,6 @@ template <int I, int N, typename F> __device__ __forceinline__ void qa_for(F&& f
   }
 }
 
-#if (QAX & 64)
-__device__ unsigned long long qa_timeline[1024 * 32];    // [workgroup][stamp]: s_memtime of wave 0 (experiments only)
-#define QA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) qa_timeline[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define QA_STAMP(i) do {} while (0)
-#endif
 
 constexpr int QA_STAGE = 16384;                          // bytes per ring stage: 2 row blocks x 16 k-chunks x 512 B
 constexpr int QA_RING = 6;
@@ -133,9 +117,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     const __attribute__((address_space(1))) void* src =
         (const __attribute__((address_space(1))) void*)(Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8) * 512 + lane16);
     __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(sW + islot * QA_STAGE + ((w >> 1) * 16 + (w & 1) * 8) * 512);
-#if (QAX & 128)
-    if (a.T < 0)
-#endif
     switch (p) {
       case 0: __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0); break;
       case 1: __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0); break;
@@ -184,10 +165,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         const char* xb = static_cast<const char*>(a.xn) + (tok >> 5) * (int64_t)KC * 512 + (tok & 31) * 16 + half * 512;   // + compile-time offsets only
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
-#if (QAX & 4)
-          xf[tt][i] = V8{(E)(1.f + i), (E)2.f, (E)(3.f * half), (E)4.f, (E)0.f, (E)1.f, (E)0.5f, (E)0.25f};
-          if (a.T < 0)
-#endif
           xf[tt][i] = *reinterpret_cast<const V8*>(xb + i * 1024);
         }
       }
@@ -242,16 +219,10 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
 #if QA_BARRIER_DRAIN
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind the barrier is stage g-1's, fully consumed
 #endif
-#if !(QAX & 8)
               __builtin_amdgcn_s_barrier();
-#endif
               asm volatile("" ::: "memory");
             }
             V8 n0, n1;
-#if (QAX & 256)
-            n0 = f0; n1 = f1;
-            if (a.T < 0)
-#endif
             if constexpr (ks < 7) {
               n0 = *reinterpret_cast<const V8*>(st + (2 * (ks + 1)) * 512);
               n1 = *reinterpret_cast<const V8*>(st + (16 + 2 * (ks + 1)) * 512);
@@ -259,9 +230,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               n0 = *reinterpret_cast<const V8*>(stn);
               n1 = *reinterpret_cast<const V8*>(stn + 16 * 512);
             }
-#if (QAX & 2)
-            if (a.T < 0)
-#endif
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
               if constexpr (CLS && sec == 0) {           // q only where the class token lives
@@ -320,18 +288,15 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         }
       });
       if constexpr (PRE) load_frags(img_next);           // the fragments are dead from here on: the loads land under the attention
-      QA_STAMP(1 + 3 * hi);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // K and V of every tile are in LDS
       asm volatile("" ::: "memory");
-      QA_STAMP(2 + 3 * hi);
 
       // ---- attention of the wave's query tiles against all keys of the image.  K / V fragments are requested one
       // step ahead by hand (with one wave per SIMD nothing else hides the LDS latency; left to itself the compiler
       // either serialises read -> wait -> MFMA or hoists every read and spills)
       const char* kb = sK + lane * 16;
       const char* vb = sV + lane * 16;
-#if !(QAX & 1)
       qa_for<0, (CLS ? 1 : NT)>([&](auto TT_) {
         constexpr int tt = decltype(TT_)::value;
         if constexpr (CLS) { if (w != 0) return; }       // (wave-uniform; the other waves go on to the next head's weight stream)
@@ -420,7 +385,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         });
         const float l = lsum[0];
-#if !(QAX & 16)
         if (tq < T) {
           const float inv = 1.0f / l;
           // The v rows of the weight copy are permuted per 32 (api.hip rowperm32): registers 8p..8p+7 of dim tile db are the 8
@@ -436,14 +400,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               *reinterpret_cast<u32x4*>(ob + blk_off(tok0 + tq, h * 8 + db * 4 + 2 * p + half, D / 8)) = v;
             }
         }
-#else
-        if (l == 12345.f && o[0][0] == 1.f && o[1][3] == 2.f) *reinterpret_cast<float*>(a.out) = l;
-#endif
       });
-#else
-      if (qf[0][0][0] == (E)12345.f && qf[NA - 1][3][1] == (E)7.f) *reinterpret_cast<float*>(a.out) = 1.f;
-#endif
-      QA_STAMP(3 + 3 * hi);
     };
 
     __syncthreads();                                     // parameters visible before the ring starts filling
@@ -462,7 +419,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       const int img = slot0 + ii * nslots;
       tok0 = (int64_t)img * T;
       refresh_lane();
-      QA_STAMP(0);
 #pragma unroll 1
       for (int i = 0; i < NH - 1; ++i) {
         const int h = hb + (h0 + i < NH ? h0 + i : h0 + i - NH);
@@ -520,10 +476,5 @@ int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s) {
   return prec == PREC_BF16 ? launch_qkvattn<__bf16>(a, s) : launch_qkvattn<_Float16>(a, s);
 }
 
-#if (QAX & 64)
-extern "C" int effocr_exp_qa_timeline(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qa_timeline), (size_t)n * 8);
-}
-#endif
 
 }  // namespace effocr

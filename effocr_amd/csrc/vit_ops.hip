@@ -7,9 +7,6 @@
 #include "ln.hpp"
 #include <math.h>
 
-#ifndef EFFOCR_EXP
-#define EFFOCR_EXP 0
-#endif
 
 namespace effocr {
 namespace {
@@ -270,21 +267,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
     }
   };
 
-#if EFFOCR_EXP >= 34 && EFFOCR_EXP <= 37
-  // experiment: put the second resident workgroup of every CU half a period out of phase, once
-  if (blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < EFFOCR_EXP - 33; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   V8 qf[4], qn[4];
   if (w * 32 < T) load_q(qf, w);                            // oldest in the VM queue: ready when the staging is
-#if EFFOCR_EXP != 32
   load_kv();
   store_kv();
-#endif
   __syncthreads();
-#if EFFOCR_EXP == 31
-  if (T > 0) return;                                       // experiment: staging only
-#endif
 
   const float cexp = 0.125f * 1.44269504088896340736f;     // head_dim^-0.5 * log2(e)
   for (int qb = w; qb * 32 < T; qb += 4) {

@@ -106,7 +106,6 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *   "mlp_stagger" [3500] fused MLP kernel: the first round of workgroups starts spread over 32 x this many clock ticks, so
  *                 that the CUs do not request / store their rows all at the same moment (0 = off; used from 4 rounds of CUs on)
  *   "use_projf"   [1] attn.proj + residual fused in front of the fused MLP kernel (0: its own row-panel launch)
- *   "use_rowlin"  [0] register-resident-input kernels for LN1+qkv and proj+residual
  *   "panel_rows"  [128] row-panel height, 64 or 128;  "chunk" (= set_chunk);  "debug" (experiment hooks) */
 int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value);
 
@@ -293,14 +292,6 @@ int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_bl
                                const void* w2_perm_dev, const float* b2_perm_dev, const float* b2_dev, int m, int d, int h, int rows_alloc,
                                void* scratch_dev, size_t scratch_bytes, void* stream);
 
-/* The two embed-dim linears of a block on the blocked layout (timm Block: norm1 + attn.qkv; attn.proj + residual):
- *   mode 0: out_blk (16-bit [m,n]) = LayerNorm(x_blk fp32 [m,d]) . w^T + bias
- *   mode 1: x_blk (fp32 [m,d], in/out) += a_blk (16-bit [m,d]) . w^T + bias          (n == d)
- * w_blk [n,d] 16-bit fragment-blocked.  (d, n) in {(384,1152), (384,384), (128,384), (128,128)}.  rows_alloc is a
- * multiple of 128 >= m: the padding rows of the last 128-row panel are written (garbage), never read. */
-int effocr_op_rowlin_blocked(int precision, int mode, float* x_blk_dev, const void* a_blk_dev, const float* gamma_dev,
-                             const float* beta_dev, float eps, const void* w_blk_dev, const float* bias_dev, void* out_blk_dev,
-                             int m, int d, int n, int rows_alloc, void* stream);
 /* attn.qkv + multi-head self-attention of one timm Block in ONE kernel, one image per workgroup at a time (timm
  * Attention.forward up to, not including, attn.proj; models/encoders.py:58,63):
  *   out_blk (16-bit [batch*tokens, d] blocked, feature = head*64 + dim) = softmax(q k^T / 8) v,

@@ -123,11 +123,6 @@ def test_fast_path_operator_argument_checks(hip_lib):
     assert L.effocr_op_mlp_blocked(0, None, p, p, 1e-6, p, p, p, p, p, 32, 384, 1536, 32, None, 0, None) == -1
     assert L.effocr_op_mlp_blocked(0, p, p, p, 1e-6, p, p, p, p, p, 0, 384, 1536, 0, None, 0, None) == 0
     assert L.effocr_op_proj_mlp_blocked(0, p, None, p, p, p, p, 1e-6, p, p, p, p, p, 32, 384, 1536, 32, None, 0, None) == -1
-    assert L.effocr_op_rowlin_blocked(0, 3, p, p, p, p, 1e-6, p, p, p, 32, 384, 1152, 128, None) == -1     # unknown mode
-    assert L.effocr_op_rowlin_blocked(0, 1, p, p, None, None, 0.0, p, p, None, 32, 384, 1152, 128, None) == -1   # residual mode needs n == d
-    assert L.effocr_op_rowlin_blocked(0, 0, p, None, p, p, 1e-6, p, p, p, 32, 384, 1152, 96, None) == -1   # rows_alloc % 128
-    assert L.effocr_op_rowlin_blocked(0, 0, p, None, p, p, 1e-6, p, p, p, 32, 256, 768, 128, None) == -2
-    assert b"rowlin" in L.effocr_last_error()
 
 
 def test_screened_knn_argument_checks(hip_lib):

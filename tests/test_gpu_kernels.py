@@ -275,47 +275,6 @@ def test_mlp_fused_blocked(hip_lib, dev, prec, shape, scratch):
         assert torch.equal(from_blocked(xd.cpu(), ra, D, ra)[M:], torch.zeros(ra - M, D))
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("mode", ["ln", "resid"])
-@pytest.mark.parametrize("shape", [(197 * 5, 384, 1152), (197 * 5, 384, 384), (100, 128, 384), (1, 128, 128), (40000, 384, 1152), (40000, 384, 384)])
-def test_rowlin_blocked(hip_lib, dev, prec, mode, shape):
-    """rowlin.hip: LN + linear -> 16-bit out (mode 0) and linear + residual in place (mode 1), inputs as register fragments."""
-    M, D, N = shape
-    if mode == "resid" and N != D:
-        pytest.skip("residual mode needs N == D")
-    g = torch.Generator().manual_seed(M + D + N)
-    w = (torch.randn(N, D, generator=g) / math.sqrt(D)).to(TDT[prec])
-    bias = 0.5 * torch.randn(N, generator=g)
-    ra = (M + 127) // 128 * 128
-    wd, bd = to_blocked(w, N).to(dev), bias.to(dev)
-    if mode == "ln":
-        x = torch.randn(M, D, generator=g) * 2 + 0.3 * torch.randn(M, 1, generator=g)
-        gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
-        xd, gd, btd = to_blocked(x, ra).to(dev), gamma.to(dev), beta.to(dev)
-        out = torch.zeros(ra * N, dtype=TDT[prec], device=dev)
-        _lib.check(hip_lib.effocr_op_rowlin_blocked(_lib.PREC[prec], 0, _lib.ptr(xd), None, _lib.ptr(gd), _lib.ptr(btd), 1e-6, _lib.ptr(wd),
-                                                    _lib.ptr(bd), _lib.ptr(out), M, D, N, ra, _stream(dev)), "op_rowlin_blocked")
-        torch.cuda.synchronize()
-        got = from_blocked(out.cpu(), M, N, ra).double()
-        xn = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6).to(TDT[prec]).double()
-        ref = xn @ w.double().T + bias.double()
-        tol = {"bf16": 8e-3, "fp16": 1e-3}[prec]
-        scale = ref.abs().max().item()
-    else:
-        x = torch.randn(M, D, generator=g)
-        av = torch.randn(M, D, generator=g).to(TDT[prec])
-        xd, ad = to_blocked(x, ra).to(dev), to_blocked(av, ra).to(dev)
-        _lib.check(hip_lib.effocr_op_rowlin_blocked(_lib.PREC[prec], 1, _lib.ptr(xd), _lib.ptr(ad), None, None, 0.0, _lib.ptr(wd),
-                                                    _lib.ptr(bd), None, M, D, N, ra, _stream(dev)), "op_rowlin_blocked")
-        torch.cuda.synchronize()
-        got = from_blocked(xd.cpu(), M, D, ra).double()
-        delta = av.double() @ w.double().T + bias.double()
-        ref = x.double() + delta
-        tol, scale = 2e-5, ref.abs().max().item()
-    err = (got - ref).abs().max().item()
-    assert err <= tol * scale, f"{prec} {mode} {shape}: err {err:.3e} scale {scale:.3e}"
-
-
 def perm32_rows(t):
     """P32 of include/effocr_hip.h along dim 0: position p of every block of 32 holds source index
     8*(2*(r>>3) + hh) + (r&7), hh = (p>>2)&1, r = (p&3) + 4*(p>>3)."""

@@ -8,14 +8,14 @@ FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of a wide co
 import json, os, re, sqlite3, sys
 
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
-    ("qkvattn_kernel", "qkv_attn_fused"), ("knn_stream_kernel", "knn_stream"), ("knn_rerank", "knn_rerank"), ("knn_prep", "knn_prep"),
+    ("qkvattn_kernel", "qkv_attn_fused"), ("patch_embed_kernel", "patch_embed_fused"), ("knn_stream_kernel", "knn_stream"), ("knn_rerank", "knn_rerank"), ("knn_prep", "knn_prep"),
     ("layernorm_blocked_kernel", "layernorm_blocked"), ("conv_igemm", "conv_igemm"),
     # mlp_fused_kernel<E, D, H, TNCW, PROJ>: whole panels + the split parts of the tail panels (TNCW chunks each) in one launch
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "proj_mlp_main"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb0", "mlp_fused_main"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb0", "mlp_fused_main"),
     ("mlp_reduce_kernel", "mlp_fused_reduce"), ("gather_cls", "gather_cls"),
-    ("rowlin_kernel", "rowlin"), ("layernorm_blocked", "layernorm_blocked"),
+    ("layernorm_blocked", "layernorm_blocked"),
     ("panel_gemm_kernelIDF16bLi384ELi1ELi1", "panel_ln_fc1_gelu"), ("panel_gemm_kernelIDF16bLi384ELi1ELi0", "panel_ln_qkv"),
     ("panel_gemm_kernelIDF16bLi384ELi0ELi2", "panel_proj_resid"), ("gemm3_kernelIDF16bLi3ELi4ELi2", "gemm_fc2_resid"),
     ("gemm3_kernel<", "gemm_fc2_resid_tail"), ("gemm2_kernelIDF16bLi2", "gemm_fc2_resid"),
@@ -69,7 +69,7 @@ def main(tag):
         f.write(f"# rocprofv3 --kernel-trace --pmc <set> (one pass per set, no other trace domain), per-dispatch averages, tag {tag}\n")
         f.write("# SQ_* cycle counters are quad-cycles summed over waves/SEs; SQ_VALU_MFMA_BUSY_CYCLES = 32 x N_mfma; FETCH/WRITE_SIZE in KB\n")
         for k, d in sorted(allc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-            if not any(s in k for s in ("panel", "gemm", "attention", "knn", "mlp", "rowlin", "qkv", "layernorm")):
+            if not any(s in k for s in ("panel", "gemm", "attention", "knn", "mlp", "qkv", "layernorm")):
                 continue
             f.write(f"\n[{k}]\n")
             for c in ctrs:
