@@ -566,9 +566,11 @@ def c5_extras(a, dev):
     nl = 16
     lines = [(rng.integers(0, 256, (256, 4096, 3)) // 32 * 32).astype(np.uint8) for _ in range(nl)]
 
-    def call():
+    dev_lines = [torch.from_numpy(im).to(dev) for im in lines]
+
+    def call(inp=None):
         t0 = time.perf_counter()
-        res, _ = run_effocr(lines, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=64)
+        res, _ = run_effocr(lines if inp is None else inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=64)
         return time.perf_counter() - t0, res
 
     def loc_only():
@@ -583,6 +585,12 @@ def c5_extras(a, dev):
     tl = sorted(loc_only() for _ in range(7))
     t, tlm = ts[len(ts) // 2], tl[len(tl) // 2]
     nb = sum(len(v) for v in res.values()) / nl
+    call(dev_lines)
+    td = sorted(call(dev_lines)[0] for _ in range(7))[3]           # line images already in HBM (uint8): no PCIe leg
+    loc._eng_net.set_option("bf16_operands", 1)                    # + the bf16-operand localizer convolutions (EffLocalizer(precision="bf16"))
+    call(dev_lines)
+    td16 = sorted(call(dev_lines)[0] for _ in range(7))[3]
+    loc._eng_net.set_option("bf16_operands", 0)
     # the localizer network alone, batched, device-resident input
     x = torch.rand(16, 3, 640, 640, device=dev)
     tn = _time_gpu(lambda: loc._eng_net.forward(x), dev, 5)
@@ -595,6 +603,7 @@ def c5_extras(a, dev):
                         f"-> {a.index_rows}-row IndexFlatIP, k=1 -> strings; host uint8 images in, strings out (PCIe-inclusive); seeded random weights",
             "lines_per_s": round(nl / t, 2), "ms_per_call_median_of_7": round(1e3 * t, 3), "ms_per_call_min": round(1e3 * ts[0], 3),
             "chars_per_line": round(nb, 1),
+            "lines_per_s_images_resident_in_hbm": round(nl / td, 2), "lines_per_s_images_resident_bf16_localizer": round(nl / td16, 2),
             "localizer_ms_per_line": round(1e3 * tlm / nl, 3), "rest_ms_per_line": round(1e3 * (t - tlm) / nl, 3),
             "localizer_network_images_per_s_batch16": round(16 / tn, 1), "localizer_network_ms_per_image": round(1e3 * tn / 16, 3),
             "localizer_GFLOP_per_image": round(fl / 1e9, 2), "localizer_mfma_fp32_frac": round(16 * fl / tn / 157.3e12, 4),

@@ -33,6 +33,7 @@ using namespace tile128;
 
 int g_knn_wg_target = 1024;          // workgroups a launch aims for (2 resident per CU); knn_set_option("wg_target")
 bool g_knn_force_tile = false;        // A/B switch (tests): 1 = always the 128-query tile kernel
+bool g_knn_two_pass = false;          // A/B switch (tests): 1 = screened search collects its candidates with a second scan of the index
 constexpr int ID_NONE = INT_MAX;          // internal sentinel id (ranks after every real id)
 constexpr int MAX_CHUNKS = 256;
 
@@ -391,6 +392,35 @@ __global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restri
   }
 }
 
+// Candidates straight from pass 1's per-chunk lists (no second scan of the index).  Every chunk list holds the chunk's KMAX best
+// approximate scores; a true top-k row r has s^_r >= tau = s^_(k) - 2 eps, so r is in its chunk's list unless KMAX rows of that chunk
+// score at least s^_r >= tau — in which case the list's LAST entry is >= tau: that raises the overflow flag and the gated exact
+// pass recomputes everything.  Otherwise the union of the list entries >= tau contains every true top-k row: same guarantee as the
+// second scan, for the price of reading nchunks x KMAX x 8 bytes per query.  One wave per query, lanes over chunks.
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_collect_lists_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx, int B, int nchunks,
+                                                                int k, const float* __restrict__ adist, const float* __restrict__ qnorm,
+                                                                float eps_scale, int* __restrict__ cand, int* __restrict__ cnt, int cap,
+                                                                int* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int qg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qg >= B) return;
+  const float tau = adist[(int64_t)qg * k + (k - 1)] - eps_scale * qnorm[qg];
+  bool over = false;
+  for (int c = lane; c < nchunks; c += 64) {
+    const int64_t base = ((int64_t)c * B + qg) * KMAX;
+    for (int t = 0; t < KMAX; ++t) {
+      const float sc = pdist[base + t];
+      const int id = pidx[base + t];
+      if (id == ID_NONE || !(sc >= tau)) break;            // lists are sorted: nothing further qualifies
+      const int pos = atomicAdd(cnt + qg, 1);
+      if (pos < cap) cand[(int64_t)qg * cap + pos] = id;
+      if (t == KMAX - 1) over = true;                     // the list is full of qualifying rows: the chunk may hold more
+    }
+  }
+  if (__any(over) && lane == 0) atomicOr(flag, 1);
+}
+
 // Exact re-rank of one query's candidates: score = the ascending-k fp32 fmaf chain (the product's definition, what the
 // fp32 MFMA kernel and oracle/flat_ip.c compute), order = (score desc, id asc).  One workgroup per query.
 constexpr int RR_CAP = 512;
@@ -720,7 +750,8 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
   // up to 128 queries against a large index: the streaming kernel (HBM / fp32-MFMA bound) in slices of 32 or 64 queries; same
   // chunking, same merge, same bits.  (Above that the 128-query tile kernel amortises the index traffic better.)
   const int sq = stream_queries(D, p.kmax);
-  if (B <= 2 * sq && N >= 4096 && D % 128 == 0 && D <= 768 && !g_knn_force_tile) {
+  // (33..128 queries pay off only where the index does not fit the caches: at 10 k rows the tile kernel is faster, measured)
+  if (B <= 2 * sq && N >= (B <= 32 ? 4096 : 65536) && D % 128 == 0 && D <= 768 && !g_knn_force_tile) {
     for (int64_t q0 = 0; q0 < B; q0 += sq) {
       KnnArgs b = a;
       b.B = (int)(B - q0 < sq ? B - q0 : sq);
@@ -755,6 +786,7 @@ size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   return screen_ws(B, N, D, k).total;
 }
 void knn_force_tile_kernel(int on) { g_knn_force_tile = on != 0; }
+void knn_two_pass_screen(int on) { g_knn_two_pass = on != 0; }
 void knn_set_wg_target(int n) { g_knn_wg_target = n < 1 ? 1 : n; }
 size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k) {
   if (B <= 0 || k <= 0) return 0;
@@ -802,6 +834,14 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   // 1e-4 relative slack for the fp32 norms.  A true top-k row has s >= s_(k), hence s^ >= s_(k) - eps >= s^_(k) - 2 eps.
   const float c = (0.00390625f + 0.0000152587890625f + 4.0f * (float)D * 5.9604645e-8f) * 1.0001f;
   a.adist = adist; a.qnorm = qnorm; a.eps_scale = 2.0f * c * xnorm_max; a.cand = cand; a.cnt = cnt; a.cap = RR_CAP;
+  if (p.nchunks > 1 && !g_knn_two_pass) {                  // the candidates are already in pass 1's per-chunk lists
+    const dim3 cg((unsigned)((B + 3) / 4));
+    switch (p.kmax) {
+      case 1: hipLaunchKernelGGL((knn_collect_lists_kernel<1>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+      case 16: hipLaunchKernelGGL((knn_collect_lists_kernel<16>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+      default: hipLaunchKernelGGL((knn_collect_lists_kernel<32>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+    }
+  } else
   switch (p.kmax) {
     case 1: hipLaunchKernelGGL((knn_partial_kernel<1, __bf16, true>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a); break;
     case 16: hipLaunchKernelGGL((knn_partial_kernel<16, __bf16, true>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a); break;

@@ -32,7 +32,6 @@ class IndexFlatIP:
     metric_type = 0          # faiss.METRIC_INNER_PRODUCT
     is_trained = True
 
-    SCREEN_MIN_QUERIES = 129  # ... and from this many queries per call on (below: the exact streaming kernel is faster, measured)
     SCREEN_MIN_ROWS = 65536   # from this size on `search` uses the screened entry point (bit-identical results, ~4x faster at 1M rows)
 
     def __init__(self, d, device="cuda:0", screen="auto"):
@@ -99,9 +98,13 @@ class IndexFlatIP:
             return False
         if self.screen is True:
             return True
-        # up to 128 queries (one text line: tens; the ONNX driver's calls: 64) the exact search streams the fp32 rows through the
-        # MFMA operands once or twice at the HBM / fp32-MFMA rate (knn.hip streaming kernel): faster than two bf16 screening passes
-        return self.ntotal >= self.SCREEN_MIN_ROWS and (nq is None or nq > self.SCREEN_MIN_QUERIES - 1)
+        # Measured (tools/knn_sweep.py, 1M rows): up to 64 queries at d <= 384 (32 above) ONE launch of the exact streaming kernel beats
+        # the screened search (0.72 vs 0.78 ms at 64 queries); beyond that screening wins (128 queries: 0.78 vs 1.42 ms; 1024: 3.2 vs 8.6 ms).
+        # Small indexes: the bf16 pass + re-rank pays only for large batches (10 k rows, 1024 queries: 0.135 vs 0.164 ms).
+        if nq is None:
+            return self.ntotal >= self.SCREEN_MIN_ROWS
+        stream_cap = 64 if self.d <= 384 else 32
+        return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512)
 
     def _screen_copy(self):
         if self._xb16 is None:

@@ -216,7 +216,40 @@ def word_end_indices(char_rights, word_lefts):
     return out
 
 
+_PINNED = {}          # (device, bytes rounded up) -> pinned uint8 staging buffer of run_effocr's uploads (grow-only, one per size class)
+
+
+def _upload_lines(imgs, dev):
+    """HWC uint8 images of ONE geometry (numpy, or uint8 tensors already on ``dev``) -> one [L,H,W,3] device tensor.  Host images
+    are copied line by line into a pinned staging buffer, each line's DMA issued right behind its memcpy (the copy of line i+1
+    runs under the transfer of line i); the buffer is reused by the next call only after this call's last transfer finished."""
+    if all(isinstance(im, torch.Tensor) for im in imgs):
+        return torch.stack([im.to(dev) for im in imgs]).contiguous()
+    L, shape = len(imgs), tuple(imgs[0].shape)
+    n = int(np.prod(shape))
+    key = (str(dev), 1 << max(20, (L * n - 1).bit_length()))
+    ent = _PINNED.get(key)
+    if ent is None:
+        ent = _PINNED[key] = [torch.empty(key[1], dtype=torch.uint8).pin_memory(), None]
+    if ent[1] is not None:
+        ent[1].synchronize()                                                  # previous call's transfers (normally long done)
+    stage = ent[0][: L * n].view((L,) + shape)
+    stage_np = stage.numpy()
+    out = torch.empty((L,) + shape, dtype=torch.uint8, device=dev)
+    for j, im in enumerate(imgs):
+        np.copyto(stage_np[j], im.cpu().numpy() if isinstance(im, torch.Tensor) else im)
+        out[j].copy_(stage[j], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ent[1] = ev
+    return out
+
+
 def _load_rgb(p):
+    if isinstance(p, torch.Tensor):
+        if p.dim() != 3 or p.shape[2] != 3 or p.dtype != torch.uint8:
+            raise ValueError("run_effocr takes image paths or HWC uint8 RGB arrays / tensors")
+        return p
     if isinstance(p, str):
         from PIL import Image
         return np.array(Image.open(p).convert("RGB"))                       # :311
@@ -257,7 +290,8 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     ``num_streams`` / ``conf_thres`` are accepted and unused (HIP streams are ordered by the device; ``conf_thres`` only feeds the
     detectron2 / mmdetection branches); ``localizer_output`` (debug drawings) raises NotImplementedError.  Results are keyed by
     the path (or by position for in-memory arrays) in INPUT order — the reference's order is thread-completion order.
-    Images of different sizes are processed in groups of one geometry."""
+    Images of different sizes are processed in groups of one geometry; HWC uint8 tensors already on the engines' device are
+    taken as they are (no upload)."""
     import copy
     from .postprocess import LinePostprocessor
     if lang not in ("en", "jp"):
@@ -276,13 +310,13 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     images = [_load_rgb(p) for p in coco_images]
     groups = {}
     for i, im in enumerate(images):
-        groups.setdefault(im.shape[:2], []).append(i)
+        groups.setdefault(tuple(im.shape[:2]), []).append(i)
     post = LinePostprocessor(lang=lang, vertical=vertical, anchor_margin=anchor_margin)
     # en_preprocess is called WITHOUT the vertical flag (:277: always sorts by x0); jp_preprocess gets it (:288)
     axis = 1 if (vertical and lang == "jp") else 0
     per_line = {}                                                            # line index -> (ids, sorted char boxes, word boxes)
     for (H, W), members in groups.items():
-        stack = torch.from_numpy(np.stack([images[i] for i in members])).to(dev, non_blocking=True)    # [L,H,W,3] uint8: the one upload
+        stack = _upload_lines([images[i] for i in members], dev)           # [L,H,W,3] uint8: the one upload (pinned staging, overlapped)
         L = len(members)
         rows, counts = localizer_engine.run_device([stack[j] for j in range(L)], max_det=max_det)
         valid = torch.arange(max_det, device=dev)[None, :] < counts[:, None]

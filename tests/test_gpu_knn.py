@@ -148,6 +148,14 @@ def test_screened_search_is_bit_identical(dev, N, D, B, k):
     assert torch.equal(Ie, Is)
     assert torch.equal(De.view(torch.int32), Ds.view(torch.int32))
     assert (Ie[:, 0] == pick).all()
+    # the default collects its candidates from pass 1's per-chunk lists; the second-scan variant (A/B switch) must agree bit for bit
+    L = _lib.lib()
+    _lib.check(L.effocr_knn_set_option(b"two_pass_screen", 1), "knn_set_option")
+    try:
+        _, _, D2, I2 = _both(dev, X, Q, k)
+    finally:
+        _lib.check(L.effocr_knn_set_option(b"two_pass_screen", 0), "knn_set_option")
+    assert torch.equal(I2, Is) and torch.equal(D2.view(torch.int32), Ds.view(torch.int32))
 
 
 def test_screened_search_non_unit_rows_ties_and_overflow(dev):
@@ -172,7 +180,7 @@ def test_screened_auto_threshold_and_invalidation(dev):
     assert not idx._use_screen(10)
     idx.add(torch.nn.functional.normalize(torch.randn(70_000, 128, device=dev), dim=1))
     assert idx._use_screen(10) and not idx._use_screen(33)
-    assert idx._use_screen(10, 129) and not idx._use_screen(10, 128)        # <= 128 queries: the exact streaming kernel, nothing to screen
+    assert idx._use_screen(10, 65) and not idx._use_screen(10, 64)          # <= 64 queries (d <= 384): one launch of the exact streaming kernel
     q = idx._xb[:140].clone()
     D1, I1 = idx.search_device(q, 5)
     assert idx._xb16 is not None and (I1[:, 0].cpu() == torch.arange(140)).all()
@@ -184,8 +192,9 @@ def test_screened_auto_threshold_and_invalidation(dev):
 
 
 @pytest.mark.parametrize("B,N,D,k", [(1, 5000, 384, 10), (16, 70001, 384, 10), (32, 4096, 512, 1), (7, 200000, 768, 32), (32, 33333, 128, 16), (5, 4100, 1024, 10),
-                                     (64, 70001, 384, 1), (33, 9000, 384, 10), (64, 50000, 384, 16), (100, 20000, 384, 10), (128, 8192, 256, 10),
-                                     (64, 30000, 768, 10), (40, 12000, 384, 32)])     # 33..128 queries: two query tiles per launch / slices of 32
+                                     (64, 70001, 384, 1), (33, 66000, 384, 10), (64, 70000, 384, 16), (100, 66001, 384, 10), (128, 65536, 256, 10),
+                                     (64, 66000, 768, 10), (40, 70000, 384, 32), (100, 20000, 384, 10)])
+                                     # 33..128 queries against >= 65 536 rows: two query tiles per launch / slices of 32 (below: the tile kernel)
 def test_streaming_kernel_small_batches_bit_exact(hip_lib, dev, B, N, D, k):
     """<= 128 queries against >= 4096 rows run the streaming kernel (index rows straight into MFMA operands at the HBM rate):
     scores and ids bit-identical to the C oracle AND to the 128-query tile kernel (A/B switch), incl. planted exact ties."""
