@@ -418,7 +418,9 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
           constexpr int SPU = NMM / nu;
           // The whole unit behind ONE MFMA.  (Spread over the unit's 12 MFMA gaps in steps of 4-8 VALU instructions — same
           // arithmetic, no bursts — the launch was 1-2 % SLOWER, same-box A/B: the compiler scalarises most of the packed FMAs
-          // once the chains are cut by scheduling barriers, and pinning them as register pairs costs an s_nop per asm boundary.)
+          // once the chains are cut by scheduling barriers, and pinning them as register pairs costs an s_nop per asm boundary.
+          // Also measured and dropped: phase B in (k half, group) order with the first 4 units of the NEXT chunk parked under its
+          // second k half — 7.25 -> 7.55 ms per 1024 crops, the longer live ranges cost more than the overlap wins.)
           if constexpr (n % SPU == 0) {
             __builtin_amdgcn_sched_barrier(0);
             gelu_unit(*gs, std::integral_constant<int, u0 + n / SPU>{});

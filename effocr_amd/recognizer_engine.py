@@ -12,6 +12,7 @@ Here ``model`` is the path of the encoder weights (``enc_best.pth`` state dict w
 """
 import queue
 import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -57,6 +58,10 @@ class EffRecognizer:
         self._lanes = queue.SimpleQueue()
         for _ in range(max(1, int(lanes))):
             self._lanes.put(_Lane(self._eng_net.device))
+        # the pageable -> pinned staging copy is the slowest leg of a call (38.5 MB per 64 crops at one core's memcpy rate): a few
+        # persistent helper threads copy slices side by side (numpy releases the GIL for large copies; torch's own intra-op pool is
+        # far too large on these hosts — see run())
+        self._copiers = ThreadPoolExecutor(max_workers=4, thread_name_prefix="effocr-stage")
 
     def __call__(self, imgs):
         return self.run(imgs)
@@ -103,10 +108,11 @@ class EffRecognizer:
                 # (np.copyto, not Tensor.copy_: torch spreads a 38 MB copy over its whole intra-op pool — 128 threads on this
                 # host — and the pool's wake-up costs 80-90 ms every few calls: 2.5 ms median but 23 ms mean per 64 crops.)
                 x = torch.empty(imgs.shape, dtype=torch.float32, device=eng.device)
-                nsl = max(1, min(4, B // 8))
-                for i in range(nsl):
-                    a, b = B * i // nsl, B * (i + 1) // nsl
-                    np.copyto(stage_np[a:b], imgs[a:b])
+                nsl = max(1, min(8, B // 8))
+                bounds = [(B * i // nsl, B * (i + 1) // nsl) for i in range(nsl)]
+                futs = [self._copiers.submit(np.copyto, stage_np[a:b], imgs[a:b]) for a, b in bounds]
+                for (a, b), f in zip(bounds, futs):             # DMA of slice i as soon as its memcpy is done, in order
+                    f.result()
                     x[a:b].copy_(stage[a:b], non_blocking=True)
                 emb = eng.forward(x, normalize=False)
                 h_out.view(B, D).copy_(emb, non_blocking=True)
