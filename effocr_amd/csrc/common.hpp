@@ -113,32 +113,42 @@ template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (
   constexpr int DEG = lo ? 6 : 8;
   constexpr float c6[7] = {3.986083969e-01f, -6.556460269e-02f, 9.218763890e-03f, -9.056357457e-04f, 5.740218682e-05f, -2.075315505e-06f, 3.214920233e-08f};
   constexpr float c8[9] = {3.989074382e-01f, -6.636037144e-02f, 9.830130026e-03f, -1.114147779e-03f, 9.457434347e-05f, -5.760762241e-06f, 2.343669162e-07f, -5.633299462e-09f, 5.998041464e-11f};
-  if constexpr (N == 8) {
+  if constexpr (N == 8 || N == 16) {
+    constexpr int NCH = N / 2;                           // packed chains in lock step (8 of them: a dependent pair is 8 issues apart, no wait states at all)
     // Eight values = FOUR packed chains kept in lock step.  A v_pk_fma_f32 consuming the previous packed result needs a wait
     // state; left alone the scheduler walks one chain at a time to save registers (an s_nop behind every packed FMA: 277 per
     // 192 MFMAs in the fused MLP's loop), and a sched_barrier does not survive instruction selection — the empty asm with
     // every chain value as an in/out operand does.  Same arithmetic, value for value, as the scalar form below.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 u[4], t[4], p[4];
+    f32x2 u[NCH], t[NCH], p[NCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       u[i] = f32x2{__builtin_amdgcn_fmed3f(x[2 * i], -L, L), __builtin_amdgcn_fmed3f(x[2 * i + 1], -L, L)};
       t[i] = u[i] * u[i];
       const float ch = lo ? c6[DEG] : c8[DEG], cl = lo ? c6[DEG - 1] : c8[DEG - 1];
       p[i] = __builtin_elementwise_fma(f32x2{ch, ch}, t[i], f32x2{cl, cl});
     }
+    // join: every chain is at the same step before any moves on.  INPUT-only operands — an asm that (re)defines the chain registers
+    // makes the hazard recognizer assume a forwarding hazard on them: two s_nop per step, 129 per 192 MFMAs in the fused MLP's loop.
+    auto join = [&](const f32x2 (&q)[NCH]) __attribute__((always_inline)) {
+      if constexpr (NCH == 4) asm volatile("" :: "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+      else asm volatile("" :: "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4 % NCH]), "v"(q[5 % NCH]), "v"(q[6 % NCH]), "v"(q[7 % NCH]));
+    };
 #pragma unroll
     for (int k = DEG - 2; k >= 0; --k) {
-      asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+      join(p);
       const float ck = lo ? c6[k] : c8[k];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{ck, ck});
+      for (int i = 0; i < NCH; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{ck, ck});
     }
-    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+    join(p);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) p[i] = __builtin_elementwise_fma(u[i], p[i], f32x2{0.5f, 0.5f});
+    join(p);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
       const f32x2 xv = {x[2 * i], x[2 * i + 1]};
-      const f32x2 r = xv * __builtin_elementwise_fma(u[i], p[i], f32x2{0.5f, 0.5f});
+      const f32x2 r = xv * p[i];
       x[2 * i] = r[0]; x[2 * i + 1] = r[1];
     }
     return;
@@ -156,6 +166,35 @@ template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (
     for (int i = 0; i < N; ++i) p[i] = fmaf(p[i], t[i], lo ? c6[k] : c8[k]);
 #pragma unroll
   for (int i = 0; i < N; ++i) x[i] = x[i] * fmaf(u[i], p[i], 0.5f);
+}
+
+// The same fit as constants + single steps, for kernels that slice the evaluation into the issue slots beside their MFMAs
+// (mlp_kernel.hpp): value for value the arithmetic of gelu_fold_n.
+template <typename E> struct GeluFit {
+  static constexpr bool lo = sizeof(E) == 2 && !__is_same(E, _Float16);
+  static constexpr int DEG = lo ? 6 : 8;
+  static constexpr float L = lo ? 3.9f : 4.2f;
+  static __device__ __forceinline__ constexpr float c(int k) {
+    constexpr float c6[7] = {3.986083969e-01f, -6.556460269e-02f, 9.218763890e-03f, -9.056357457e-04f, 5.740218682e-05f, -2.075315505e-06f, 3.214920233e-08f};
+    constexpr float c8[9] = {3.989074382e-01f, -6.636037144e-02f, 9.830130026e-03f, -1.114147779e-03f, 9.457434347e-05f, -5.760762241e-06f, 2.343669162e-07f, -5.633299462e-09f, 5.998041464e-11f};
+    return lo ? c6[k < 7 ? k : 6] : c8[k];
+  }
+};
+// two floats -> one 32-bit word of two 16-bit values (first value in the low half), and back
+template <typename E> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  typedef __attribute__((__vector_size__(2 * sizeof(E)))) E V2;
+  typedef float F2 __attribute__((__vector_size__(8)));
+  const F2 f = {a, b};
+  const V2 v = __builtin_convertvector(f, V2);            // ONE v_cvt_pk_*: a vector conversion, not two scalar ones the vectoriser would have to find
+  return __builtin_bit_cast(uint32_t, v);
+}
+template <typename E> __device__ __forceinline__ float unpack1(uint32_t wd, int hi) {
+  if constexpr (GeluFit<E>::lo) return __builtin_bit_cast(float, hi ? (wd & 0xffff0000u) : (wd << 16));
+  else {
+    typedef __attribute__((__vector_size__(2 * sizeof(E)))) E V2;
+    const V2 v = __builtin_bit_cast(V2, wd);
+    return (float)v[hi];
+  }
 }
 
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }

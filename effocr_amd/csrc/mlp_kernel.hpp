@@ -33,9 +33,33 @@
 #ifndef MLP_BARRIER_DRAIN
 #define MLP_BARRIER_DRAIN 0
 #endif
+#ifndef MLP_SLICED
+#define MLP_SLICED 1                                     // bias + GELU of a chunk as single scalar instructions in the issue slots beside the MFMAs
+#endif
+#ifndef MLP_WF2
+#define MLP_WF2 0                                        // two W-fragment sets: the four reads of step c+1 as a group, ONE counted wait per step
+#endif
+#ifndef MLP_DMA_SPREAD
+#define MLP_DMA_SPREAD 1
+#endif
+#ifndef MLP_GELU_W
+#define MLP_GELU_W 8                                     // values per GELU unit (8: four packed chains, 16: eight)
+#endif
 
 namespace effocr {
 namespace {
+
+// -DMLP_STAMP (tools/ab_build.sh variant, never shipped): wave 0 of every whole-panel workgroup records s_memtime at the panel's
+// milestones + its hardware id; tools/mlp_timeline.py reads the last launch's table through effocr_debug_mlp_stamps.
+#ifdef MLP_STAMP
+constexpr int MLP_STAMP_WGS = 2048, MLP_STAMP_N = 16;
+__device__ unsigned long long mlp_stamps[MLP_STAMP_WGS * MLP_STAMP_N];
+// branch-free (a branch would split the kernel's scheduling regions): every lane of wave 0..3 stores, the last writer's value stays
+#define MLP_STAMP_AT(k)                                                                                          \
+  if constexpr (!PARTIAL) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define MLP_STAMP_AT(k)
+#endif
 
 template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
   if constexpr (I < N) {
@@ -44,6 +68,38 @@ template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) 
   }
 }
 
+
+// ---- the hand-over work of one hidden chunk (128 features x 32 tokens per wave = 16 quads of 4 values per lane) as a list of single
+// instructions ("ops"), hosted a few at a time in the issue slots behind the MFMAs of the two phases that follow the chunk's phase A:
+//   park  (quad q): bias read | 4 x (accumulator + bias) | 2 x pack            -> pre-activations, rounded to the operand type
+//   gelu  (quad q): 4 x unpack | clamp | square | DEG x Horner | 0.5 + u p | x . | 2 x pack   (GeluFit<E>: gelu_fold_n value for value)
+// Measured (tools/ubench/mfma_fill.hip, one wave per SIMD): up to 6 scalar VALU instructions (or a ds_read_b128 + 4) behind a
+// v_mfma_f32_32x32x16 are free (32.8 -> 34 cycles per MFMA), every further one costs its 4 cycles; ONE v_pk_fma_f32 in the same
+// place costs 17 cycles and each further one 4.5 — packed fp32 never overlaps the matrix pipe.  So the list is scalar.
+template <int DEG> struct ChunkOps {
+  // park list: op 0 = bias read of quad 0, then per quad { bias read of the NEXT quad (its use is two gaps away) | 4 adds | 2 packs }
+  static constexpr int PARK_Q = 7, GELU_Q = 4 * (DEG + 5) + 2, NPARK = 1 + 16 * PARK_Q, N = NPARK + 16 * GELU_Q;
+  static constexpr int cost_before(int k) {               // issued instructions of ops [0, k): an accumulator add is a v_accvgpr_read + v_add
+    if (k >= NPARK) return 1 + 16 * 11 + (k - NPARK);
+    if (k == 0) return 0;
+    const int q = (k - 1) / PARK_Q, o = (k - 1) % PARK_Q;
+    return 1 + q * 11 + (o == 0 ? 0 : o <= 4 ? 1 + 2 * (o - 1) : 9 + (o - 5));
+  }
+  // first op of gap j when ops [K0, K1) are spread over NG gaps by cost (j = NG: K1)
+  static constexpr int first_op(int K0, int K1, int NG, int j) {
+    const int w = cost_before(K1) - cost_before(K0);
+    int k = K0;
+    while (k < K1 && (cost_before(k) - cost_before(K0)) * NG < j * w) ++k;
+    return j >= NG ? K1 : k;
+  }
+  // split point of a chunk's list between the NB gaps of the phase B and the NA gaps of the phase A that host it
+  static constexpr int split(int NB, int NA) {
+    const int total = cost_before(N);
+    int k = 0;
+    while (k < N && cost_before(k) * (NA + NB) < total * NB) ++k;
+    return k < NPARK ? NPARK : k;                          // the park ops all sit in phase B: phase A overwrites the accumulators
+  }
+};
 
 constexpr int MLP_PT = 128;                              // tokens per workgroup
 constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
@@ -89,6 +145,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
+  MLP_STAMP_AT(0)
+#ifdef MLP_STAMP
+  if (!PARTIAL) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+#endif
   // First round of workgroups only: spread the start over `stagger` x 32 ticks.  All panels cost the same, so the
   // workgroups of a launch otherwise stay in lock step from the first to the last round: every CU requests its rows at the
   // same moment (61 MB per round: an HBM-bound 12 us during which nothing computes) and stores them at the same moment.
@@ -96,6 +156,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((bid >> 3) & 31) * a.stagger);
     while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
   }
+  MLP_STAMP_AT(1)
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
   const int panel = (PARTIAL ? a.panel0 : 0) + bid / SPLIT;
   const int c0 = (bid % SPLIT) * NCW;        // first hidden chunk of this workgroup
@@ -220,6 +281,20 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
+  // one piece (MLP_DMA_SPREAD: the four pieces of a stage go out in four different MFMA gaps behind the barrier, so that the
+  // sixteen 1 KB requests of the workgroup do not hit the address unit in one burst)
+  auto issue_piece_asm = [&](int s, auto I_) __attribute__((always_inline)) {
+    constexpr int i = decltype(I_)::value;
+    const char* src = stage_src(s) + lane16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)((s & (R - 1)) * MLP_STAGE) + (unsigned)w * 4096u));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:%3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst), "n"(i * 1024) : "memory");
+  };
 #pragma unroll
   for (int s0 = 0; s0 < R - 1; ++s0)
     if (s0 < NS) {
@@ -239,6 +314,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     }
   }
   __syncthreads();                                       // parameters visible
+  MLP_STAMP_AT(2)
 
   if constexpr (PARTIAL && !PROJ) {
 #pragma unroll
@@ -326,37 +402,64 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // middle of stage s: stage s+1 has landed (own pieces; the R-3 younger stages may stay in flight) and, past
   // the barrier, everybody's; every wave holds the rest of stage s in registers and is done with stage s-1, whose
   // slot takes stage s+R-1
+#ifdef MLP_STAMP
+  unsigned long long vm_wait = 0, bar_wait = 0;          // ticks this wave spent in the mid-stage vmcnt wait / barrier (sum over the panel)
+#endif
   auto stage_mid = [&](auto STEADY) __attribute__((always_inline)) {
+#ifdef MLP_STAMP
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (decltype(STEADY)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MLP_STAMP
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+#endif
 #if MLP_BARRIER_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind this barrier is stage s-1's, whose fragment
 #endif                                                  // reads were all consumed by MFMAs before stage s began; the reads in flight here are stage s's
+#ifndef MLP_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
+#ifdef MLP_STAMP
+    const unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+    vm_wait += t1_ - t0_; bar_wait += t2_ - t1_;
+#endif
   };
+#if MLP_WF2
+  WF wf2[2];
+  WF& wf = wf2[0];
+#else
   WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
+#endif
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
   __builtin_amdgcn_s_barrier();                          // ... and everybody's
   asm volatile("" ::: "memory");
   load_w(wf, sW, 0);
+  MLP_STAMP_AT(3)
 
   // ---- chunk hand-over registers: the set holds the 8 B-operand fragments (8 values each) of one chunk, first as
   // pre-activations (bias added, rounded to the operand type: "parked"), then GELU'd IN PLACE, 4 values at a time.
   // (Two alternating sets, with the GELU spread over both phases, do not fit next to the 96 VGPRs of xn: spills.)
   struct HSet { u32x4 u[8]; };
-  // unit q (0..7) = 8 values = four independent v_pk_fma_f32 Horner chains kept in lock step (gelu_fold_n, common.hpp)
+  // unit q = MLP_GELU_W values = that many / 2 independent v_pk_fma_f32 Horner chains kept in lock step (gelu_fold_n, common.hpp)
   auto gelu_unit = [&](HSet& hs, auto Q) __attribute__((always_inline)) {     // Q: compile-time -> static register indices
     typedef __attribute__((__vector_size__(8 * sizeof(E)))) E E8;
-    constexpr int u = decltype(Q)::value;
-    const E8 pv = __builtin_bit_cast(E8, hs.u[u]);
-    float v[8];
+    constexpr int u = decltype(Q)::value, NV = MLP_GELU_W / 8;                 // NV set entries (8 values each) per unit
+    float v[8 * NV];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)pv[e];
-    gelu_fold_n<E, 8>(v);
-    const u32x2 o0 = pack4<E>(v[0], v[1], v[2], v[3]);
-    const u32x2 o1 = pack4<E>(v[4], v[5], v[6], v[7]);
-    hs.u[u] = u32x4{o0[0], o0[1], o1[0], o1[1]};
+    for (int j = 0; j < NV; ++j) {
+      const E8 pv = __builtin_bit_cast(E8, hs.u[NV * u + j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[8 * j + e] = (float)pv[e];
+    }
+    gelu_fold_n<E, 8 * NV>(v);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const u32x2 o0 = pack4<E>(v[8 * j], v[8 * j + 1], v[8 * j + 2], v[8 * j + 3]);
+      const u32x2 o1 = pack4<E>(v[8 * j + 4], v[8 * j + 5], v[8 * j + 6], v[8 * j + 7]);
+      hs.u[NV * u + j] = u32x4{o0[0], o0[1], o1[0], o1[1]};
+    }
   };
   // acc1 (+ bias1 of chunk c) -> set, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
   auto park = [&](HSet& hs, int c) __attribute__((always_inline)) {
@@ -375,15 +478,84 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     });
   };
 
+#if MLP_SLICED
+  typedef GeluFit<E> GF;
+  typedef ChunkOps<GF::DEG> CO;
+  float gx[4], gu[4], gt[4], gp[4];                      // the quad in flight (one at a time: the list is sequential)
+  f32x4 gb[2];                                           // bias of the quad being parked / of the next one (read ahead)
+  // op K of chunk (bias base cb) on hand-over set hs
+  auto gop = [&](HSet& hs, const int cb, auto K_) __attribute__((always_inline)) {
+    constexpr int K = decltype(K_)::value;
+    if constexpr (K == 0) gb[0] = *reinterpret_cast<const f32x4*>(sB1 + cb + 4 * half);
+    else if constexpr (K < CO::NPARK) {
+      constexpr int q = (K - 1) / CO::PARK_Q, o = (K - 1) % CO::PARK_Q, i = q >> 2, r0 = 4 * (q & 3);
+      if constexpr (o == 0) {
+        constexpr int qn = q + 1;
+        if constexpr (qn < 16) gb[qn & 1] = *reinterpret_cast<const f32x4*>(sB1 + cb + (qn >> 2) * 32 + 8 * (qn & 3) + 4 * half);
+      } else if constexpr (o <= 4) gx[o - 1] = acc1[i][r0 + o - 1] + gb[q & 1][o - 1];
+      else hs.u[q >> 1][2 * (q & 1) + (o - 5)] = pack2<E>(gx[2 * (o - 5)], gx[2 * (o - 5) + 1]);
+    } else {
+      constexpr int kk = K - CO::NPARK, q = kk / CO::GELU_Q, o = kk % CO::GELU_Q, st = o >> 2, e = o & 3, DEG = GF::DEG;
+      if constexpr (o >= 4 * (DEG + 5)) {
+        constexpr int j = o - 4 * (DEG + 5);
+        hs.u[q >> 1][2 * (q & 1) + j] = pack2<E>(gx[2 * j], gx[2 * j + 1]);
+      } else if constexpr (st == 0) {
+        const uint32_t wd = hs.u[q >> 1][2 * (q & 1) + (e >> 1)];
+        gx[e] = unpack1<E>(wd, e & 1);
+      } else if constexpr (st == 1) gu[e] = __builtin_amdgcn_fmed3f(gx[e], -GF::L, GF::L);
+      else if constexpr (st == 2) gt[e] = gu[e] * gu[e];
+      else if constexpr (st == 3) gp[e] = __builtin_fmaf(GF::c(DEG), gt[e], GF::c(DEG - 1));
+      else if constexpr (st < 3 + DEG) gp[e] = __builtin_fmaf(gp[e], gt[e], GF::c(DEG - 1 - (st - 3)));
+      else if constexpr (st == 3 + DEG) gp[e] = __builtin_fmaf(gu[e], gp[e], 0.5f);
+      else gx[e] = gx[e] * gp[e];
+    }
+  };
+  // ops [K0, K1) of a chunk hosted by a phase of NG MFMAs: the share of gap n
+  auto host = [&](HSet* hs, const int cb, auto K0_, auto K1_, auto NG_, auto N_) __attribute__((always_inline)) {
+    constexpr int K0 = decltype(K0_)::value, K1 = decltype(K1_)::value, NG = decltype(NG_)::value, n = decltype(N_)::value;
+    if constexpr (K1 > K0) {
+      constexpr int lo = CO::first_op(K0, K1, NG, n), hi = CO::first_op(K0, K1, NG, n + 1);
+#ifndef MLP_ABL_NOOPS
+      sfor<lo, hi>([&](auto K_) { gop(*hs, cb, K_); });
+#endif
+    }
+  };
+#endif
+
   // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
   // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
   // is one basic block (a scalar branch between two MFMAs is a bubble with one wave per SIMD; see gemm3.hip).
   auto ring_stage = [&](auto REM, auto&& mfma1, auto NOPF) __attribute__((always_inline)) {   // NOPF: do not prefetch stage s+1's first fragments
     constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1 && !decltype(NOPF)::value;
-    const char* st = sW + (s & (R - 1)) * MLP_STAGE;
-    const char* stn = sW + ((s + 1) & (R - 1)) * MLP_STAGE;
+    // (slot offsets opaque: where the stage counter is static — the two-chunk loop body is 24 stages, a multiple of the ring — the
+    // compiler would fold slot + fragment offset into constants beyond the 16-bit ds_read offset field: a v_or per read)
+    int so = (s & (R - 1)) * MLP_STAGE, son = ((s + 1) & (R - 1)) * MLP_STAGE;
+    asm volatile("" : "+s"(so), "+s"(son));
+    const char* st = sW + so;
+    const char* stn = sW + son;
     // ONE fragment set, refilled in a rolling fashion: right after MFMA (c4, i) has consumed wf.w[i], the same
-    // registers receive fragment i of step c4+1 (of stage s+1's step 0 after step 3) — 16 VGPRs instead of 32
+    // registers receive fragment i of step c4+1 (of stage s+1's step 0 after step 3) — 16 VGPRs instead of 32.  (Two alternating
+    // sets with the four reads of a step issued as a group and ONE counted wait per step — 75 instead of 216 s_waitcnt per chunk —
+    // measured 2 % slower, same box: the satisfied waits are cheap, the read-per-MFMA interleave is what hides the LDS latency.)
+#if MLP_WF2
+    sfor<0, 4>([&](auto C4) {
+      constexpr int c4 = decltype(C4)::value;
+      if constexpr (c4 == 2) {
+        stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
+      }
+      if constexpr (c4 < 3) load_w(wf2[(c4 + 1) & 1], st, c4 + 1);
+      else if constexpr (next) load_w(wf2[0], stn, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      sfor<0, 4>([&](auto J) {
+        constexpr int i = 3 - decltype(J)::value;          // last-requested fragment first: its wait covers the other three
+        mfma1(C4, std::integral_constant<int, i>{}, wf2[c4 & 1].w[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef MLP_ABL_NODMA
+        if constexpr (more && c4 >= 2 && (i & 1) == 0) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});
+#endif
+      });
+    });
+#else
     sfor<0, 4>([&](auto C4) {
       constexpr int c4 = decltype(C4)::value;
       if constexpr (c4 == 2) {
@@ -393,11 +565,20 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         constexpr int i = decltype(I)::value;
         mfma1(C4, I, wf.w[i]);
         __builtin_amdgcn_sched_barrier(0);
+#ifndef MLP_ABL_NOLDS
         if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
         else if constexpr (next) wf.w[i] = *reinterpret_cast<const V8*>(stn + wo + (i * 8) * 512);
+#endif
+#ifndef MLP_ABL_NODMA
+#if MLP_DMA_SPREAD
+        if constexpr (more && c4 >= 2 && (i & 1) == 0) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});
+#else
         if constexpr (more && c4 == 2 && i == 0) issue_stage_asm(s + R - 1);   // right behind the barrier: slot of stage s-1 is free
+#endif
+#endif
       });
     });
+#endif
     ++s;
   };
   constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
@@ -452,6 +633,37 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     });
   };
 
+#if MLP_SLICED
+  // ---- the same phases hosting ops [K0, K1) of the chunk with bias base cb on set hd
+  auto phase_a_h = [&](auto AFTER, HSet* hd, const int cb, auto K0_, auto K1_) __attribute__((always_inline)) {
+    sfor<0, SA>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
+      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+        if constexpr (ks == 0 && c4 == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc1[i] = Op16<E>::mfma(wfrag, xf[0], z);        // the chunk's accumulators start from the instruction's zero operand
+        } else acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
+        host(hd, cb, K0_, K1_, std::integral_constant<int, SA * 16>{}, std::integral_constant<int, ks * 16 + c4 * 4 + i>{});
+      }, std::false_type{});
+    });
+  };
+  auto phase_b_h = [&](auto AFTER, const HSet& hs, HSet* hd, const int cb, auto K0_, auto K1_) __attribute__((always_inline)) {
+    sfor<0, SB>([&](auto SBI) {
+      constexpr int sb = decltype(SBI)::value;
+      constexpr int g = sb >> 1, kh = sb & 1;
+      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SB - 1 - sb);
+      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+        const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
+        acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
+        host(hd, cb, K0_, K1_, std::integral_constant<int, SB * 16>{}, std::integral_constant<int, sb * 16 + c4 * 4 + i>{});
+      }, std::false_type{});
+    });
+  };
+#endif
+
   if constexpr (PROJ) {
     // ---- projection: outT[D x 32 tok] = x + bias + Wpp . a^T, (group g, k stage) ring stages; B-operand = attention fragments.
     // The accumulators of a group start at its rows + bias (first group: requested in the prologue; the others: requested
@@ -468,6 +680,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         }, std::integral_constant<bool, (g == OG - 1 && ks == SA - 1)>{});   // nothing of the ring held in registers across the LayerNorm
       });
     });
+    MLP_STAMP_AT(4)
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
@@ -492,27 +705,67 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     }
   }
 
+  MLP_STAMP_AT(5)
   // Schedule (ring stream order A(0) | A(1) | B(0) | A(2) | B(1) | ...).  ONE hand-over set: parked after A(c) — once B(c-1)
   // has consumed the previous contents — activated in place under A(c+1), consumed by B(c):
   //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
   static_assert(NC >= 3, "mlp: at least three hidden chunks");
   typedef std::integral_constant<int, FAR> Far;
-  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 8> U16_;   // 8 units per chunk
+#if MLP_SLICED
+  // Schedule, same ring stream order.  TWO hand-over sets (chunk c uses set c & 1): while B(c-1) consumes one, the ops of chunk c
+  // fill the other — its park ops and the first part of its GELU behind B(c-1)'s MFMAs, the rest behind A(c+1)'s:
+  //   A(0) | park(0) | A(1)+gelu(0) | { B(c-1)+ops(c)[0,KB) | A(c+1)+ops(c)[KB,N) } c=1..NC-2 | B(NC-2)+ops(NC-1)[0,KB) | ops(NC-1)[KB,N) | B(NC-1)
+  // (only the first chunk's park and the last chunk's second part run without MFMAs beside them)
+  constexpr int KB = CO::split(SB * 16, SA * 16);
+  typedef std::integral_constant<int, 0> K0_; typedef std::integral_constant<int, CO::NPARK> KP_;
+  typedef std::integral_constant<int, KB> KB_; typedef std::integral_constant<int, CO::N> KN_;
+  HSet S2[2];
+  const int cb0 = c0 * 128;
+  phase_a_h(Far{}, nullptr, 0, K0_{}, K0_{});                               // A(0)
+  sfor<0, CO::NPARK>([&](auto K_) { gop(S2[0], cb0, K_); });              // park(0)
+  MLP_STAMP_AT(6)
+  phase_a_h(Far{}, &S2[0], cb0, KP_{}, KN_{});                            // A(1) + gelu(0)
+  auto pair_step = [&](auto PAR, auto AFTER_A, const int c) __attribute__((always_inline)) {   // chunk c, c & 1 == PAR
+    constexpr int par = decltype(PAR)::value;
+    constexpr int after_b = decltype(AFTER_A)::value >= FAR ? FAR : decltype(AFTER_A)::value + SA;
+    phase_b_h(std::integral_constant<int, after_b>{}, S2[par ^ 1], &S2[par], cb0 + c * 128, K0_{}, KB_{});   // B(c-1) + ops(c)[0, KB)
+    phase_a_h(AFTER_A, &S2[par], cb0 + c * 128, KB_{}, KN_{});                                                // A(c+1) + ops(c)[KB, N)
+  };
+  {
+    int c = 1;                                           // chunks 1 .. NC-3 rolled in pairs (static set roles), chunk NC-2 peeled (static stage counts)
+#pragma unroll 1
+    for (; c + 1 <= NC - 3; c += 2) {
+      pair_step(std::integral_constant<int, 1>{}, Far{}, c);
+      pair_step(std::integral_constant<int, 0>{}, Far{}, c + 1);
+    }
+    if constexpr ((NC - 3) % 2 == 1) pair_step(std::integral_constant<int, 1>{}, Far{}, NC - 3);
+  }
+  MLP_STAMP_AT(7)
+  pair_step(std::integral_constant<int, (NC - 2) & 1>{}, std::integral_constant<int, 2 * SB>{}, NC - 2);      // B(NC-3) | A(NC-1)
+  phase_b_h(std::integral_constant<int, SB>{}, S2[(NC - 2) & 1], &S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K0_{}, KB_{});   // B(NC-2)
+  sfor<KB, CO::N>([&](auto K_) { gop(S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K_); });
+  phase_b_h(std::integral_constant<int, 0>{}, S2[(NC - 1) & 1], nullptr, 0, K0_{}, K0_{});                     // B(NC-1)
+#else
+  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 64 / MLP_GELU_W> U16_;   // GELU units per chunk
   HSet S;
   phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
   park(S, 0);
+  MLP_STAMP_AT(6)
 #pragma unroll 1
   for (int c = 1; c < NC - 1; ++c) {
     phase_a(Far{}, &S, U0_{}, U16_{});                    // A(c) + gelu(c-1)
     phase_b(Far{}, S, nullptr, U0_{}, U0_{});             // B(c-1)
     park(S, c);
   }
+  MLP_STAMP_AT(7)
   phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
   phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
   park(S, NC - 1);
-  sfor<0, 8>([&](auto Q) { gelu_unit(S, Q); });
+  sfor<0, 64 / MLP_GELU_W>([&](auto Q) { gelu_unit(S, Q); });
   phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
 
+#endif
+  MLP_STAMP_AT(8)
   // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row (W2's
   // rows are permuted per 32: api.hip rowperm32).  Whole panels: acc2 already holds x + bias2 + fc2 — nothing is re-read.
   int hf = half;
@@ -542,6 +795,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
       }
     });
+    MLP_STAMP_AT(9)
     if (a.xn_out) {
       // ---- second output.  The lane pair (r31, half 0 / 1) holds the whole new row: two-pass statistics (one cross-half
       // exchange each) and the next block's norm1 applied on the way out, rounded to the operand type (same arithmetic as
@@ -576,6 +830,12 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       });
     }
   }
+  MLP_STAMP_AT(10)
+#ifdef MLP_STAMP
+  if constexpr (!PARTIAL) { mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 12] = vm_wait; mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 13] = bar_wait; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MLP_STAMP_AT(11)
 }
 
 // One launch for the whole panels (workgroups [0, main_wgs)) AND the split parts of the tail panels (TNCW hidden chunks each; TNCW = 0:
