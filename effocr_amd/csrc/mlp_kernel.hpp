@@ -36,9 +36,6 @@
 #ifndef MLP_SLICED
 #define MLP_SLICED 1                                     // bias + GELU of a chunk as single scalar instructions in the issue slots beside the MFMAs
 #endif
-#ifndef MLP_WF2
-#define MLP_WF2 0                                        // two W-fragment sets: the four reads of step c+1 as a group, ONE counted wait per step
-#endif
 #ifndef MLP_DMA_SPREAD
 #define MLP_DMA_SPREAD 1
 #endif
@@ -145,6 +142,15 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
+  // PROJ: the projection bias and bias2 are added by ONE extra MFMA per output tile instead of 16 x (read accumulator, add, write
+  // back) per lane: A = [32 features x 16 k] with k0 = hi(bias), k1 = lo(bias) (two operand-type values: 16+ mantissa bits),
+  // B = [16 k x 32 tokens] with rows k0 = k1 = 1.  ~1 000 of the 3 400 VALU instructions between the projection and phase A(0).
+  constexpr bool BIAS_MM = PROJ && !PARTIAL;
+  auto hilo = [](float b) __attribute__((always_inline)) -> uint32_t {
+    const E hi = (E)b;
+    const E lo = (E)(b - (float)hi);
+    return pack2<E>((float)hi, (float)lo);                 // (exact: both are operand-type values)
+  };
   MLP_STAMP_AT(0)
 #ifdef MLP_STAMP
   if (!PARTIAL) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
@@ -186,6 +192,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   f32x16 acc2[OT];                                       // outT tiles
   f32x4 xv[2 * NXF];
   V8 xf[NXF];                                            // B-operand fragments: attention output (PROJ), then LayerNorm(x)
+  auto bias_mm = [&](const float* sb, auto T_) __attribute__((always_inline)) {   // acc2[t] += bias (as stored by the prologue)
+    constexpr int t = decltype(T_)::value;
+    const uint32_t wd = reinterpret_cast<const uint32_t*>(sb)[t * 32 + r31];
+    const uint32_t one2 = GeluFit<E>::lo ? 0x3f803f80u : 0x3c003c00u;
+    const u32x4 af = {half ? 0u : wd, 0u, 0u, 0u}, bf = {half ? 0u : one2, 0u, 0u, 0u};
+    acc2[t] = Op16<E>::mfma(__builtin_bit_cast(V8, af), __builtin_bit_cast(V8, bf), acc2[t]);
+  };
   const int64_t rbc = rb < (a.rows_alloc >> 5) ? rb : (a.rows_alloc >> 5) - 1;
   const char* xb = reinterpret_cast<const char*>(a.x) + rbc * (D / 4) * 512 + r31 * 16;
   // (PROJ) x is the projection's initial accumulator value (x + bias + a . Wp^T lands where LayerNorm reads it).  Output tile t,
@@ -308,8 +321,14 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   for (int j = 0; j < ND; ++j) {
     const int n = tid + 256 * j;
     if (n < D) {
-      sB2[n] = pdv[0][j]; sG[n] = pdv[1][j]; sBt[n] = pdv[2][j];
-      if constexpr (PROJ) sBp[n] = pdv[3][j];
+      sG[n] = pdv[1][j]; sBt[n] = pdv[2][j];
+      if constexpr (BIAS_MM) {                             // biases that enter through an MFMA: (hi, lo) operand-type pair per feature
+        reinterpret_cast<uint32_t*>(sB2)[n] = hilo(pdv[0][j]);
+        reinterpret_cast<uint32_t*>(sBp)[n] = hilo(pdv[3][j]);
+      } else {
+        sB2[n] = pdv[0][j];
+        if constexpr (PROJ) sBp[n] = pdv[3][j];
+      }
       if (second) { sGn[n] = pdv[4][j]; sBn[n] = pdv[5][j]; }
     }
   }
@@ -371,7 +390,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         const f32x4 v = j == 0 ? row(std::integral_constant<int, 2 * t>{}) : row(std::integral_constant<int, 2 * t + 1>{});
         pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
                          (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
-        if constexpr (!PARTIAL) {
+        if constexpr (!PARTIAL && !BIAS_MM) {
           constexpr int tt = t >> 1;
           const int q = 2 * (t & 1) + j;
           const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + tt * 32 + 8 * q + 4 * half);
@@ -426,12 +445,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     vm_wait += t1_ - t0_; bar_wait += t2_ - t1_;
 #endif
   };
-#if MLP_WF2
-  WF wf2[2];
-  WF& wf = wf2[0];
-#else
   WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
-#endif
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
   __builtin_amdgcn_s_barrier();                          // ... and everybody's
   asm volatile("" ::: "memory");
@@ -536,26 +550,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     // ONE fragment set, refilled in a rolling fashion: right after MFMA (c4, i) has consumed wf.w[i], the same
     // registers receive fragment i of step c4+1 (of stage s+1's step 0 after step 3) — 16 VGPRs instead of 32.  (Two alternating
     // sets with the four reads of a step issued as a group and ONE counted wait per step — 75 instead of 216 s_waitcnt per chunk —
-    // measured 2 % slower, same box: the satisfied waits are cheap, the read-per-MFMA interleave is what hides the LDS latency.)
-#if MLP_WF2
-    sfor<0, 4>([&](auto C4) {
-      constexpr int c4 = decltype(C4)::value;
-      if constexpr (c4 == 2) {
-        stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
-      }
-      if constexpr (c4 < 3) load_w(wf2[(c4 + 1) & 1], st, c4 + 1);
-      else if constexpr (next) load_w(wf2[0], stn, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      sfor<0, 4>([&](auto J) {
-        constexpr int i = 3 - decltype(J)::value;          // last-requested fragment first: its wait covers the other three
-        mfma1(C4, std::integral_constant<int, i>{}, wf2[c4 & 1].w[i]);
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef MLP_ABL_NODMA
-        if constexpr (more && c4 >= 2 && (i & 1) == 0) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});
-#endif
-      });
-    });
-#else
+    // measured 2 % slower in the burst form of the kernel and 4 % slower in this one, same box: the satisfied waits are cheap, the
+    // read-per-MFMA interleave is what hides the LDS latency.)
     sfor<0, 4>([&](auto C4) {
       constexpr int c4 = decltype(C4)::value;
       if constexpr (c4 == 2) {
@@ -578,7 +574,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #endif
       });
     });
-#endif
     ++s;
   };
   constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
@@ -681,7 +676,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       });
     });
     MLP_STAMP_AT(4)
-    sfor<0, OT>([&](auto T_) {
+    if constexpr (BIAS_MM) sfor<0, OT>([&](auto T_) { bias_mm(sBp, T_); });
+    else sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -691,6 +687,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       }
     });
     layernorm_to_xf();
+    if constexpr (BIAS_MM) sfor<0, OT>([&](auto T_) { bias_mm(sB2, T_); });   // (after the statistics: the LayerNorm is of the row without bias2)
     load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)                          // (not before: the 64 registers are free for the compiler up to here)
