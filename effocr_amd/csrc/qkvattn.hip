@@ -353,35 +353,48 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         // compiler can put the matrix instructions under the VALU work (with the MFMAs of a step behind ITS OWN
         // exponentials the in-order wave ran them strictly one after the other)
         V8 pf[2];
-        auto p_frag = [&](auto ST_) __attribute__((always_inline)) {
-          constexpr int st = decltype(ST_)::value, kt = st >> 1, m = st & 1;
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          f32x2 av[4];
-          float ev[8];
+        float av[8], ev[8];                                // the fragment in the making (one at a time)
+        // part 0..2 of fragment st: v_exp_f32 issues at half rate — THREE per MFMA gap are free, each further one costs 8 cycles
+        // (tools/ubench/mfma_fill.hip) — so the eight exponentials of a fragment are spread over the step's three MFMA gaps
+        // instead of queueing behind its last MFMA: { 2 V reads, args 0-3, exp 0-1 } | { args 4-7, exp 2-4 } | { exp 5-7, 4 packs }
+        auto p_part = [&](auto ST_, auto PART_) __attribute__((always_inline)) {
+          constexpr int st = decltype(ST_)::value, kt = st >> 1, m = st & 1, part = decltype(PART_)::value;
+          if constexpr (part == 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {                  // exponent arguments two at a time (v_pk_fma_f32)
-            const f32x2 sv = {s[kt][8 * m + 2 * j], s[kt][8 * m + 2 * j + 1]};
-            av[j] = __builtin_elementwise_fma(sv, f32x2{cexp, cexp}, f32x2{-mxc, -mxc});
+            for (int j = 0; j < 4; ++j) av[j] = __builtin_fmaf(s[kt][8 * m + j], cexp, -mxc);
+            ev[0] = __builtin_amdgcn_exp2f(av[0]); ev[1] = __builtin_amdgcn_exp2f(av[1]);
+          } else if constexpr (part == 1) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j) av[j] = __builtin_fmaf(s[kt][8 * m + j], cexp, -mxc);
+            ev[2] = __builtin_amdgcn_exp2f(av[2]); ev[3] = __builtin_amdgcn_exp2f(av[3]); ev[4] = __builtin_amdgcn_exp2f(av[4]);
+          } else {
+            ev[5] = __builtin_amdgcn_exp2f(av[5]); ev[6] = __builtin_amdgcn_exp2f(av[6]); ev[7] = __builtin_amdgcn_exp2f(av[7]);
+            const u32x4 pw = {pack2<E>(ev[0], ev[1]), pack2<E>(ev[2], ev[3]), pack2<E>(ev[4], ev[5]), pack2<E>(ev[6], ev[7])};
+            pf[st & 1] = __builtin_bit_cast(V8, pw);
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ev[j] = __builtin_amdgcn_exp2f(av[j >> 1][j & 1]);   // all eight before the first is consumed:
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[st & 1][j] = (E)ev[j];                           // a transcendental result needs a wait state
         };
-        p_frag(std::integral_constant<int, 0>{});
+        qa_for<0, 3>([&](auto P_) { p_part(std::integral_constant<int, 0>{}, P_); });
         __builtin_amdgcn_sched_barrier(0);
         qa_for<0, 2 * NTT>([&](auto ST_) {
           constexpr int st = decltype(ST_)::value, cur = st & 1, nxt = cur ^ 1;
-          if constexpr (st + 1 < 2 * NTT) {
+          constexpr bool more = st + 1 < 2 * NTT;
+          if constexpr (more) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) vf[nxt][db] = *reinterpret_cast<const V8*>(vb + ((st + 1) * 2 + db) * 1024);
           }
-#pragma unroll
-          for (int db = 0; db < 2; ++db) o[db] = Op16<E>::mfma(vf[cur][db], pf[cur], o[db]);
+          o[0] = Op16<E>::mfma(vf[cur][0], pf[cur], o[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (more) p_part(std::integral_constant<int, st + 1>{}, std::integral_constant<int, 0>{});
+          __builtin_amdgcn_sched_barrier(0);
+          o[1] = Op16<E>::mfma(vf[cur][1], pf[cur], o[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (more) p_part(std::integral_constant<int, st + 1>{}, std::integral_constant<int, 1>{});
+          __builtin_amdgcn_sched_barrier(0);
           // row sums on the (otherwise idle) matrix pipe: an all-ones A operand makes every row of the tile sum_k P[k][query],
           // i.e. the softmax denominator of exactly the rounded P that enters the numerator; no per-value adds, no exchange
           lsum = Op16<E>::mfma(ones, pf[cur], lsum);
-          if constexpr (st + 1 < 2 * NTT) p_frag(std::integral_constant<int, st + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (more) p_part(std::integral_constant<int, st + 1>{}, std::integral_constant<int, 2>{});
           __builtin_amdgcn_sched_barrier(0);
         });
         const float l = lsum[0];

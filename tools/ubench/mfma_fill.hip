@@ -17,6 +17,9 @@ template <int KIND, int K> __device__ __forceinline__ void fill(float (&f)[16], 
       if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[idx & 3]) : "v"((unsigned)(size_t)lds + (threadIdx.x & 63) * 16 + (idx & 3) * 1024));
       else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
     } else if constexpr (KIND == 3) asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
+    else if constexpr (KIND == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(f[(idx * K + j) & 15]));
+    else if constexpr (KIND == 6) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
+    else if constexpr (KIND == 7) { if (j & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(f[(idx * K + j) & 15])); else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c)); }
     else asm volatile("s_nop 0");
   }
 }
@@ -81,6 +84,9 @@ int main() {
   run<1, 1>("v_pk_fma_f32", out, ticks); run<1, 2>("v_pk_fma_f32", out, ticks); run<1, 3>("v_pk_fma_f32", out, ticks); run<1, 4>("v_pk_fma_f32", out, ticks); run<1, 6>("v_pk_fma_f32", out, ticks);
   run<2, 1>("ds_read_b128 (+K-1 fma)", out, ticks); run<2, 3>("ds_read_b128 (+K-1 fma)", out, ticks); run<2, 5>("ds_read_b128 (+K-1 fma)", out, ticks); run<2, 7>("ds_read_b128 (+K-1 fma)", out, ticks);
   run<3, 2>("2x dependent v_fma pairs", out, ticks); run<3, 4>("2x dependent v_fma pairs", out, ticks);
+  run<5, 1>("v_exp_f32", out, ticks); run<5, 2>("v_exp_f32", out, ticks); run<5, 3>("v_exp_f32", out, ticks); run<5, 4>("v_exp_f32", out, ticks); run<5, 6>("v_exp_f32", out, ticks); run<5, 8>("v_exp_f32", out, ticks);
+  run<6, 4>("v_cvt_pk_bf16_f32", out, ticks); run<6, 6>("v_cvt_pk_bf16_f32", out, ticks);
+  run<7, 4>("fma/exp alternating", out, ticks); run<7, 6>("fma/exp alternating", out, ticks); run<7, 8>("fma/exp alternating", out, ticks);
   run<4, 4>("s_nop 0", out, ticks); run<4, 8>("s_nop 0", out, ticks);
   return 0;
 }
