@@ -13,7 +13,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # EFFOCR_HIP_LIB: A/B experiments only (tools/): another build of the SAME library; the product default is the in-tree .so
 SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip.so")
 
-ABI_VERSION = 3          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
+ABI_VERSION = 4          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
@@ -92,6 +92,7 @@ def _declare(lib):
         "effocr_letterbox": (i32, [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32, i32, f32p, vp]),
         "effocr_nms_workspace_bytes": (sz, [i32, i32]),
         "effocr_nms": (i32, [f32p, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
+        "effocr_nms_batch": (i32, [f32p, i32, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
         "effocr_op_linear": (i32, [i32, i32, vp, vp, f32p, f32p, vp, i32, i32, i32, vp]),
         "effocr_op_layernorm": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
         "effocr_op_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),

@@ -177,6 +177,9 @@ int yolo_decode(const float* raw, int raw_ld, float* pred, int B, int ny, int nx
 int letterbox_u8(const uint8_t* img, int H, int W, int64_t row_stride, int bgr, int out_h, int out_w, int new_h, int new_w, int top, int left,
                  float fill, float* out, hipStream_t s);
 size_t nms_workspace_bytes(int n, int max_nms);
+bool nms_greedy_applies(int n, int max_det, int max_nms);
+int nms_yolo_batch(const float* pred, int B, int n, int nc, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+                   float* out, int* count, void* ws, size_t ws_bytes, hipStream_t s);
 int nms_yolo(const float* pred, int n, int nc, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
              float* out, int* count, void* ws, size_t ws_bytes, hipStream_t s);
 

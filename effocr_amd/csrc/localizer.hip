@@ -373,4 +373,13 @@ int effocr_nms(const float* pred_dev, int n, int num_classes, float conf_thres, 
                   LS(stream));
 }
 
+int effocr_nms_batch(const float* pred_dev, int batch, int n, int num_classes, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh,
+                     int agnostic, float* out_dev, int* count_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (batch > 0 && n > 0 && !pred_dev) return fail(EFFOCR_EINVAL, "nms: NULL device pointer");
+  if (batch > 0 && (!out_dev || !count_dev)) return fail(EFFOCR_EINVAL, "nms: NULL output pointer");
+  if (batch > 0 && n > 0 && !nms_greedy_applies(n, max_det, max_nms) && !workspace_dev) return fail(EFFOCR_EINVAL, "nms: NULL workspace");
+  return nms_yolo_batch(pred_dev, batch, n, num_classes, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, out_dev, count_dev, workspace_dev,
+                        workspace_bytes, LS(stream));
+}
+
 }  // extern "C"

@@ -305,6 +305,108 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
   if (lane == 0) *count = kept;
 }
 
+
+// ---- few kept boxes out of many candidates (text lines: max_det of tens, a detector that fires on thousands of anchors): greedy NMS
+// WITHOUT the sort and WITHOUT the m x m mask.  torchvision's result is "walk the boxes by descending score, keep a box iff no kept
+// box overlaps it with IoU > thr"; the same set comes out of: keep the best live candidate, kill every live candidate it overlaps,
+// repeat — each round one pass over the candidates, which never leave the registers (boxes) / LDS (scores) of ONE workgroup per image:
+//   work = kept x candidates IoUs (64 x 25 200) instead of candidates^2 / 2 compares + candidates^2 / 2 IoUs (6.4e8 each),
+// and the images of a batch run side by side (one launch, grid = images).  Same arithmetic as the three-kernel path: the filter of
+// nms_filter_kernel, the boxes of nms_rank_kernel, the IoU expression of nms_mask_kernel, ties by ascending row index.
+constexpr int NG_T = 512, NG_PER = 50;                    // 2 waves per SIMD (256 registers): 4 x 50 box registers per thread; n <= 25 600
+__global__ __launch_bounds__(NG_T) void nms_greedy_kernel(const float* __restrict__ pred_all, int n, int nc, float conf_thr, float iou_thr, int max_det,
+                                                          float max_wh, int agnostic, float* __restrict__ out_all, int* __restrict__ count_all) {
+  const float* pred = pred_all + (int64_t)blockIdx.x * n * (5 + nc);
+  float* out = out_all + (int64_t)blockIdx.x * max_det * 6;
+  __shared__ float sc[NG_PER * NG_T];                     // score of candidate (slot j, thread t) = row j * NG_T + t; -inf: dead
+  __shared__ float red_s[NG_T / 64];
+  __shared__ int red_r[NG_T / 64];
+  __shared__ float kb[4];                                 // the box kept in this round (offset form)
+  __shared__ int kr;                                      // its row (-1: nothing left)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  float bx[NG_PER][4];
+#pragma unroll
+  for (int j = 0; j < NG_PER; ++j) {
+    const int r = j * NG_T + t;
+    float s = -INFINITY;
+    bx[j][0] = bx[j][1] = bx[j][2] = bx[j][3] = 0.f;
+    if (r < n) {
+      const float* p = pred + (int64_t)r * (5 + nc);
+      const float obj = p[4];
+      if (obj > conf_thr) {
+        float best = -INFINITY; int bj = 0;
+        for (int c = 0; c < nc; ++c) { const float v = p[5 + c] * obj; if (v > best) { best = v; bj = c; } }   // first maximum wins
+        if (best > conf_thr) {
+          s = best;
+          const float x1 = p[0] - p[2] / 2, y1 = p[1] - p[3] / 2, x2 = p[0] + p[2] / 2, y2 = p[1] + p[3] / 2;   // xywh2xyxy
+          const float off = agnostic ? 0.f : (float)bj * max_wh;
+          bx[j][0] = x1 + off; bx[j][1] = y1 + off; bx[j][2] = x2 + off; bx[j][3] = y2 + off;
+        }
+      }
+    }
+    sc[j * NG_T + t] = s;
+  }
+  int kept = 0;
+  float ax1 = 0.f, ay1 = 0.f, ax2 = 0.f, ay2 = 0.f, aa = 0.f;
+  bool have = false;                                      // a box was kept in the previous round: its kills are applied in this pass
+  while (true) {
+    // one pass: apply the previous winner's kills, find this thread's best live candidate
+    float bs = -INFINITY; int br = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NG_PER; ++j) {
+      float s = sc[j * NG_T + t];
+      if (s > -INFINITY) {
+        if (have) {
+          const float iw = fminf(ax2, bx[j][2]) - fmaxf(ax1, bx[j][0]), ih = fminf(ay2, bx[j][3]) - fmaxf(ay1, bx[j][1]);
+          const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+          const float ab = (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]);
+          if (inter / (aa + ab - inter) > iou_thr) { s = -INFINITY; sc[j * NG_T + t] = s; }
+        }
+        if (s > bs) { bs = s; br = j * NG_T + t; }       // (rows ascend with j: the first of equal scores stays)
+      }
+    }
+    if (kept >= max_det) break;                           // (uniform)
+    // workgroup argmax by (score descending, row ascending)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float os = __shfl_xor(bs, d, 64); const int orw = __shfl_xor(br, d, 64);
+      if (os > bs || (os == bs && orw < br)) { bs = os; br = orw; }
+    }
+    if (lane == 0) { red_s[wv] = bs; red_r[wv] = br; }
+    __syncthreads();
+    if (wv == 0) {
+      float s2 = lane < NG_T / 64 ? red_s[lane] : -INFINITY; int r2 = lane < NG_T / 64 ? red_r[lane] : 0x7fffffff;
+#pragma unroll
+      for (int d = 4; d >= 1; d >>= 1) {
+        const float os = __shfl_xor(s2, d, 64); const int orw = __shfl_xor(r2, d, 64);
+        if (os > s2 || (os == s2 && orw < r2)) { s2 = os; r2 = orw; }
+      }
+      if (lane == 0) kr = s2 > -INFINITY ? r2 : -1;
+    }
+    __syncthreads();
+    const int win = kr;
+    if (win < 0) break;                                   // (uniform)
+    if ((win & (NG_T - 1)) == t) {                        // the owner publishes the box and retires the candidate
+      const int jw = win / NG_T;
+#pragma unroll
+      for (int j = 0; j < NG_PER; ++j)
+        if (j == jw) { kb[0] = bx[j][0]; kb[1] = bx[j][1]; kb[2] = bx[j][2]; kb[3] = bx[j][3]; sc[j * NG_T + t] = -INFINITY; }
+      const float* p = pred + (int64_t)win * (5 + nc);
+      const float obj = p[4];
+      float best = -INFINITY; int bj = 0;
+      for (int c = 0; c < nc; ++c) { const float v = p[5 + c] * obj; if (v > best) { best = v; bj = c; } }
+      float* o = out + (int64_t)kept * 6;
+      o[0] = p[0] - p[2] / 2; o[1] = p[1] - p[3] / 2; o[2] = p[0] + p[2] / 2; o[3] = p[1] + p[3] / 2; o[4] = best; o[5] = (float)bj;
+    }
+    __syncthreads();
+    ax1 = kb[0]; ay1 = kb[1]; ax2 = kb[2]; ay2 = kb[3];
+    aa = (ax2 - ax1) * (ay2 - ay1);
+    have = true;
+    ++kept;
+  }
+  if (t == 0) count_all[blockIdx.x] = kept;
+}
+
 }  // namespace
 
 int im2col_nchw(const float* x, float* col, int B, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW, int kpad, hipStream_t s) {
@@ -374,6 +476,27 @@ int nms_yolo(const float* pred, int n, int nc, float conf_thres, float iou_thres
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, srt, counter, max_nms, iou_thres, mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, s, srt, counter, max_nms, max_det, mask, out, count);
   return check_launch("nms");
+}
+
+// B images, pred [B][n][5 + nc] -> out [B][max_det][6], count [B].  One launch of the greedy kernel when it applies (every candidate of an
+// image fits one workgroup and few boxes are kept), else the three-kernel path image by image (one workspace, stream order).
+bool nms_greedy_applies(int n, int max_det, int max_nms) { return n <= NG_T * NG_PER && n <= max_nms && max_det <= 128; }
+
+int nms_yolo_batch(const float* pred, int B, int n, int nc, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+                   float* out, int* count, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (B < 0 || n < 0 || nc < 1 || max_det < 1 || max_nms < 1) return fail(EFFOCR_EINVAL, "nms: bad sizes");
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f) || !(iou_thres >= 0.f && iou_thres <= 1.f)) return fail(EFFOCR_EINVAL, "nms: thresholds must lie in [0, 1]");
+  if (B == 0) return EFFOCR_OK;
+  if (n > 0 && nms_greedy_applies(n, max_det, max_nms)) {
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)B), dim3(NG_T), 0, s, pred, n, nc, conf_thres, iou_thres, max_det, max_wh, agnostic, out, count);
+    return check_launch("nms_greedy");
+  }
+  for (int b = 0; b < B; ++b) {
+    const int rc = nms_yolo(pred + (int64_t)b * n * (5 + nc), n, nc, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, out + (int64_t)b * max_det * 6,
+                            count + b, ws, ws_bytes, s);
+    if (rc) return rc;
+  }
+  return EFFOCR_OK;
 }
 
 }  // namespace effocr

@@ -251,6 +251,29 @@ class HipLocalizer:
                                           _lib.current_stream(self.device)), "effocr_nms")
         return out, cnt
 
+    def nms_batch_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False, out=None, cnt=None):
+        """pred [B, n, 5 + nc] (the images of one network call) -> (rows [B, max_det, 6], counts [B] int32) on the device, no
+        synchronisation: effocr_nms_batch — one launch for all images when max_det <= 128 and n <= 25600 (text lines), else the
+        per-image kernels back to back.  ``out`` / ``cnt``: slices of a caller's result to fill."""
+        if not (0 <= conf_thres <= 1):
+            raise AssertionError(f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0")
+        if not (0 <= iou_thres <= 1):
+            raise AssertionError(f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0")
+        pred = pred.to(self.device, torch.float32).contiguous()
+        B, n = int(pred.shape[0]), int(pred.shape[1])
+        if out is None:
+            out = torch.empty((B, max_det, 6), dtype=torch.float32, device=self.device)
+        if cnt is None:
+            cnt = torch.zeros(B, dtype=torch.int32, device=self.device)
+        assert out.is_contiguous() and cnt.is_contiguous() and out.shape == (B, max_det, 6) and cnt.shape == (B,)
+        need = int(self._L.effocr_nms_workspace_bytes(n, MAX_NMS))
+        with self._lock, torch.cuda.device(self.device):
+            ws = self._workspace("nms", need)
+            _lib.check(self._L.effocr_nms_batch(_lib.ptr(pred), B, n, self.nc, float(conf_thres), float(iou_thres), int(max_det), MAX_NMS, MAX_WH,
+                                                1 if agnostic else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(),
+                                                _lib.current_stream(self.device)), "effocr_nms_batch")
+        return out, cnt
+
     def nms(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False):
         """pred [n, 5 + nc] (one image) -> [m,6] device tensor, m <= max_det (non_max_suppression(...)[0])."""
         out, cnt = self.nms_async(pred, conf_thres, iou_thres, max_det, agnostic)
@@ -307,7 +330,7 @@ class EffLocalizer:
     def run_device(self, imgs, max_det=1000):
         """``run`` without the download: -> (rows [n, max_det, 6] float32, counts [n] int32), both on the device, nothing
         synchronised — rows[i, :counts[i]] = (x1, y1, x2, y2, conf, cls) of entry i.  The letterboxed images go through the network
-        in sub-batches of 16 and the per-image NMS launches are queued back to back on the current stream."""
+        in sub-batches of 16, each followed by ONE batched NMS call on the current stream."""
         eng = self._eng_net
         if not isinstance(imgs, (list, tuple)):
             imgs = [imgs]
@@ -319,8 +342,7 @@ class EffLocalizer:
         x = self._letterboxed(imgs)
         for b0 in range(0, n, 16):
             pred = eng.forward(x[b0:b0 + 16])
-            for i in range(pred.shape[0]):
-                eng.nms_async(pred[i], self._conf_thresh, self._iou_thresh, max_det=max_det, out=rows[b0 + i], cnt=counts[b0 + i:b0 + i + 1])
+            eng.nms_batch_async(pred, self._conf_thresh, self._iou_thresh, max_det=max_det, out=rows[b0:b0 + 16], cnt=counts[b0:b0 + 16])
         return rows, counts
 
     def run(self, imgs):

@@ -118,6 +118,25 @@ def test_nms_matches_oracle_exactly(dev, n, nc, conf, iou, max_det):
     assert torch.equal(agn, Y.non_max_suppression(pred[None], conf, iou, agnostic=True, max_det=max_det)[0])
 
 
+@pytest.mark.parametrize("B,n,nc,conf,iou,max_det", [(3, 2000, 2, 0.05, 0.45, 64), (3, 25200, 2, 0.01, 0.05, 64), (2, 300, 1, 0.5, 0.2, 5),
+                                                     (2, 64, 2, 0.999, 0.5, 10), (1, 1, 2, 0.0, 0.5, 10), (1, 25600, 3, 0.5, 0.6, 128),
+                                                     (2, 2000, 2, 0.05, 0.45, 1000), (2, 25601, 2, 0.97, 0.3, 16)])
+def test_nms_batch_matches_oracle_exactly(dev, B, n, nc, conf, iou, max_det):
+    """effocr_nms_batch — the one-launch greedy kernel (max_det <= 128, n <= 25600) and its fall-back to the per-image kernels —
+    against the restated non_max_suppression, image by image: identical rows, order and counts (duplicates, tied confidences,
+    a detector that fires on every anchor, the max_det cut)."""
+    sd = init_yolov5s_state_dict(nc, seed=0)
+    eng = HipLocalizer(sd, input_shape=(64, 64), device=dev)
+    pred = torch.stack([_random_pred(n, nc, seed=7 * b + n + nc) for b in range(B)])
+    for agnostic in (False, True):
+        rows, cnt = eng.nms_batch_async(pred.to(dev), conf, iou, max_det=max_det, agnostic=agnostic)
+        rows, cnt = rows.cpu(), cnt.cpu().tolist()
+        ref = Y.non_max_suppression(pred, conf, iou, agnostic=agnostic, max_det=max_det)
+        for b in range(B):
+            assert cnt[b] == ref[b].shape[0], (b, cnt[b], ref[b].shape)
+            assert torch.equal(rows[b, :cnt[b]], ref[b]), b
+
+
 def test_nms_argument_errors(dev):
     eng = HipLocalizer(init_yolov5s_state_dict(2, seed=0), input_shape=(64, 64), device=dev)
     with pytest.raises(AssertionError):
