@@ -49,6 +49,7 @@ struct MlpArgs {
   int no_tail_split;                // 1: single launch (A/B switch)
   int panel0, tail_rb, stagger_wgs, main_wgs; // set by the launcher
   int stagger;                      // > 0: the first round of workgroups starts spread over 32 x stagger clock ticks (see mlp_kernel.hpp)
+  int stagger_min_rounds;           // ... when the launch has at least this many rounds of CUs (0 = 4)
   // optional leading projection + residual (attn.proj): x <- x + A . Wp^T + bp, fused in front of the MLP.  Then Wpp is
   // Wp fragment-blocked with the rows of every 32-row block permuted, bp permuted alike.  b2_logical is the unpermuted
   // fc2 bias (tail reduction; always required).

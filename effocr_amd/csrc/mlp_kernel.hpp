@@ -893,7 +893,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   a.panel0 = main_panels;                                // first split panel
   a.main_wgs = main_panels;
   a.tail_rb = tail * 4;
-  a.stagger_wgs = main_panels >= 4 * slots ? slots : 0;  // (the spread costs ~0.4 panel times at the end of the launch: worth it from ~4 rounds on)
+  a.stagger_wgs = main_panels >= (a.stagger_min_rounds > 0 ? a.stagger_min_rounds : 4) * slots ? slots : 0;  // (the spread costs ~0.4 panel times at the end of the launch; measured worth it from 2 rounds on: api.hip)
   const dim3 grid((unsigned)(main_panels + (split > 1 ? tail * split : 0)));
   if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, PROJ>), grid, dim3(256), 0, s, a);
   else if (split == 2) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, PROJ>), grid, dim3(256), 0, s, a);
