@@ -36,6 +36,9 @@
 #ifndef MLP_SLICED
 #define MLP_SLICED 1                                     // bias + GELU of a chunk as single scalar instructions in the issue slots beside the MFMAs
 #endif
+#ifndef MLP_NT
+#define MLP_NT 15                                        // non-temporal: 1 row loads, 2 attention-fragment loads, 4 row stores, 8 second-output stores
+#endif
 #ifndef MLP_DMA_SPREAD
 #define MLP_DMA_SPREAD 1
 #endif
@@ -97,6 +100,15 @@ template <int DEG> struct ChunkOps {
     return k < NPARK ? NPARK : k;                          // the park ops all sit in phase B: phase A overwrites the accumulators
   }
 };
+
+template <int BIT, typename T> __device__ __forceinline__ T ld_act(const T* p) {
+  if constexpr ((MLP_NT & BIT) != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int BIT, typename T> __device__ __forceinline__ void st_act(T* p, const T& v) {
+  if constexpr ((MLP_NT & BIT) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 constexpr int MLP_PT = 128;                              // tokens per workgroup
 constexpr int MLP_STAGE = 16384;                         // bytes per ring stage: 4 row blocks x 8 k-chunks x 512 B
@@ -210,7 +222,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     for (int t = t0; t < t1; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        xv[4 * t + q] = *reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512);
+        xv[4 * t + q] = ld_act<1>(reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512));
   };
   if constexpr (PROJ) {
     load_rows(0, OT);
@@ -222,13 +234,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] = xv[4 * t + q][e];
     const char* ab = static_cast<const char*>(a.A) + rbc * KC * 512 + half * 512 + r31 * 16;
 #pragma unroll
-    for (int t = 0; t < NXF; ++t) xf[t] = *reinterpret_cast<const V8*>(ab + (size_t)t * 1024);
+    for (int t = 0; t < NXF; ++t) xf[t] = ld_act<2>(reinterpret_cast<const V8*>(ab + (size_t)t * 1024));
   } else {
 #pragma unroll
     for (int t = 0; t < NXF; ++t) {
       {
-      xv[2 * t] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half) * 512);
-      xv[2 * t + 1] = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half + 1) * 512);
+      xv[2 * t] = ld_act<1>(reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half) * 512));
+      xv[2 * t + 1] = ld_act<1>(reinterpret_cast<const f32x4*>(xb + (size_t)(4 * t + 2 * half + 1) * 512));
       }
     }
   }
@@ -789,7 +801,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       for (int q = 0; q < 4; ++q) {
         const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
         sm += (o[0] + o[1]) + (o[2] + o[3]);
-        *reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512) = o;
+        st_act<4>(reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512), o);
       }
     });
     MLP_STAMP_AT(9)
@@ -822,7 +834,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
                              (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
           }
           const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
-          *reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512) = o;
+          st_act<8>(reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512), o);
         }
       });
     }

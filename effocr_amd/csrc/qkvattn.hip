@@ -39,6 +39,9 @@
 #include <math.h>
 #include <type_traits>
 
+#ifndef QA_NT
+#define QA_NT 0                                          // non-temporal: 1 row loads, 2 output stores (both measured slower: the fused MLP reads the output next)
+#endif
 #ifndef QA_BARRIER_DRAIN
 #define QA_BARRIER_DRAIN 0
 #endif
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         const char* xb = static_cast<const char*>(a.xn) + (tok >> 5) * (int64_t)KC * 512 + (tok & 31) * 16 + half * 512;   // + compile-time offsets only
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
-          xf[tt][i] = *reinterpret_cast<const V8*>(xb + i * 1024);
+          xf[tt][i] = (QA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const V8*>(xb + i * 1024)) : *reinterpret_cast<const V8*>(xb + i * 1024);
         }
       }
     };
@@ -410,7 +413,8 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               const u32x2 lo = pack4<E>(o[db][8 * p] * inv, o[db][8 * p + 1] * inv, o[db][8 * p + 2] * inv, o[db][8 * p + 3] * inv);
               const u32x2 hi = pack4<E>(o[db][8 * p + 4] * inv, o[db][8 * p + 5] * inv, o[db][8 * p + 6] * inv, o[db][8 * p + 7] * inv);
               const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-              *reinterpret_cast<u32x4*>(ob + blk_off(tok0 + tq, h * 8 + db * 4 + 2 * p + half, D / 8)) = v;
+              u32x4* op = reinterpret_cast<u32x4*>(ob + blk_off(tok0 + tq, h * 8 + db * 4 + 2 * p + half, D / 8));
+              if (QA_NT & 2) __builtin_nontemporal_store(v, op); else *op = v;
             }
         }
       });
