@@ -499,6 +499,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
 // index fragment (one LDS read, two MFMA pairs), twice the MFMA work per byte — 64 queries against 1M x 384 is MFMA-bound at 0.31 ms
 // instead of 1.4 ms on the 128-query tile kernel.  The query images of both tiles (D * 256 bytes) leave room for ONE transpose
 // stage per wave instead of two (LDS operations of a wave execute in order, so re-writing the stage behind its reads is safe).
+#ifndef KNN_STREAM_NT
+#define KNN_STREAM_NT 1                                  // the index rows pass once: non-temporal loads
+#endif
 constexpr int KS_THREADS = 512;
 template <int KMAX, int NQT>
 __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
@@ -552,7 +555,11 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
     for (int i = 0; i < 4; ++i) {
       int row = r0i + 8 * i + (lane >> 3);
       row = row < a.N ? row : a.N - 1;                              // clamp: rows past the end are masked below
+#if KNN_STREAM_NT
+      r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + ((lane & 7) << 4)));
+#else
       r[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + ((lane & 7) << 4));
+#endif
     }
   };
   int fb = 0, fs = 0;                                               // (block, slab) of the next stage to fetch
