@@ -20,9 +20,13 @@
 // Weights stream through an 8-slot ring of 16 KB stages (32 cells = 4 row blocks x 64 k) by global_load_lds, six
 // stages ahead (LDS holds nothing else but the biases); both weight copies are fragment-blocked so a stage is a
 // verbatim copy of 512-byte HBM cells and every fragment read is conflict-free without swizzles.  As in gemm3 the
-// barrier sits in the MIDDLE of a stage, so the first fragments of stage s+1 are read under stage s's last MFMAs.  GELU of chunk c is software-pipelined under phase A of
-// chunk c+1 (pre-activations parked as packed 16-bit values), so the stream of MFMAs never waits for it:
-//     A(0) | A(1)+gelu(0) | B(0) | A(2)+gelu(1) | B(1) | ... | A(n-1)+gelu(n-2) | B(n-2) | gelu(n-1) | B(n-1)
+// barrier sits in the MIDDLE of a stage, so the first fragments of stage s+1 are read under stage s's last MFMAs.
+// The bias + GELU hand-over of chunk c is a list of single scalar instructions (ChunkOps below) hosted in the issue slots behind the
+// MFMAs of the two phases that follow its phase A, on one of two alternating register sets:
+//     A(0) | park(0) | A(1)+gelu(0) | { B(c-1)+ops(c)[first part] | A(c+1)+ops(c)[rest] } ... | B(n-2)+ops(n-1)[first part] | ops(n-1)[rest] | B(n-1)
+// (History, same-box A/B each: the round-2 form ran the GELU as 8-value bursts of packed FMAs behind single MFMAs — packed fp32 never
+// overlaps the matrix pipe, tools/ubench/mfma_fill.hip; slicing THAT form over the gaps was 1-2 % slower, parking half a chunk under
+// phase B's second k half 4 % slower; the scalar list is 7 % faster than the bursts.)
 // (kernel template + launcher; instantiated per operand type / projection flag in mlp_*.hip so that the four
 // variants compile in parallel: one translation unit took 200 s)
 #pragma once
@@ -33,17 +37,8 @@
 #ifndef MLP_BARRIER_DRAIN
 #define MLP_BARRIER_DRAIN 0
 #endif
-#ifndef MLP_SLICED
-#define MLP_SLICED 1                                     // bias + GELU of a chunk as single scalar instructions in the issue slots beside the MFMAs
-#endif
 #ifndef MLP_NT
 #define MLP_NT 15                                        // non-temporal: 1 row loads, 2 attention-fragment loads, 4 row stores, 8 second-output stores
-#endif
-#ifndef MLP_DMA_SPREAD
-#define MLP_DMA_SPREAD 1
-#endif
-#ifndef MLP_GELU_W
-#define MLP_GELU_W 8                                     // values per GELU unit (8: four packed chains, 16: eight)
 #endif
 
 namespace effocr {
@@ -292,21 +287,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // asm the DMA costs the compiler nothing; its completion is counted by hand anyway (stage_mid: vmcnt).  M0 = LDS base of the
   // pieces (saved / restored: the register is the compiler's), the s_nop is the M0-write -> LDS-DMA wait state.
   const unsigned sW_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sW;
-  auto issue_stage_asm = [&](int s) __attribute__((always_inline)) {                     // caller guarantees s < NS
-    const char* src = stage_src(s) + lane16;
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)((s & (R - 1)) * MLP_STAGE) + (unsigned)w * 4096u));   // (wave-uniform)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %2\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-  };
-  // one piece (MLP_DMA_SPREAD: the four pieces of a stage go out in four different MFMA gaps behind the barrier, so that the
+  // one piece (the four pieces of a stage go out in four different MFMA gaps behind the barrier, so that the
   // sixteen 1 KB requests of the workgroup do not hit the address unit in one burst)
   auto issue_piece_asm = [&](int s, auto I_) __attribute__((always_inline)) {
     constexpr int i = decltype(I_)::value;
@@ -448,9 +429,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #if MLP_BARRIER_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind this barrier is stage s-1's, whose fragment
 #endif                                                  // reads were all consumed by MFMAs before stage s began; the reads in flight here are stage s's
-#ifndef MLP_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
 #ifdef MLP_STAMP
     const unsigned long long t2_ = __builtin_amdgcn_s_memtime();
@@ -468,43 +447,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // pre-activations (bias added, rounded to the operand type: "parked"), then GELU'd IN PLACE, 4 values at a time.
   // (Two alternating sets, with the GELU spread over both phases, do not fit next to the 96 VGPRs of xn: spills.)
   struct HSet { u32x4 u[8]; };
-  // unit q = MLP_GELU_W values = that many / 2 independent v_pk_fma_f32 Horner chains kept in lock step (gelu_fold_n, common.hpp)
-  auto gelu_unit = [&](HSet& hs, auto Q) __attribute__((always_inline)) {     // Q: compile-time -> static register indices
-    typedef __attribute__((__vector_size__(8 * sizeof(E)))) E E8;
-    constexpr int u = decltype(Q)::value, NV = MLP_GELU_W / 8;                 // NV set entries (8 values each) per unit
-    float v[8 * NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const E8 pv = __builtin_bit_cast(E8, hs.u[NV * u + j]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[8 * j + e] = (float)pv[e];
-    }
-    gelu_fold_n<E, 8 * NV>(v);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const u32x2 o0 = pack4<E>(v[8 * j], v[8 * j + 1], v[8 * j + 2], v[8 * j + 3]);
-      const u32x2 o1 = pack4<E>(v[8 * j + 4], v[8 * j + 5], v[8 * j + 6], v[8 * j + 7]);
-      hs.u[NV * u + j] = u32x4{o0[0], o0[1], o1[0], o1[1]};
-    }
-  };
-  // acc1 (+ bias1 of chunk c) -> set, acc1 = 0.  Tile i, registers 8m..8m+7 = unit 2i+m.
-  auto park = [&](HSet& hs, int c) __attribute__((always_inline)) {
-    sfor<0, 8>([&](auto U) {                             // one unit (8 values) at a time: bounds the live temporaries
-      constexpr int u = decltype(U)::value, i = u >> 1, m = u & 1;
-      __builtin_amdgcn_sched_barrier(0);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + (c0 + c) * 128 + i * 32 + 8 * (2 * m) + 4 * half);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + (c0 + c) * 128 + i * 32 + 8 * (2 * m + 1) + 4 * half);
-      const u32x2 lo = pack4<E>(acc1[i][8 * m] + b0[0], acc1[i][8 * m + 1] + b0[1], acc1[i][8 * m + 2] + b0[2], acc1[i][8 * m + 3] + b0[3]);
-      const u32x2 hi = pack4<E>(acc1[i][8 * m + 4] + b1[0], acc1[i][8 * m + 5] + b1[1], acc1[i][8 * m + 6] + b1[2], acc1[i][8 * m + 7] + b1[3]);
-      const u32x4 p = {lo[0], lo[1], hi[0], hi[1]};
-      hs.u[u] = p;
-#pragma unroll
-      for (int r = 8 * m; r < 8 * m + 8; ++r) acc1[i][r] = 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-
-#if MLP_SLICED
   typedef GeluFit<E> GF;
   typedef ChunkOps<GF::DEG> CO;
   float gx[4], gu[4], gt[4], gp[4];                      // the quad in flight (one at a time: the list is sequential)
@@ -541,12 +483,9 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     constexpr int K0 = decltype(K0_)::value, K1 = decltype(K1_)::value, NG = decltype(NG_)::value, n = decltype(N_)::value;
     if constexpr (K1 > K0) {
       constexpr int lo = CO::first_op(K0, K1, NG, n), hi = CO::first_op(K0, K1, NG, n + 1);
-#ifndef MLP_ABL_NOOPS
       sfor<lo, hi>([&](auto K_) { gop(*hs, cb, K_); });
-#endif
     }
   };
-#endif
 
   // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
   // s+R-1 iff REM >= R-1 and prefetches stage s+1's fragments iff REM >= 1.  Compile-time so that the steady state
@@ -573,75 +512,17 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         constexpr int i = decltype(I)::value;
         mfma1(C4, I, wf.w[i]);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef MLP_ABL_NOLDS
         if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
         else if constexpr (next) wf.w[i] = *reinterpret_cast<const V8*>(stn + wo + (i * 8) * 512);
-#endif
-#ifndef MLP_ABL_NODMA
-#if MLP_DMA_SPREAD
-        if constexpr (more && c4 >= 2 && (i & 1) == 0) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});
-#else
-        if constexpr (more && c4 == 2 && i == 0) issue_stage_asm(s + R - 1);   // right behind the barrier: slot of stage s-1 is free
-#endif
-#endif
+        if constexpr (more && c4 >= 2 && (i & 1) == 0) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});   // behind the barrier: slot of stage s-1 is free
       });
     });
     ++s;
   };
   constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
 
-  // GELU half-units [U0, U1) of `gs` are placed in the MFMA shadows of a phase of NMM MFMAs, evenly spaced
-  // ---- phase A of a chunk: SA stages x 4 k16 steps x 4 tiles
-  auto phase_a = [&](auto AFTER, HSet* gs, auto U0, auto U1) __attribute__((always_inline)) {        // AFTER = ring stages that follow the phase
-    constexpr int NMM = SA * 16, u0 = decltype(U0)::value, nu = decltype(U1)::value - u0;
-    sfor<0, SA>([&](auto KS) {
-      constexpr int ks = decltype(KS)::value;
-      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
-      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
-        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
-        acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
-        if constexpr (nu > 0) {
-          static_assert(NMM % nu == 0, "mlp: GELU units must divide the phase's MFMAs");
-          constexpr int n = ks * 16 + c4 * 4 + i;        // MFMA index within the phase: unit n / SPU, slice n % SPU of it
-          constexpr int SPU = NMM / nu;
-          // The whole unit behind ONE MFMA.  (Spread over the unit's 12 MFMA gaps in steps of 4-8 VALU instructions — same
-          // arithmetic, no bursts — the launch was 1-2 % SLOWER, same-box A/B: the compiler scalarises most of the packed FMAs
-          // once the chains are cut by scheduling barriers, and pinning them as register pairs costs an s_nop per asm boundary.
-          // Also measured and dropped: phase B in (k half, group) order with the first 4 units of the NEXT chunk parked under its
-          // second k half — 7.25 -> 7.55 ms per 1024 crops, the longer live ranges cost more than the overlap wins.)
-          if constexpr (n % SPU == 0) {
-            __builtin_amdgcn_sched_barrier(0);
-            gelu_unit(*gs, std::integral_constant<int, u0 + n / SPU>{});
-          }
-        }
-      }, std::false_type{});
-    });
-  };
-  // ---- phase B of a chunk: (group g, k half kh) stages; B-operand = fragment 4*kh + c4 of `hs`
-  auto phase_b = [&](auto AFTER, const HSet& hs, HSet* gs, auto U0, auto U1) __attribute__((always_inline)) {
-    constexpr int NMM = SB * 16, u0 = decltype(U0)::value, nu = decltype(U1)::value - u0;
-    sfor<0, SB>([&](auto SBI) {
-      constexpr int sb = decltype(SBI)::value;
-      constexpr int g = sb >> 1, kh = sb & 1;
-      constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SB - 1 - sb);
-      ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
-        constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
-        const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
-        acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
-        if constexpr (nu > 0) {
-          constexpr int n = sb * 16 + c4 * 4 + i;
-          constexpr int k = (n * nu) / NMM;
-          if constexpr ((k * NMM + nu - 1) / nu == n && k < nu) {
-            __builtin_amdgcn_sched_barrier(0);
-            gelu_unit(*gs, std::integral_constant<int, u0 + k>{});
-          }
-        }
-      }, std::false_type{});
-    });
-  };
-
-#if MLP_SLICED
-  // ---- the same phases hosting ops [K0, K1) of the chunk with bias base cb on set hd
+  // ---- phase A of a chunk (SA stages x 4 k16 steps x 4 tiles) / phase B ((group g, k half kh) stages; B-operand = fragment 4 kh + c4 of `hs`),
+  // each hosting ops [K0, K1) of the chunk with bias base cb on set hd in the issue slots behind its MFMAs
   auto phase_a_h = [&](auto AFTER, HSet* hd, const int cb, auto K0_, auto K1_) __attribute__((always_inline)) {
     sfor<0, SA>([&](auto KS) {
       constexpr int ks = decltype(KS)::value;
@@ -669,7 +550,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       }, std::false_type{});
     });
   };
-#endif
 
   if constexpr (PROJ) {
     // ---- projection: outT[D x 32 tok] = x + bias + Wpp . a^T, (group g, k stage) ring stages; B-operand = attention fragments.
@@ -720,7 +600,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
   static_assert(NC >= 3, "mlp: at least three hidden chunks");
   typedef std::integral_constant<int, FAR> Far;
-#if MLP_SLICED
   // Schedule, same ring stream order.  TWO hand-over sets (chunk c uses set c & 1): while B(c-1) consumes one, the ops of chunk c
   // fill the other — its park ops and the first part of its GELU behind B(c-1)'s MFMAs, the rest behind A(c+1)'s:
   //   A(0) | park(0) | A(1)+gelu(0) | { B(c-1)+ops(c)[0,KB) | A(c+1)+ops(c)[KB,N) } c=1..NC-2 | B(NC-2)+ops(NC-1)[0,KB) | ops(NC-1)[KB,N) | B(NC-1)
@@ -754,26 +633,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   phase_b_h(std::integral_constant<int, SB>{}, S2[(NC - 2) & 1], &S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K0_{}, KB_{});   // B(NC-2)
   sfor<KB, CO::N>([&](auto K_) { gop(S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K_); });
   phase_b_h(std::integral_constant<int, 0>{}, S2[(NC - 1) & 1], nullptr, 0, K0_{}, K0_{});                     // B(NC-1)
-#else
-  typedef std::integral_constant<int, 0> U0_; typedef std::integral_constant<int, 64 / MLP_GELU_W> U16_;   // GELU units per chunk
-  HSet S;
-  phase_a(Far{}, nullptr, U0_{}, U0_{});                  // A(0)
-  park(S, 0);
-  MLP_STAMP_AT(6)
-#pragma unroll 1
-  for (int c = 1; c < NC - 1; ++c) {
-    phase_a(Far{}, &S, U0_{}, U16_{});                    // A(c) + gelu(c-1)
-    phase_b(Far{}, S, nullptr, U0_{}, U0_{});             // B(c-1)
-    park(S, c);
-  }
-  MLP_STAMP_AT(7)
-  phase_a(std::integral_constant<int, 2 * SB>{}, &S, U0_{}, U16_{});      // A(NC-1) + gelu(NC-2)
-  phase_b(std::integral_constant<int, SB>{}, S, nullptr, U0_{}, U0_{});   // B(NC-2)
-  park(S, NC - 1);
-  sfor<0, 64 / MLP_GELU_W>([&](auto Q) { gelu_unit(S, Q); });
-  phase_b(std::integral_constant<int, 0>{}, S, nullptr, U0_{}, U0_{});    // B(NC-1)
-
-#endif
   MLP_STAMP_AT(8)
   // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row (W2's
   // rows are permuted per 32: api.hip rowperm32).  Whole panels: acc2 already holds x + bias2 + fc2 — nothing is re-read.
