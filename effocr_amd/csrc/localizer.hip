@@ -53,6 +53,7 @@ struct effocr_localizer {
   size_t wbytes = 0;
   const char* wdev = nullptr;
   int64_t npred = 0;
+  int direct_stem = 1;                                   // 0: the stem through im2col + the 1x1 implicit GEMM (A/B)
   int bf16 = 0;                                          // 1: bf16-operand MFMAs for every convolution with an activation (Detect's 1x1 heads stay fp32)
 };
 
@@ -280,6 +281,7 @@ int effocr_localizer_upload(effocr_localizer_t* loc, void* weights_dev, size_t b
 int effocr_localizer_set_option(effocr_localizer_t* loc, const char* name, int value) {
   if (!loc || !name) return fail(EFFOCR_EINVAL, "localizer_set_option: NULL argument");
   if (std::string(name) == "bf16_operands") { loc->bf16 = value != 0; return EFFOCR_OK; }
+  if (std::string(name) == "direct_stem") { loc->direct_stem = value != 0; return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, std::string("localizer_set_option: unknown option '") + name + "'");
 }
 int64_t effocr_localizer_num_predictions(const effocr_localizer_t* loc) { return loc ? loc->npred : 0; }
@@ -309,6 +311,12 @@ int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int ba
       case OP_STEM: {
         const LConv& c = loc->convs[op.conv];
         const Buf o = loc->bufs[op.out.buf];
+        if (loc->direct_stem && c.k == 6 && c.stride == 2 && c.pad == 2 && c.cin == 3 && c.cout_pad == 32 && c.kpad >= 108) {
+          // (fp32 in both precision modes: 108 taps per pixel are VALU work, the operand rounding of the bf16 mode starts at layer 1)
+          if ((rc = stem6x6s2_nchw(x_dev, reinterpret_cast<const float*>(loc->wdev + c.w_off), c.kpad, reinterpret_cast<const float*>(loc->wdev + c.b_off),
+                                   P(op.out.buf), batch, loc->in_h, loc->in_w, o.H, o.W, o.C, op.out.off, c.act, s))) return rc;
+          break;
+        }
         if ((rc = im2col_nchw(x_dev, P(loc->stem_col), batch, 3, loc->in_h, loc->in_w, c.k, c.k, c.stride, c.pad, o.H, o.W, c.kpad, s))) return rc;
         ConvArgs a{};
         a.in = P(loc->stem_col); a.w = reinterpret_cast<const float*>(loc->wdev + c.w_off); a.bias = reinterpret_cast<const float*>(loc->wdev + c.b_off);

@@ -36,6 +36,69 @@ __global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restric
   col[id] = v;
 }
 
+// YOLOv5 stem Conv(3, 32, 6, 2, 2) + folded BN + SiLU straight from the NCHW input: out NHWC [B,OH,OW,out_ld] channels out_off .. +32.
+// The im2col detour wrote and re-read 128 fp32 per output pixel (1.7 GB per 16 letterboxed images: 0.88 ms + its GEMM); the layer is
+// 108 taps x 32 channels per pixel, i.e. VALU work: a thread owns TWO horizontally adjacent pixels (their 6-wide windows share 4 of 8
+// columns) x 32 channels = 64 accumulators, taps ascending (ky, kx, c) like the weight rows [co][(ky*6 + kx)*3 + c]; the weights sit
+// transposed in LDS ([tap][co]: every lane reads the same 16 bytes — broadcast reads).
+__global__ __launch_bounds__(256) void stem6x6s2_kernel(const float* __restrict__ x, const float* __restrict__ w, int w_ld, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int B, int H, int W, int OH, int OW, int out_ld, int out_off, int silu) {
+  __shared__ __attribute__((aligned(16))) float wt[108 * 32];
+  for (int i = threadIdx.x; i < 108 * 32; i += 256) { const int k = i >> 5, co = i & 31; wt[i] = w[(size_t)co * w_ld + k]; }
+  __syncthreads();
+  const int OW2 = (OW + 1) >> 1;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)B * OH * OW2) return;
+  const int ox = (int)(id % OW2) * 2, oy = (int)((id / OW2) % OH);
+  const int64_t b = id / ((int64_t)OW2 * OH);
+  float acc[2][32];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[p][co] = 0.f;
+  const int ix0 = ox * 2 - 2;
+#pragma unroll 1
+  for (int ky = 0; ky < 6; ++ky) {
+    const int iy = oy * 2 - 2 + ky;
+    const bool rowok = iy >= 0 && iy < H;
+    float v[3][8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* xr = x + ((b * 3 + c) * H + (rowok ? iy : 0)) * (int64_t)W;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int ix = ix0 + j; v[c][j] = (rowok && ix >= 0 && ix < W) ? xr[ix] : 0.f; }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 6; ++kx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* wr = wt + ((ky * 6 + kx) * 3 + c) * 32;
+        const float a0 = v[c][kx], a1 = v[c][kx + 2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[0][4 * q + e] = fmaf(a0, wv[e], acc[0][4 * q + e]); acc[1][4 * q + e] = fmaf(a1, wv[e], acc[1][4 * q + e]); }
+        }
+      }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (ox + p >= OW) break;
+    float* o = out + ((b * OH + oy) * (int64_t)OW + ox + p) * out_ld + out_off;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+      f32x4 r = {acc[p][4 * q] + bv[0], acc[p][4 * q + 1] + bv[1], acc[p][4 * q + 2] + bv[2], acc[p][4 * q + 3] + bv[3]};
+      if (silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = r[e] / (1.0f + expf(-r[e]));
+      }
+      *reinterpret_cast<f32x4*>(o + 4 * q) = r;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, int in_ld, int in_off, float* __restrict__ out, int out_ld,
                                                          int out_off, int B, int H, int W, int C) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -415,6 +478,15 @@ int im2col_nchw(const float* x, float* col, int B, int Cin, int H, int W, int KH
   if (kpad < KH * KW * Cin) return fail(EFFOCR_EINVAL, "im2col: padded K smaller than the tap count");
   hipLaunchKernelGGL(im2col_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, col, B, Cin, H, W, KH, KW, stride, pad, OH, OW, kpad);
   return check_launch("im2col_nchw");
+}
+
+int stem6x6s2_nchw(const float* x, const float* w, int w_ld, const float* bias, float* out, int B, int H, int W, int OH, int OW, int out_ld, int out_off,
+                   int silu, hipStream_t s) {
+  const int64_t total = (int64_t)B * OH * ((OW + 1) / 2);
+  if (total <= 0) return EFFOCR_OK;
+  if (w_ld < 108 || ((out_ld | out_off) & 3)) return fail(EFFOCR_EINVAL, "stem conv: weight rows of >= 108 taps, channel stride / offset multiples of 4");
+  hipLaunchKernelGGL(stem6x6s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, w_ld, bias, out, B, H, W, OH, OW, out_ld, out_off, silu);
+  return check_launch("stem6x6s2");
 }
 
 int upsample2x_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s) {

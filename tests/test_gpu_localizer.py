@@ -36,6 +36,11 @@ def test_network_matches_oracle(dev, shape, B):
     assert (err[..., :4].max() / ref[..., :4].abs().max()).item() < 2e-4
     assert err[..., 4:].max().item() < 2e-4
     assert torch.equal(got, eng.forward(x.to(dev)).cpu())                 # deterministic
+    eng.set_option("direct_stem", 0)                                      # the stem through im2col + implicit GEMM instead of the direct kernel
+    alt = eng.forward(x.to(dev)).cpu()
+    err = (alt - ref).abs()
+    assert (err[..., :4].max() / ref[..., :4].abs().max()).item() < 2e-4 and err[..., 4:].max().item() < 2e-4
+    assert (alt - got).abs().max().item() < 1e-2 * max(shape)             # two summation orders of the same layer
 
 
 @pytest.mark.parametrize("shape,B", [((640, 640), 1), ((64, 96), 3)])
