@@ -831,6 +831,7 @@ int effocr_knn_set_option(const char* name, int value) {
   if (std::string(name) == "force_tile") { knn_force_tile_kernel(value); return EFFOCR_OK; }
   if (std::string(name) == "wg_target") { knn_set_wg_target(value); return EFFOCR_OK; }
   if (std::string(name) == "two_pass_screen") { knn_two_pass_screen(value); return EFFOCR_OK; }
+  if (std::string(name) == "q16_tile") { knn_q16_tile(value); return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, std::string("knn_set_option: unknown option '") + name + "'");
 }
 

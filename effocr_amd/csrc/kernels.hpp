@@ -130,6 +130,7 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
 // bit-identical to knn_ip_topk.  xb16 = bf16 copy of xb (convert_bf16), xnorm_max >= every row's L2 norm.
 size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k);
 void knn_set_wg_target(int n);
+void knn_q16_tile(int on);            // A/B: 0 = <= 16 queries on the 32-wide streaming tile too (default 1: 16-wide tile, v_mfma_f32_16x16x4_f32)
 void knn_two_pass_screen(int on);     // A/B: 1 = the screened search collects candidates with a second bf16 scan (default 0: from pass 1's chunk lists)
 void knn_force_tile_kernel(int on);   // A/B: 1 = the 128-query tile kernel also for <= 32 queries (default 0: streaming kernel)
 size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k);   // byte offset of the int32 overflow flag in that workspace

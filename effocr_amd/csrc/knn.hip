@@ -33,6 +33,7 @@ using namespace tile128;
 
 int g_knn_wg_target = 1024;          // workgroups a launch aims for (2 resident per CU); knn_set_option("wg_target")
 bool g_knn_force_tile = false;        // A/B switch (tests): 1 = always the 128-query tile kernel
+bool g_knn_q16 = true;                // A/B switch (tests): 0 = calls of <= 16 queries on the 32-wide tile as well
 bool g_knn_two_pass = false;          // A/B switch (tests): 1 = screened search collects its candidates with a second scan of the index
 constexpr int ID_NONE = INT_MAX;          // internal sentinel id (ranks after every real id)
 constexpr int MAX_CHUNKS = 256;
@@ -503,7 +504,12 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
 #define KNN_STREAM_NT 1                                  // the index rows pass once: non-temporal loads
 #endif
 constexpr int KS_THREADS = 512;
-template <int KMAX, int NQT>
+// Q16 (<= 16 queries; NQT = 1): the query tile is 16 wide and the products run on v_mfma_f32_16x16x4_f32 — half the matrix time per index
+// byte of the 32-wide tile, which at <= 32 queries costs as much as the HBM stream itself (16 B/clk/CU); the instruction adds its four k
+// products in ascending k with one rounding each (tools/ubench/mfma16_order.hip: 256 of 256 results bit-identical to the fmaf chain), so
+// the scores stay those of oracle/flat_ip.c.  A: lane (row l & 15, k l >> 4) reads ITS 4 bytes of the transposed stage; B: LDS image
+// [m][k 0..3][16 queries]; C: lane holds query l & 15, rows 4 (l >> 4) + r of the 16-row group: four partial lists per query and wave.
+template <int KMAX, int NQT, bool Q16 = false>
 __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -514,12 +520,20 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   const float* Q = static_cast<const float*>(a.q);
   const float* X = static_cast<const float*>(a.xb);
   f32x2* sQ = reinterpret_cast<f32x2*>(smem);                       // [NQT][nm][2][32]
-  for (int id = tid; id < NQT * nm * 64; id += KS_THREADS) {
-    const int qt = id / (nm * 64), rem = id - qt * nm * 64;
-    const int q = qt * 32 + (rem & 31), h = (rem >> 5) & 1, m = rem >> 6;
-    f32x2 v = {0.f, 0.f};
-    if (q < a.B) { v[0] = Q[(int64_t)q * D + 4 * m + h]; v[1] = Q[(int64_t)q * D + 4 * m + 2 + h]; }
-    sQ[id] = v;
+  if constexpr (Q16) {
+    float* sQ1 = reinterpret_cast<float*>(smem);                    // [D / 4][4][16]
+    for (int id = tid; id < D * 16; id += KS_THREADS) {
+      const int q = id & 15, kk = id >> 4;                          // kk = 4 m + kq
+      sQ1[id] = q < a.B ? Q[(int64_t)q * D + kk] : 0.f;
+    }
+  } else {
+    for (int id = tid; id < NQT * nm * 64; id += KS_THREADS) {
+      const int qt = id / (nm * 64), rem = id - qt * nm * 64;
+      const int q = qt * 32 + (rem & 31), h = (rem >> 5) & 1, m = rem >> 6;
+      f32x2 v = {0.f, 0.f};
+      if (q < a.B) { v[0] = Q[(int64_t)q * D + 4 * m + h]; v[1] = Q[(int64_t)q * D + 4 * m + 2 + h]; }
+      sQ[id] = v;
+    }
   }
   __syncthreads();
 
@@ -573,6 +587,9 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
+  f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // Q16: row groups 0-15 / 16-31 of the block
+  const int q16 = lane & 15, kq = lane >> 4;
+  const float* qp16 = reinterpret_cast<const float*>(smem) + kq * 16 + q16;
   int sl = 0, r0 = row_lo + w * 32;
   const int wr = lane >> 3, wc = lane & 7;
   for (int t0 = 0; t0 < nst; t0 += P) {
@@ -586,6 +603,22 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
       }
       if (fb < nblk) fetch(rg[u], fb, fs);                           // the slot's next stage (P stages ahead)
       if (++fs == nsl) { fs = 0; ++fb; }
+      if constexpr (Q16) {
+        float xa[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const int row = 16 * g + q16;
+            xa[g][m] = *reinterpret_cast<const float*>(buf + row * 128 + ((m ^ (row & 7)) << 4) + kq * 4);
+          }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float qv = qp16[((sl + u) * 8 + m) * 64];
+          acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][m], qv, acc16[0], 0, 0, 0);
+          acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][m], qv, acc16[1], 0, 0, 0);
+        }
+      } else {
       f32x4 xv[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) xv[m] = *reinterpret_cast<const f32x4*>(buf + r31 * 128 + ((m ^ (r31 & 7)) << 4));
@@ -598,9 +631,34 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
           acc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? xv[m][3] : xv[m][2], qv[1], acc[qt], 0, 0, 0);
         }
       }
+      }
     }
     sl += P;
     if (sl == nsl) {
+      if constexpr (Q16) {
+        // C layout: col = query (lane & 15), rows 16 g + 4 (lane >> 4) + r, ascending with (g, r)
+        uint32_t hits = 0;
+        const float thr = ls[0][KMAX - 1];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = r0 + 16 * g + 4 * kq + r;
+            hits |= (n < a.N && acc16[g][r] > thr) ? (1u << (4 * g + r)) : 0u;
+          }
+        if (__any(hits != 0)) {
+#pragma unroll
+          for (int bsel = 0; bsel < 8; ++bsel) {
+            const bool mine = (hits >> bsel) & 1u;
+            if (__any(mine)) {
+              const int n = r0 + 16 * (bsel >> 2) + 4 * kq + (bsel & 3);
+              const float sc = acc16[bsel >> 2][bsel & 3];
+              if (mine) topk_insert<KMAX>(ls[0], li[0], sc, n);
+            }
+          }
+        }
+        acc16[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc16[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
       // C layout: col = query (r31), rows = index rows (r & 3) + 8 (r >> 2) + 4 half, ascending with r
 #pragma unroll
       for (int qt = 0; qt < NQT; ++qt) {
@@ -628,16 +686,25 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
       }
+      }
       sl = 0; r0 += WSTEP;
     }
   }
 
   // ---- merge the 16 partial lists of every query through LDS (the query image is dead)
   __syncthreads();
-  constexpr int NSRC = (KS_THREADS / 64) * 2;
-  float* mS = reinterpret_cast<float*>(smem);                       // [32 * NQT][NSRC][KMAX]
-  int* mI = reinterpret_cast<int*>(smem + 32 * NQT * NSRC * KMAX * 4);
-  {
+  constexpr int NSRC = (KS_THREADS / 64) * (Q16 ? 4 : 2);
+  constexpr int QW = Q16 ? 16 : 32;                                 // queries per tile
+  float* mS = reinterpret_cast<float*>(smem);                       // [QW * NQT][NSRC][KMAX]
+  int* mI = reinterpret_cast<int*>(smem + QW * NQT * NSRC * KMAX * 4);
+  if constexpr (Q16) {
+    const int src = w * 4 + kq;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      mS[(q16 * NSRC + src) * KMAX + t] = ls[0][t];
+      mI[(q16 * NSRC + src) * KMAX + t] = li[0][t];
+    }
+  } else {
     const int src = w * 2 + half;
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt)
@@ -648,7 +715,7 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
       }
   }
   __syncthreads();
-  if (tid < 32 * NQT && tid < a.B) {
+  if (tid < QW * NQT && tid < a.B) {
     const float* s0 = mS + tid * NSRC * KMAX;
     const int* i0 = mI + tid * NSRC * KMAX;
     int ptr[NSRC];
@@ -680,7 +747,7 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   }
 }
 
-template <int KMAX, int NQT>
+template <int KMAX, int NQT, bool Q16 = false>
 int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   KnnArgs a = a_in;
   constexpr int NBUF = NQT == 1 ? 2 : 1;
@@ -689,9 +756,9 @@ int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   if (s_bytes > 160 * 1024 || m_bytes > 160 * 1024) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim / k too large for the LDS image");
   const size_t lds = s_bytes > m_bytes ? s_bytes : m_bytes;
   // per launch: the attribute belongs to the (function, device) pair and a process may search on several GPUs; the call is cheap
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX, NQT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX, NQT, Q16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     return fail(EFFOCR_EHIP, "knn(stream): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-  hipLaunchKernelGGL((knn_stream_kernel<KMAX, NQT>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
+  hipLaunchKernelGGL((knn_stream_kernel<KMAX, NQT, Q16>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
   int rc = check_launch("knn_stream");
   if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
   hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
@@ -703,6 +770,14 @@ int launch_knn_stream_k(int kmax, int nqt, const KnnArgs& a, hipStream_t s) {
     switch (kmax) {
       case 1: return launch_knn_stream<1, 2>(a, s);
       case 16: return launch_knn_stream<16, 2>(a, s);
+    }
+    return fail(EFFOCR_EINVAL, "knn: internal");
+  }
+  if (a.B <= 16 && g_knn_q16) {
+    switch (kmax) {
+      case 1: return launch_knn_stream<1, 1, true>(a, s);
+      case 16: return launch_knn_stream<16, 1, true>(a, s);
+      case 32: return launch_knn_stream<32, 1, true>(a, s);
     }
     return fail(EFFOCR_EINVAL, "knn: internal");
   }
@@ -794,6 +869,7 @@ size_t knn_screen_workspace_bytes(int64_t B, int64_t N, int D, int k) {
 }
 void knn_force_tile_kernel(int on) { g_knn_force_tile = on != 0; }
 void knn_two_pass_screen(int on) { g_knn_two_pass = on != 0; }
+void knn_q16_tile(int on) { g_knn_q16 = on != 0; }
 void knn_set_wg_target(int n) { g_knn_wg_target = n < 1 ? 1 : n; }
 size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k) {
   if (B <= 0 || k <= 0) return 0;

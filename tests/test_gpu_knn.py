@@ -191,7 +191,7 @@ def test_screened_auto_threshold_and_invalidation(dev):
     assert (I2[:, 0].cpu() == torch.arange(3)).all()        # rows shifted down by one
 
 
-@pytest.mark.parametrize("B,N,D,k", [(1, 5000, 384, 10), (16, 70001, 384, 10), (32, 4096, 512, 1), (7, 200000, 768, 32), (32, 33333, 128, 16), (5, 4100, 1024, 10),
+@pytest.mark.parametrize("B,N,D,k", [(1, 5000, 384, 10), (16, 70001, 384, 10), (9, 40000, 256, 1), (16, 30011, 128, 32), (2, 1000000, 384, 10), (32, 4096, 512, 1), (7, 200000, 768, 32), (32, 33333, 128, 16), (5, 4100, 1024, 10),
                                      (64, 70001, 384, 1), (33, 66000, 384, 10), (64, 70000, 384, 16), (100, 66001, 384, 10), (128, 65536, 256, 10),
                                      (64, 66000, 768, 10), (40, 70000, 384, 32), (100, 20000, 384, 10)])
                                      # 33..128 queries against >= 65 536 rows: two query tiles per launch / slices of 32 (below: the tile kernel)
@@ -218,6 +218,13 @@ def test_streaming_kernel_small_batches_bit_exact(hip_lib, dev, B, N, D, k):
     finally:
         _lib.check(hip_lib.effocr_knn_set_option(b"force_tile", 0), "knn_set_option")
     assert torch.equal(It, Iv) and torch.equal(Dt.view(torch.int32), Dv.view(torch.int32))
+    if B <= 16:                                             # default: the 16-wide query tile (v_mfma_f32_16x16x4_f32); switch: the 32-wide one
+        _lib.check(hip_lib.effocr_knn_set_option(b"q16_tile", 0), "knn_set_option")
+        try:
+            D32, I32 = idx.search_device(Q.to(dev), k)
+        finally:
+            _lib.check(hip_lib.effocr_knn_set_option(b"q16_tile", 1), "knn_set_option")
+        assert torch.equal(I32, Iv) and torch.equal(D32.view(torch.int32), Dv.view(torch.int32))
     assert hip_lib.effocr_knn_set_option(b"nope", 1) == -1
 
 
