@@ -20,6 +20,9 @@
 #include <type_traits>
 
 
+#ifndef GEMM3_NT
+#define GEMM3_NT 3                                        // non-temporal: 1 = fp32 residual in / out (touched once), 2 = + the 16-bit outputs
+#endif
 namespace effocr {
 namespace {
 
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rv[i][q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.resid) + blk_off(mr, (nb + i * 32 + 8 * q) >> 2, g.N >> 2));
+          rv[i][q] = GEMM3_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.resid) + blk_off(mr, (nb + i * 32 + 8 * q) >> 2, g.N >> 2)))
+                              : *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.resid) + blk_off(mr, (nb + i * 32 + 8 * q) >> 2, g.N >> 2));
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -214,9 +218,10 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
           char* p = reinterpret_cast<char*>(out) + blk_off(mr, n / CH, g.N / CH) + (n % CH) * (int)sizeof(TO);
           if constexpr (sizeof(TO) == 4) {
             const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(p) = o;
+            if (GEMM3_NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = o;
           } else {
-            *reinterpret_cast<u32x2*>(p) = pack4<TO>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            const u32x2 o2 = pack4<TO>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            if (GEMM3_NT & 2) __builtin_nontemporal_store(o2, reinterpret_cast<u32x2*>(p)); else *reinterpret_cast<u32x2*>(p) = o2;
           }
         }
       }

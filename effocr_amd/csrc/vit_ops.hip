@@ -8,6 +8,12 @@
 #include <math.h>
 
 
+#ifndef ATT_NT
+#define ATT_NT 0                                          // attention (token-panel path / ViT-B): non-temporal 1 = qkv loads, 2 = output stores (both measured slower: 3.65 -> 3.9 ms)
+#endif
+#ifndef LN_NT
+#define LN_NT 1                                           // blocked LayerNorm: non-temporal 1 = row loads, 2 = stores
+#endif
 namespace effocr {
 namespace {
 
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __r
   const int c0 = wv * (D / 16) + part;
   f32x4 v[NQ];
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) v[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512);
+  for (int i = 0; i < NQ; ++i) v[i] = (LN_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512)) : *reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -78,9 +84,10 @@ __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __r
     const int c = c0 + 2 * i;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c * 4);
-    *reinterpret_cast<u32x2*>(ob + (size_t)(c >> 1) * 512) =
-        pack4<TO>((v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1],
-                  (v[i][2] - mean) * rstd * gm[2] + bt[2], (v[i][3] - mean) * rstd * gm[3] + bt[3]);
+    const u32x2 o = pack4<TO>((v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1],
+                              (v[i][2] - mean) * rstd * gm[2] + bt[2], (v[i][3] - mean) * rstd * gm[3] + bt[3]);
+    if (LN_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(ob + (size_t)(c >> 1) * 512));
+    else *reinterpret_cast<u32x2*>(ob + (size_t)(c >> 1) * 512) = o;
   }
 }
 
@@ -216,11 +223,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
     else return reinterpret_cast<const u32x4*>(qkv + (tok0 + t) * ld + sec * D + h * 64 + c8 * 8);
   };
 
+  auto ld_qkv = [&](const u32x4* p) -> u32x4 { return (ATT_NT & 1) ? __builtin_nontemporal_load(p) : *p; };   // (q, k, v rows are read once)
   auto load_q = [&](V8 (&q)[4], int qb) {
     int tq = qb * 32 + r31;
     tq = tq < T ? tq : T - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) q[ks] = __builtin_bit_cast(V8, *qkv_ptr(tq, 0, 2 * ks + half));
+    for (int ks = 0; ks < 4; ++ks) q[ks] = __builtin_bit_cast(V8, ld_qkv(qkv_ptr(tq, 0, 2 * ks + half)));
   };
   // K rows (zero rows beyond T) and V -> registers.  Every global load of the workgroup is issued before the
   // first LDS write: ONE exposed memory latency per workgroup instead of one per loop iteration (2.50 -> 2.01 ms;
@@ -235,15 +243,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
       const int id = tid + 256 * i, t = id >> 3, c = id & 7;
       const u32x4 z = {0u, 0u, 0u, 0u};
       kreg[i] = z;
-      if (t < T) kreg[i] = *qkv_ptr(t, 1, c);
+      if (t < T) kreg[i] = ld_qkv(qkv_ptr(t, 1, c));
     }
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
       const int id = tid + 256 * i, tp = id >> 3, c = id & 7, t0 = 2 * tp;
       const u32x4 z = {0u, 0u, 0u, 0u};
       v0reg[i] = z; v1reg[i] = z;
-      if (t0 < T) v0reg[i] = *qkv_ptr(t0, 2, c);
-      if (t0 + 1 < T) v1reg[i] = *qkv_ptr(t0 + 1, 2, c);
+      if (t0 < T) v0reg[i] = ld_qkv(qkv_ptr(t0, 2, c));
+      if (t0 + 1 < T) v1reg[i] = ld_qkv(qkv_ptr(t0 + 1, 2, c));
     }
   };
   // registers -> LDS: K row-major, V transposed: dword (d, tp) = {V[2tp][d], V[2tp+1][d]}
@@ -350,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const E* __restrict__
           const int d = db * 32 + 8 * q4 + 4 * half;
           u32x2* dst = reinterpret_cast<u32x2*>(orow + d);
           if constexpr (BLK) dst = reinterpret_cast<u32x2*>(reinterpret_cast<char*>(out) + blk_off(tok0 + tq, (h * 64 + db * 32 + 8 * q4) / 8, D / 8) + half * 8);
-          *dst =
-              pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+          const u32x2 ov = pack4<E>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv, o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+          if (ATT_NT & 2) __builtin_nontemporal_store(ov, dst); else *dst = ov;
         }
     }
     if (more) {
