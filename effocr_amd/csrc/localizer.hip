@@ -221,7 +221,12 @@ constexpr size_t LOC_SPLIT_BYTES = (size_t)16 << 20;   // split-K scratch of con
 struct LWs { std::vector<size_t> off; size_t split, total; };
 LWs localizer_ws(const effocr_localizer* e, int B) {
   LWs w; size_t off = 0;
-  for (const Buf& b : e->bufs) { w.off.push_back(off); off = align_up(off + (size_t)B * b.H * b.W * b.C * 4, 256); }
+  for (size_t i = 0; i < e->bufs.size(); ++i) {
+    const Buf& b = e->bufs[i];
+    w.off.push_back(off);
+    if ((int)i == e->stem_col && e->direct_stem) continue;   // the im2col rows of the stem (840 MB at 16 x 640 x 640) exist only on the A/B path
+    off = align_up(off + (size_t)B * b.H * b.W * b.C * 4, 256);
+  }
   w.split = off; off += LOC_SPLIT_BYTES;
   w.total = off;
   return w;
