@@ -37,6 +37,9 @@
 #ifndef MLP_BARRIER_DRAIN
 #define MLP_BARRIER_DRAIN 0
 #endif
+#ifndef MLP_ROWS_LATE
+#define MLP_ROWS_LATE 1                                  // rows of output group g+1 requested at the start of group g of the projection
+#endif
 #ifndef MLP_NT
 #define MLP_NT 15                                        // non-temporal: 1 row loads, 2 attention-fragment loads, 4 row stores, 8 second-output stores
 #endif
@@ -219,14 +222,18 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       for (int q = 0; q < 4; ++q)
         xv[4 * t + q] = ld_act<1>(reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512));
   };
-  if constexpr (PROJ) {
-    load_rows(0, OT);
+  auto rows_to_acc = [&](auto T0_, auto T1_) __attribute__((always_inline)) {
+    constexpr int t0 = decltype(T0_)::value, t1 = decltype(T1_)::value;
+    load_rows(t0, t1);
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = t0; t < t1; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] = xv[4 * t + q][e];
+  };
+  if constexpr (PROJ) {
+    rows_to_acc(std::integral_constant<int, 0>{}, std::integral_constant<int, (MLP_ROWS_LATE && OG > 1) ? 4 : OT>{});
     const char* ab = static_cast<const char*>(a.A) + rbc * KC * 512 + half * 512 + r31 * 16;
 #pragma unroll
     for (int t = 0; t < NXF; ++t) xf[t] = ld_act<2>(reinterpret_cast<const V8*>(ab + (size_t)t * 1024));
@@ -559,6 +566,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     // reduction then adds no residual).
     sfor<0, OG>([&](auto G_) {
       constexpr int g = decltype(G_)::value;
+      if constexpr (MLP_ROWS_LATE && g + 1 < OG) {         // the next group's rows: requested now, landed under this group's MFMAs
+        rows_to_acc(std::integral_constant<int, 4 * (g + 1)>{}, std::integral_constant<int, 4 * (g + 2)>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
       sfor<0, SA>([&](auto KS) {
         constexpr int ks = decltype(KS)::value;
         ring_stage(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
