@@ -127,25 +127,25 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       default: __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0); break;
     }
   };
-  // Steady state: the four pieces in ONE inline-asm statement.  hipcc treats __builtin_amdgcn_global_load_lds as an access to both
+  // Steady state: the pieces as inline asm.  hipcc treats __builtin_amdgcn_global_load_lds as an access to both
   // address spaces ("pending flat") and turns its next LDS wait into s_waitcnt lgkmcnt(0): every piece issued between two MFMAs
   // drained the weight-fragment read issued a moment earlier (mlp_kernel.hpp has the numbers).  Completion is counted by hand
   // (vmcnt at the stage barrier) either way.  M0 = LDS base (saved / restored), s_nop = the M0-write -> LDS-DMA wait state.
   const unsigned sW_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sW;
-  auto issue_stage_asm = [&]() __attribute__((always_inline)) {
+  // one piece (the four pieces of a stage go out behind four different k16 steps after the barrier: the workgroup's sixteen 1 KB requests
+  // do not hit the address unit in one burst; tools/ubench/dma_cost.hip: 38.4 -> 36.6 cycles per MFMA for the ring alone)
+  auto issue_piece_asm = [&](auto P_) __attribute__((always_inline)) {
+    constexpr int pc = decltype(P_)::value;
     const int rb = (isec * D + ih * 64) / 32 + (w >> 1);
     const char* src = Wb + ((size_t)rb * KC + ikt * 16 + (w & 1) * 8) * 512 + lane16;
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)(islot * QA_STAGE) + (unsigned)(((w >> 1) * 16 + (w & 1) * 8) * 512)));   // (wave-uniform; the compiler may keep the ring counters in VGPRs)
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)(islot * QA_STAGE) + (unsigned)(((w >> 1) * 16 + (w & 1) * 8) * 512)));
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %2\n\t"
                  "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:%3\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                 : "=&s"(keep) : "v"(src), "s"(dst), "n"(pc * 1024) : "memory");
   };
   auto issue_advance = [&]() __attribute__((always_inline)) {
     islot = islot + 1 == R ? 0 : islot + 1;
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
                 acc[tt][1] = Op16<E>::mfma(xf[tt][kt * 8 + ks], f1, acc[tt][1]);
               }
             }
-            if constexpr (ks == 4) {                     // right behind the stage barrier: the slot of stage g-1 is free
-              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_stage_asm(); }
-              else if constexpr (!LAST || ft >= R - 1) issue_stage_asm();
+            if constexpr (ks >= 4) {                     // behind the stage barrier: the slot of stage g-1 is free
+              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_piece_asm(std::integral_constant<int, ks - 4>{}); }
+              else if constexpr (!LAST || ft >= R - 1) issue_piece_asm(std::integral_constant<int, ks - 4>{});
             }
             if constexpr (ks < 7 || sl + 1 < NSH) { f0 = n0; f1 = n1; }
           });
