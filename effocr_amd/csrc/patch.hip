@@ -18,6 +18,9 @@
 #include "kernels.hpp"
 #include <type_traits>
 
+#ifndef PATCH_NT
+#define PATCH_NT 1                                        // non-temporal: 1 = pixel loads (read once), 2 = row stores
+#endif
 namespace effocr {
 namespace {
 
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
     for (int c4 = 0; c4 < 4; ++c4) {
       const int kk = ks * 4 + c4;
       const float* q = xp + (int64_t)(kk >> 4) * plane + (int64_t)(kk & 15) * a.W;
-      sl.v[2 * c4] = *reinterpret_cast<const f32x4*>(q);
-      sl.v[2 * c4 + 1] = *reinterpret_cast<const f32x4*>(q + 4);
+      sl.v[2 * c4] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q);
+      sl.v[2 * c4 + 1] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4)) : *reinterpret_cast<const f32x4*>(q + 4);
     }
   };
   Slab sl[2];
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
         const f32x4 pv = *reinterpret_cast<const f32x4*>(posr + f0);
         const f32x4 o = {acc[t][4 * q] + bv[0] + pv[0], acc[t][4 * q + 1] + bv[1] + pv[1], acc[t][4 * q + 2] + bv[2] + pv[2],
                          acc[t][4 * q + 3] + bv[3] + pv[3]};
-        *reinterpret_cast<f32x4*>(ob + blk_off(orow, f0 >> 2, D / 4)) = o;
+        if (PATCH_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(ob + blk_off(orow, f0 >> 2, D / 4))); else *reinterpret_cast<f32x4*>(ob + blk_off(orow, f0 >> 2, D / 4)) = o;
       }
     });
   }
