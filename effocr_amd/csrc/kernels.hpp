@@ -110,6 +110,8 @@ bool panel_gemm_supported(int prec, int N, int K);
 int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s);
 
 // vit_ops.hip
+int reduce_layernorm_rows_blocked(int prec_out, float* x, int64_t rows, int D, const float* partial, const float* b2, int nparts, int tail_rb,
+                                  int add_x, const float* gamma, const float* beta, float eps, void* out, hipStream_t s);
 int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                            float eps, void* out, hipStream_t s);
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,

@@ -37,6 +37,9 @@
 #ifndef MLP_BARRIER_DRAIN
 #define MLP_BARRIER_DRAIN 0
 #endif
+#ifndef MLP_FUSED_REDUCE_LN
+#define MLP_FUSED_REDUCE_LN 1
+#endif
 #ifndef MLP_ROWS_LATE
 #define MLP_ROWS_LATE 1                                  // rows of output group g+1 requested at the start of group g of the projection
 #endif
@@ -782,15 +785,21 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 0, PROJ>), grid, dim3(256), 0, s, a);
   int rc = check_launch("mlp_fused");
   if (rc || split == 1) return rc;
+  const int64_t rb0 = (int64_t)main_panels * 4;          // first row block of the split panels
+  const int prec = std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16;
+  if (a.xn_out && MLP_FUSED_REDUCE_LN) {
+    // the split panels' reduction (parts in a fixed order + bias2 [+ x]) and the second output in ONE launch
+    return reduce_layernorm_rows_blocked(prec, reinterpret_cast<float*>(reinterpret_cast<char*>(a.x) + rb0 * (a.D / 4) * 512), (int64_t)a.M - rb0 * 32, a.D,
+                                         a.partial, a.b2_logical, split, a.tail_rb, PROJ ? 0 : 1, a.gamma_n, a.beta_n, a.eps,
+                                         static_cast<char*>(a.xn_out) + rb0 * (a.D / 8) * 512, s);
+  }
   const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical,
-                     (int64_t)main_panels * 4, a.tail_rb, a.D, split, (int64_t)a.M, PROJ ? 0 : 1);
+                     rb0, a.tail_rb, a.D, split, (int64_t)a.M, PROJ ? 0 : 1);
   rc = check_launch("mlp_reduce");
   if (rc || !a.xn_out) return rc;
   // second output for the split panels: the blocked LayerNorm kernel over their rows (a few thousand)
-  const int64_t rb0 = (int64_t)main_panels * 4;
-  return layernorm_rows_blocked(sizeof(E) == 2 && std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16,
-                                reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + rb0 * (a.D / 4) * 512), (int64_t)a.M - rb0 * 32, a.D,
+  return layernorm_rows_blocked(prec, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + rb0 * (a.D / 4) * 512), (int64_t)a.M - rb0 * 32, a.D,
                                 a.gamma_n, a.beta_n, a.eps, static_cast<char*>(a.xn_out) + rb0 * (a.D / 8) * 512, s);
 }
 

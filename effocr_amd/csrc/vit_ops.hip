@@ -45,11 +45,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // a contiguous 512-byte cell per half-wave).  Statistics: lane sums -> xor-32 exchange -> 4-wave exchange in
 // LDS; exact two-pass variance from the registers (same arithmetic order class as ln_apply).  A lane with
 // part = 0 / 1 holds the even / odd fp32 chunks = the low / high 8 bytes of one 16-byte output chunk.
-template <int D, typename TO>
+// REDUCE (the split tail panels of the fused MLP, mlp_kernel.hpp): the row is first ASSEMBLED from the parts' fp32 partial outputs
+// (fixed order) + bias2 (+ the old row), written back as the new residual row, then normalised — one launch instead of the
+// reduction kernel + this one (each launch of a small-batch forward costs ~7 us + its queue gap); the arithmetic of both is unchanged.
+struct LnReduce { const float* partial; const float* b2; float* xw; int nparts, tail_rb, add_x; };
+template <int D, typename TO, bool REDUCE = false>
 __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __restrict__ x, int64_t rows,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps,
-                                                                TO* __restrict__ out) {
+                                                                TO* __restrict__ out, LnReduce rd) {
   static_assert(sizeof(TO) == 2 && D % 32 == 0, "blocked LayerNorm writes 16-bit operands");
   constexpr int NQ = D / 32;                               // float4 chunks per lane
   __shared__ float red[2][4][32];
@@ -58,8 +62,30 @@ __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __r
   const char* xb = reinterpret_cast<const char*>(x) + rb * (D / 4) * 512 + tl * 16;
   const int c0 = wv * (D / 16) + part;
   f32x4 v[NQ];
+  if constexpr (REDUCE) {
+    const int64_t per_rb = (int64_t)(D / 4) * 32;
+    const bool live = rb * 32 + tl < rows;
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) v[i] = (LN_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512)) : *reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512);
+    for (int i = 0; i < NQ; ++i) {
+      const int c = c0 + 2 * i;
+      const int64_t rem = (int64_t)c * 32 + tl;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < rd.nparts; ++p) {
+        const f32x4 pv = reinterpret_cast<const f32x4*>(rd.partial)[((int64_t)p * rd.tail_rb + rb) * per_rb + rem];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += pv[e];
+      }
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(rd.b2 + c * 4);
+      f32x4 xo = {0.f, 0.f, 0.f, 0.f};
+      if (rd.add_x) xo = *reinterpret_cast<const f32x4*>(xb + (size_t)c * 512);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = acc[e] + bv[e] + (rd.add_x ? xo[e] : 0.f);
+      if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(rd.xw) + rb * (D / 4) * 512 + tl * 16 + (size_t)c * 512) = v[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) v[i] = (LN_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512)) : *reinterpret_cast<const f32x4*>(xb + (size_t)(c0 + 2 * i) * 512);
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -442,9 +468,10 @@ int launch_ln_blocked(const float* x, int64_t rows, int D, const float* gamma, c
                       hipStream_t s) {
   if (rows <= 0) return EFFOCR_OK;
   const dim3 grid((unsigned)((rows + 31) / 32));
-  if (D == 768) hipLaunchKernelGGL((layernorm_blocked_kernel<768, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out);
-  else if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out);
-  else if (D == 128) hipLaunchKernelGGL((layernorm_blocked_kernel<128, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out);
+  const LnReduce none{};
+  if (D == 768) hipLaunchKernelGGL((layernorm_blocked_kernel<768, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, none);
+  else if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, none);
+  else if (D == 128) hipLaunchKernelGGL((layernorm_blocked_kernel<128, TO>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, none);
   else return fail(EFFOCR_EUNSUPPORTED, "layernorm(blocked): embed dim must be 128, 384 or 768");
   return check_launch("layernorm_blocked");
 }
@@ -491,6 +518,28 @@ int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const floa
 }
 
 // x and out fragment-blocked (common.hpp blk_off); the x buffer must be addressable up to the next multiple of 32 rows
+template <typename TO>
+int launch_reduce_ln_blocked(float* x, int64_t rows, int D, const float* partial, const float* b2, int nparts, int tail_rb, int add_x,
+                             const float* gamma, const float* beta, float eps, TO* out, hipStream_t s) {
+  if (rows <= 0) return EFFOCR_OK;
+  const dim3 grid((unsigned)((rows + 31) / 32));
+  const LnReduce rd{partial, b2, x, nparts, tail_rb, add_x};
+  if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
+  else if (D == 128) hipLaunchKernelGGL((layernorm_blocked_kernel<128, TO, true>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
+  else return fail(EFFOCR_EUNSUPPORTED, "reduce + layernorm(blocked): embed dim must be 128 or 384");
+  return check_launch("reduce_layernorm_blocked");
+}
+
+// x (row block 0 = the first split panel) <- sum of the parts' partial outputs + bias2 (+ x), then its LayerNorm -> out, one launch
+int reduce_layernorm_rows_blocked(int prec_out, float* x, int64_t rows, int D, const float* partial, const float* b2, int nparts, int tail_rb,
+                                  int add_x, const float* gamma, const float* beta, float eps, void* out, hipStream_t s) {
+  switch (prec_out) {
+    case PREC_BF16: return launch_reduce_ln_blocked<__bf16>(x, rows, D, partial, b2, nparts, tail_rb, add_x, gamma, beta, eps, static_cast<__bf16*>(out), s);
+    case PREC_FP16: return launch_reduce_ln_blocked<_Float16>(x, rows, D, partial, b2, nparts, tail_rb, add_x, gamma, beta, eps, static_cast<_Float16*>(out), s);
+  }
+  return fail(EFFOCR_EUNSUPPORTED, "reduce + layernorm(blocked): 16-bit output only");
+}
+
 int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                            float eps, void* out, hipStream_t s) {
   switch (prec_out) {
