@@ -195,6 +195,7 @@ def run_recognizer_batches(char_crops, recognizer_engine, knn_func, candidate_ch
 # ---------------------------------------------------------------------------------------------------------------------
 # run_effocr: the whole ONNX driver (infer_effocr_onnx_multi.py:227-397) with every array-sized step on the device
 
+LARGE_NUMBER = 1_000_000_000          # infer_effocr_onnx_multi.py:46 (the torch driver's self.LARGE_NUM is 1_000_000, infer_effocr.py:239)
 COCO_JSON_SKELETON = {"info": {"": ""}, "licenses": [{"": ""}], "images": [], "annotations": [],
                       "categories": [{"id": 0, "name": "char"}]}          # utils/coco_utils.py:3-9
 
@@ -210,7 +211,7 @@ def word_end_indices(char_rights, word_lefts):
         cand = np.nonzero(rights > wl)[0]
         if cand.size:
             d = np.abs(wl - rights[cand])
-            if d.min() < 1_000_000:                                          # LARGE_NUMBER (:38)
+            if d.min() < LARGE_NUMBER:                                       # prev_dist starts at LARGE_NUMBER (:80)
                 closest = int(cand[int(np.argmin(d))])
         out.append(closest)
     return out

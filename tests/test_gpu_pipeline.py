@@ -146,3 +146,46 @@ def test_word_end_indices_keeps_the_reference_quirks():
     assert word_end_indices([10.0, 20.0, 30.0], [15.0, 25.0]) == [1, 2]
     assert R.en_preprocess([torch.tensor([0., 0, 10, 5]), torch.tensor([12., 0, 20, 5]), torch.tensor([22., 0, 30, 5])],
                            [torch.tensor([15., 0, 40, 5]), torch.tensor([25., 0, 40, 5])])[1] == [1, 2]
+
+
+class _PresetLocalizer:
+    """Stands in for EffLocalizer.run_device with the NMS rows of a fixture (keyed by the image bytes)."""
+    _model_backend = "yolo"
+
+    def __init__(self, images, rows, dev):
+        import hashlib
+        self._h = hashlib
+        self.dev = dev
+        self.by_img = {hashlib.sha256(im.tobytes()).hexdigest(): r for im, r in zip(images, rows)}
+
+    def run_device(self, imgs, max_det=1000):
+        out = torch.zeros(len(imgs), max_det, 6, device=self.dev)
+        cnt = torch.zeros(len(imgs), dtype=torch.int64, device=self.dev)
+        for j, im in enumerate(imgs):
+            r = self.by_img[self._h.sha256(im.cpu().numpy().tobytes()).hexdigest()]
+            out[j, :r.shape[0]] = r.to(self.dev)
+            cnt[j] = r.shape[0]
+        return out, cnt
+
+
+def test_run_effocr_reproduces_the_references_own_strings(dev):
+    """tests/golden/ref_run_effocr.*: strings produced by the REFERENCE's run_effocr (infer_effocr_onnx_multi.py:227-397, imported and
+    run by tests/golden/make_ref_golden.py over oracle-backed engines).  The product function — HIP crop transform, HIP encoder
+    (fp32 mode), HIP k-NN, device box arithmetic, product line assembly — fed the same NMS rows must return them character for
+    character: en with / without case repair, jp, vertical, empty crops (zero image), negative and out-of-image coordinates."""
+    from test_ref_golden import load_run_effocr_fixture
+    meta, index = load_run_effocr_fixture()
+    enc_sd = init_state_dict(meta["arch"], seed=meta["enc_seed"], img_size=meta["size"])
+    rec = EffRecognizer(enc_sd, arch=meta["arch"], precision="fp32", img_size=meta["size"], device=dev)
+    tf = PairedTransform(size=meta["size"], device=dev)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.train(torch.from_numpy(index))
+    total = 0
+    for c in meta["cases"]:
+        loc = _PresetLocalizer(c["images"], c["rows"], dev)
+        got, coco = run_effocr(c["images"], loc, rec, tf, c["lang"], vertical=c["vertical"], knn_func=knn, candidate_chars=meta["chars"],
+                               anchor_margin=c["anchor_margin"])
+        assert [got[i] for i in range(len(c["images"]))] == c["outputs"], (c["lang"], c["vertical"], got, c["outputs"])
+        assert coco == c["coco"]
+        total += sum(len(o) for o in c["outputs"] if o)
+    assert total > 300
