@@ -52,3 +52,36 @@ def en_postprocess(line_output, word_end_idx, charheights, charbottoms, anchor_m
         line = "".join(c.upper() if i in toupper and c in NONDISTINCT else c for i, c in enumerate(line))
         line = "".join("." if i in toperiod else c for i, c in enumerate(line))
     return line
+
+
+def infer_ref(image, result, lang, encode, knn_search, candidate_chars, transform, k=10, vertical=False, score_thresh=0.5,
+              score_thresh_word=0.5, anchor_margin=None, double_clipped=True):
+    """``EffOCR.infer`` from the localizer result on (infer_effocr.py:268-343, kNN branch :310-319), loop for loop over caller-supplied
+    oracle stages: ``transform(crop HWC uint8) -> [3,S,S]``, ``encode([n,3,S,S]) -> [n,D]``, ``knn_search(q [n,D] unit rows, k) -> ids [n,k]``.
+    Pinned to the reference by tests/golden/ref_run_effocr.json["infer"] (tests/test_ref_golden.py)."""
+    import numpy as np
+    import torch
+    if lang == "en":
+        char_bboxes, word_bboxes = result if isinstance(result[0], np.ndarray) else result[0]
+        char_bboxes, word_end_idx = en_preprocess(char_bboxes, word_bboxes, score_thresh, score_thresh_word, vertical)
+        word_bboxes = [list(w[:5]) for w in word_bboxes]
+    else:
+        char_bboxes, word_bboxes = sort_filter(result[0][0], score_thresh, vertical), None
+    H, W = image.shape[0], image.shape[1]
+    crops, heights, bottoms = [], [], []
+    for bbox in char_bboxes:
+        x0, y0, x1, y1 = map(int, map(round, bbox))
+        if double_clipped:
+            x0, y0, x1, y1 = (0, y0, W, y1) if vertical else (x0, 0, x1, H)
+        crops.append(transform(image[y0:y1, x0:x1, :]))
+        heights.append(bbox[3] - bbox[1]); bottoms.append(bbox[3])
+    if len(crops) == 0:
+        return None, None, None, None
+    emb = torch.nn.functional.normalize(encode(torch.stack(crops)), p=2, dim=1)
+    index_list = knn_search(emb, k).squeeze(-1).tolist()
+    nearest = [[candidate_chars[nn] for nn in nns] for nns in index_list]
+    output_nns = ["".join(chars).strip() for chars in nearest]
+    output = "".join(x[0] for x in nearest).strip()
+    if lang == "en":
+        output = en_postprocess(output, word_end_idx, heights, bottoms, anchor_margin=anchor_margin)
+    return output, output_nns, char_bboxes, word_bboxes

@@ -19,6 +19,8 @@ Recorded (reference file:line):
   EffOCR.en_preprocess / en_postprocess / jp_preprocess   infer_effocr.py:345-418 (torch driver form: scores + thresholds)
   EffLocalizer.xywh2xyxy / box_iou / letterbox geometry   onnx_engines/localizer_engine.py:107-169
   MedianPad pad geometry      utils/datasets_utils.py:67-88
+  EffOCR.infer                infer_effocr.py:255-343   the torch driver's per-line function incl. the kNN branch (:310-319, k = 10),
+                              unbound on a namespace, localizer call replaced by preset results, oracle-backed transform / encoder / k-NN
   run_effocr                  infer_effocr_onnx_multi.py:227-397   the WHOLE ONNX driver function, run over duck-typed engines whose
                               arithmetic is the oracle's (localizer = preset NMS rows, char_transform = oracle/crop_transform_ref,
                               recognizer = oracle/encoders_ref vit_tiny_test, knn_func = oracle/flat_ip.c): every line of the
@@ -373,54 +375,63 @@ def driver_cases():
     return cases
 
 
-def record_run_effocr(multi, tmpdir):
-    from PIL import Image
+def make_world():
+    """What the duck-typed engines share: oracle-backed transform / encoder / k-NN, the glyph index and its characters."""
     sys.path.insert(0, ROOT)
     from effocr_amd.weights import init_state_dict
     from oracle import knn_ref
     from oracle.crop_transform_ref import paired_transform
-    from oracle.encoders_ref import encoder_forward, l2_normalize
-    enc_sd = init_state_dict(ARCH, seed=SEED_ENC, img_size=SIZE)
+    from oracle.encoders_ref import encoder_forward
+    w = {"enc_sd": init_state_dict(ARCH, seed=SEED_ENC, img_size=SIZE), "seen": {}, "tag": (0, "en")}
+    rng = np.random.RandomState(5)
+    d = rng.standard_normal((32, 128)).astype(np.float32)
+    w["index"] = np.ascontiguousarray(d / np.linalg.norm(d, axis=1, keepdims=True))
+    w["chars"] = ["x"] * 32
 
     def char_transform(crop):                                       # stands in for create_paired_transform (torchvision absent)
         if crop.shape[0] == 0 or crop.shape[1] == 0:
             raise ValueError("empty crop")
+        w["seen"].setdefault(hashlib.sha256(crop.tobytes() + bytes(str(crop.shape), "ascii")).hexdigest(), (w["tag"], crop.copy()))
         return torch.from_numpy(np.asarray(paired_transform(crop, size=SIZE), dtype=np.float32))
+
+    def knn_func(embedding, k):                                     # PML FaissKNN.__call__ convention: (distances, indices) tensors
+        dd, ii = knn_ref.flat_ip_search(embedding.numpy(), w["index"], k)
+        return torch.from_numpy(dd), torch.from_numpy(ii)
+    w["char_transform"], w["knn_func"] = char_transform, knn_func
+    w["encode"] = lambda x: encoder_forward(ARCH, w["enc_sd"], x)
+    return w
+
+
+def build_index(w):
+    """Glyph index = the oracle's embeddings of EVERY distinct crop the reference cut in pass 1 (each query then finds itself with
+    score 1 and a top-1 margin of ~5e-3 — this miniature encoder's embeddings of different crops are 0.97-0.995 alike) + 16 random rows.
+    Rows of 'en' cases get Latin letters (cycling; candidate chars need not be unique), the others CJK."""
+    from oracle.encoders_ref import l2_normalize
+    items = sorted(w["seen"].items(), key=lambda kv: (kv[1][0][0], kv[0]))
+    xs = torch.stack([w["char_transform"](c) for _, (_, c) in items])
+    emb = l2_normalize(w["encode"](xs)).numpy()
+    rng = np.random.RandomState(6)
+    d = rng.standard_normal((16, emb.shape[1])).astype(np.float32)
+    w["index"] = np.ascontiguousarray(np.concatenate([emb, d / np.linalg.norm(d, axis=1, keepdims=True)]).astype(np.float32))
+    latin = "aenrwuosvcxzTHEQUICKBROWN-"
+    w["chars"] = [latin[i % 26] if tag[1] == "en" else chr(0x4E00 + i) for i, (_, (tag, _)) in enumerate(items)] + [chr(0x3041 + i) for i in range(16)]
+
+
+def record_run_effocr(multi, tmpdir, w):
+    from PIL import Image
+    char_transform, index = w["char_transform"], w["index"]
 
     class Rec:
         def run(self, batch):
             assert isinstance(batch, np.ndarray) and batch.shape[1:] == (3, SIZE, SIZE)
-            return [encoder_forward(ARCH, enc_sd, torch.from_numpy(batch)).numpy()]
+            return [w["encode"](torch.from_numpy(batch)).numpy()]
 
     cases = driver_cases()
-    # glyph index: the oracle's embeddings of a sample of the crops the reference would cut (self retrieval, a top-1 margin) + distractors
-    sample = []
-    for lang, vertical, lines in cases:
-        for (H, W, seed, r) in lines:
-            im = line_image(seed, H, W)
-            for row in r[r[:, 5] == 0][:6]:
-                b = torch.round(torch.from_numpy(row[:4]))
-                if vertical:
-                    c = im[int(round(b[1].item() * H / 640)):int(round(b[3].item() * H / 640)), 0:W]
-                else:
-                    c = im[0:H, int(round(b[0].item() * W / 640)):int(round(b[2].item() * W / 640))]
-                if c.shape[0] and c.shape[1]:
-                    sample.append(c)
-    sample = sample[:len(CHARS) - 20]
-    emb = l2_normalize(encoder_forward(ARCH, enc_sd, torch.stack([char_transform(c) for c in sample]))).numpy()
-    rng = np.random.RandomState(5)
-    distract = rng.standard_normal((len(CHARS) - emb.shape[0], emb.shape[1])).astype(np.float32)
-    distract /= np.linalg.norm(distract, axis=1, keepdims=True)
-    index = np.ascontiguousarray(np.concatenate([emb, distract]).astype(np.float32))
+    multi.knn_func, multi.candidate_chars = w["knn_func"], w["chars"]    # module globals in the reference (:372,375; set in __main__ :496-505)
 
-    def knn_func(embedding, k):                                     # PML FaissKNN.__call__ convention: (distances, indices) tensors
-        d, i = knn_ref.flat_ip_search(embedding.numpy(), index, k)
-        return torch.from_numpy(d), torch.from_numpy(i)
-    multi.knn_func, multi.candidate_chars = knn_func, CHARS         # module globals in the reference (:372,375; set in __main__ :496-505)
-
-    out_cases, arrays = [], {"index": index}
-    margins = []
+    out_cases, arrays = [], {}
     for ci, (lang, vertical, lines) in enumerate(cases):
+        w["tag"] = (ci, lang)
         paths, by_path = [], {}
         for li, (H, W, seed, r) in enumerate(lines):
             p = os.path.join(tmpdir, f"c{ci}_l{li}.png")
@@ -453,6 +464,74 @@ def record_run_effocr(multi, tmpdir):
     return out_cases, arrays
 
 
+def record_infer(single, tmpdir, w):
+    """``EffOCR.infer`` (infer_effocr.py:255-343), the torch driver's per-line function, called UNBOUND on a namespace that carries
+    what ``__init__`` sets (:217-241).  The localizer call (``inference_detector``, mmdet — absent) is replaced by preset mmdet-style
+    results; ``char_transform`` / ``recongizer_encoder`` / ``recognizer.knn_func`` are oracle-backed.  k = 10 (the default, :112,241)."""
+    from PIL import Image
+    char_transform, index, knn_func = w["char_transform"], w["index"], w["knn_func"]
+    rng = np.random.RandomState(91)
+    presets = {}
+    single.inference_detector = lambda localizer, im: presets[im]     # mmdet.apis.inference_detector (:262): the localizer stage
+    out = []
+    min_gap = 1.0
+    for ci, (lang, vertical, H, W, seed, nc, nw, margin) in enumerate([
+            ("en", False, 48, 400, 401, 11, 3, None), ("en", False, 64, 640, 402, 16, 4, 0.15), ("jp", False, 64, 640, 403, 13, 0, None),
+            ("jp", True, 400, 48, 404, 9, 0, None), ("en", False, 64, 640, 405, 0, 2, None), ("jp", False, 64, 640, 406, 5, 0, None)]):
+        w["tag"] = (100 + ci, lang)
+        im = line_image(seed, H, W)
+        p = os.path.join(tmpdir, f"infer_{ci}.png")
+        Image.fromarray(im).save(p)
+        span = H if vertical else W
+        pos = np.sort(rng.uniform(2, span - 30, nc))
+        cb = []
+        for q in pos:
+            a, b = q, q + rng.uniform(6, 24)
+            t0, t1 = rng.uniform(2, 10), rng.uniform(20, 40)
+            cb.append(([t0, a, t1, b] if vertical else [a, t0, b, t1]) + [rng.uniform(0.3, 0.99)])
+        wbx = [[pos[rng.randint(0, nc)] - rng.uniform(0.2, 3), 1.0, 0.0, 44.0, rng.uniform(0.3, 0.99)] for _ in range(nw)] if nc else \
+              [[5.0, 1.0, 50.0, 44.0, 0.9] for _ in range(nw)]
+        for w_ in wbx:
+            w_[2] = w_[0] + 70.0
+        cb = np.asarray(cb, np.float32).reshape(-1, 5)
+        cb = cb[rng.permutation(len(cb))]
+        wb = np.asarray(wbx, np.float32).reshape(-1, 5)
+        if ci == 5:
+            cb[0, :4] = [0.5, 2.0, 11.5, 30.0]                        # .5 -> Python's round: half to even (0, 12).  A NEGATIVE x0 would slice
+            #                                                           an empty crop, ValueError -> the reference calls exit(1) (:294-297)
+            cb[1, :4] = [630.0, 2.0, 660.0, 30.0]                     # beyond the right edge
+        presets[p] = [cb, wb] if lang == "en" else [[cb]]
+        ns = types.SimpleNamespace(d2=False, localizer=None, lang=lang, vertical=vertical, double_clipped=True, char_transform=char_transform,
+                                   N_classes=None, device="cpu", knn=10, candidate_chars=w["chars"], spell_check=False, LARGE_NUM=1_000_000,
+                                   anchor_multiplier=4, anchor_margin=margin, score_thresh=0.5, score_thresh_word=0.5,
+                                   recongizer_encoder=w["encode"],
+                                   recognizer=types.SimpleNamespace(knn_func=knn_func))
+        ns.en_preprocess = lambda r, ns=ns: single.EffOCR.en_preprocess(ns, r)
+        ns.jp_preprocess = lambda r, ns=ns: single.EffOCR.jp_preprocess(ns, r)
+        ns.en_postprocess = lambda *a, ns=ns: single.EffOCR.en_postprocess(ns, *a)
+        with contextlib.redirect_stdout(io.StringIO()):
+            output, output_nns, char_bboxes, word_bboxes = single.EffOCR.infer(ns, p)
+        if output_nns is not None:                                    # rank stability of the recorded top-10 lists under fp32 re-ordering
+            kept = [c for c in sorted(cb.tolist(), key=lambda x: x[1] if vertical else x[0]) if c[4] > 0.5]
+            xs = []
+            for bb in kept:
+                x0, y0, x1, y1 = map(int, map(round, bb[:4]))
+                xs.append(char_transform(im[y0:y1, 0:W] if vertical else im[0:H, x0:x1]))
+            from oracle.encoders_ref import l2_normalize
+            e = l2_normalize(w["encode"](torch.stack(xs))).numpy()
+            sc = np.sort(e @ index.T, axis=1)[:, ::-1][:, :11]
+            gaps = (sc[:, :-1] - sc[:, 1:]).min(1)
+            min_gap = min(min_gap, float(gaps.min()))
+        else:
+            gaps = np.zeros(0)
+        out.append({"lang": lang, "vertical": vertical, "H": H, "W": W, "seed": seed, "anchor_margin": margin,
+                    "sha256": hashlib.sha256(im.tobytes()).hexdigest(), "chars": cb.tolist(), "words": wb.tolist(),
+                    "output": output, "output_nns": output_nns, "rank_gap": [float(g) for g in gaps],
+                    "char_bboxes": None if char_bboxes is None else [[float(v) for v in b] for b in char_bboxes],
+                    "word_bboxes": None if word_bboxes is None else [[float(v) for v in b] for b in word_bboxes]})
+    return out, min_gap
+
+
 def main():
     import tempfile
     multi, single, EffLocalizer, du = import_reference()
@@ -476,14 +555,24 @@ def main():
         json.dump(fixture, f, ensure_ascii=False, separators=(",", ":"))
     np.savez_compressed(os.path.join(HERE, "ref_hostlogic.npz"), **arrays)
     with tempfile.TemporaryDirectory() as tmp:
-        cases, arr = record_run_effocr(multi, tmp)
+        w = make_world()
+        record_run_effocr(multi, tmp, w)       # pass 1: only to see which crops the reference cuts
+        record_infer(single, tmp, w)
+        build_index(w)
+        cases, arr = record_run_effocr(multi, tmp, w)
+        infer_cases, min_gap = record_infer(single, tmp, w)
+        arr["index"] = w["index"]
     with open(os.path.join(HERE, "ref_run_effocr.json"), "w") as f:
-        json.dump({"chars": CHARS, "arch": ARCH, "size": SIZE, "enc_seed": SEED_ENC, "cases": cases}, f, ensure_ascii=False, indent=0)
+        json.dump({"chars": w["chars"], "arch": ARCH, "size": SIZE, "enc_seed": SEED_ENC, "cases": cases,
+                   "infer": infer_cases, "infer_min_rank_gap": min_gap}, f, ensure_ascii=False, indent=0)
     np.savez_compressed(os.path.join(HERE, "ref_run_effocr.npz"), **arr)
     n = sum(len(v) for v in fixture.values() if isinstance(v, list))
     print(f"recorded {n} host-logic cases + {len(cases)} run_effocr runs from the imported reference")
     for c in cases:
         print(c["lang"], c["vertical"], c["anchor_margin"], c["outputs"])
+    for c in infer_cases:
+        print("infer", c["lang"], c["vertical"], c["anchor_margin"], repr(c["output"]), (c["output_nns"] or [None])[0])
+    print("infer min rank gap", min_gap)
 
 
 if __name__ == "__main__":

@@ -189,3 +189,41 @@ def test_run_effocr_reproduces_the_references_own_strings(dev):
         assert coco == c["coco"]
         total += sum(len(o) for o in c["outputs"] if o)
     assert total > 300
+
+
+def test_line_recognizer_reproduces_the_references_infer(dev):
+    """tests/golden/ref_run_effocr.json["infer"]: what the REFERENCE's ``EffOCR.infer`` (infer_effocr.py:255-343, kNN branch with the
+    default k = 10) returned over oracle-backed stages.  The product chain — LinePostprocessor, HIP crop transform, HIP encoder (fp32),
+    HIP IndexFlatIP top-10, ``indices_to_chars``, en_postprocess — returns the same transcription and boxes; the ten-neighbour strings
+    are compared in full wherever the recorded score gaps between successive ranks exceed 2e-5 (fp32 summation order cannot reorder
+    those), by their first character (the top-1, margin ~5e-3) otherwise."""
+    from effocr_amd.encoders import AutoEncoderFactory
+    from effocr_amd.pipeline import Recognizer
+    from effocr_amd.postprocess import LinePostprocessor, LineRecognizer
+    from test_ref_golden import infer_case_inputs, load_run_effocr_fixture
+    meta, index = load_run_effocr_fixture()
+    enc_sd = init_state_dict(meta["arch"], seed=meta["enc_seed"], img_size=meta["size"])
+    enc = AutoEncoderFactory("timm", meta["arch"], precision="fp32", img_size=meta["size"])()
+    enc.load_state_dict(enc_sd)
+    enc.to(dev).eval()
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
+    knn.train(torch.from_numpy(index))
+    rec = Recognizer(enc, knn, meta["chars"], knn=10)
+    full = 0
+    for c in meta["infer"]:
+        im, result = infer_case_inputs(c)
+        post = LinePostprocessor(lang=c["lang"], vertical=c["vertical"], anchor_margin=c["anchor_margin"])
+        out, nns, cb, wb = LineRecognizer(rec, post).infer(im, result)
+        assert out == c["output"], (out, c["output"])
+        if c["output_nns"] is None:
+            assert nns is None and cb is None
+            continue
+        assert [[float(v) for v in b] for b in cb] == c["char_bboxes"]
+        assert len(nns) == len(c["output_nns"])
+        for got, want, gap in zip(nns, c["output_nns"], c["rank_gap"]):
+            if gap > 2e-5:
+                assert got == want
+                full += 1
+            else:
+                assert got[:1] == want[:1]
+    assert full >= 20

@@ -205,3 +205,35 @@ def test_reference_run_effocr_replayed_through_the_oracle_driver():
         assert c["coco"] == {"info": {"": ""}, "licenses": [{"": ""}], "images": [], "annotations": [], "categories": [{"id": 0, "name": "char"}]}
         total += sum(len(o) for o in c["outputs"] if o)
     assert total > 300
+
+
+def infer_case_inputs(c):
+    im = line_image(c["seed"], c["H"], c["W"])
+    assert hashlib.sha256(im.tobytes()).hexdigest() == c["sha256"]
+    cb, wb = np.asarray(c["chars"], np.float32).reshape(-1, 5), np.asarray(c["words"], np.float32).reshape(-1, 5)
+    return im, ([cb, wb] if c["lang"] == "en" else [[cb]])
+
+
+def test_reference_infer_replayed_through_the_oracle():
+    """``EffOCR.infer`` (infer_effocr.py:255-343; kNN branch :310-319 with the default k = 10) as recorded from the reference over
+    oracle-backed stages: the oracle's restated chain returns the same transcription, the same ten-neighbour strings per glyph and
+    the same sorted / filtered boxes."""
+    from effocr_amd.weights import init_state_dict
+    from oracle import knn_ref
+    from oracle.crop_transform_ref import paired_transform
+    from oracle.encoders_ref import encoder_forward
+    from oracle.postprocess_ref import infer_ref
+    meta, index = load_run_effocr_fixture()
+    enc_sd = init_state_dict(meta["arch"], seed=meta["enc_seed"], img_size=meta["size"])
+    tf = lambda c: torch.from_numpy(np.asarray(paired_transform(c, size=meta["size"]), dtype=np.float32))
+    enc = lambda x: encoder_forward(meta["arch"], enc_sd, x)
+    knn = lambda q, k: torch.from_numpy(knn_ref.flat_ip_search(q.numpy(), index, k)[1])
+    seen = 0
+    for c in meta["infer"]:
+        im, result = infer_case_inputs(c)
+        out, nns, cb, wb = infer_ref(im, result, c["lang"], enc, knn, meta["chars"], tf, k=10, vertical=c["vertical"],
+                                     anchor_margin=c["anchor_margin"])
+        assert out == c["output"] and nns == c["output_nns"], (out, c["output"])
+        assert (cb is None and c["char_bboxes"] is None) or _floats(cb) == c["char_bboxes"]
+        seen += len(nns or [])
+    assert seen > 35
