@@ -13,7 +13,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # EFFOCR_HIP_LIB: A/B experiments only (tools/): another build of the SAME library; the product default is the in-tree .so
 SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip.so")
 
-ABI_VERSION = 4          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
+ABI_VERSION = 5          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
@@ -91,6 +91,7 @@ def _declare(lib):
         "effocr_localizer_forward": (i32, [vp, f32p, i32, f32p, vp, sz, vp]),
         "effocr_letterbox": (i32, [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32, i32, f32p, vp]),
         "effocr_nms_workspace_bytes": (sz, [i32, i32]),
+        "effocr_nms_batch_workspace_bytes": (sz, [i32, i32, i32]),
         "effocr_nms": (i32, [f32p, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
         "effocr_nms_batch": (i32, [f32p, i32, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
         "effocr_op_linear": (i32, [i32, i32, vp, vp, f32p, f32p, vp, i32, i32, i32, vp]),
@@ -105,7 +106,12 @@ def _declare(lib):
     }
     for name, (res, args) in sig.items():
         if os.environ.get("EFFOCR_HIP_LIB") and not hasattr(lib, name):
-            continue                       # A/B against an older build (tools/ab_bench.sh): symbols added since are simply absent
+            # A/B against an older build of the SAME ABI (tools/ab_bench.sh): a symbol added since is absent — calling it must fail
+            # loudly, never run with ctypes' default int signature
+            def _absent(*a, _n=name, **k):
+                raise EffOCRHipError(f"{_n} is not exported by the library EFFOCR_HIP_LIB points at")
+            setattr(lib, name, _absent)
+            continue
         fn = getattr(lib, name)            # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
@@ -126,8 +132,12 @@ def lib():
                     "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C effocr_amd/csrc`.")
             handle = ctypes.CDLL(SO_PATH)
             EXPORTS = sorted(_declare(handle).keys())
-            if handle.effocr_abi_version() != ABI_VERSION and not os.environ.get("EFFOCR_HIP_LIB"):
-                raise EffOCRHipError(f"libeffocr_hip.so ABI version {handle.effocr_abi_version()} != {ABI_VERSION} expected by this package: rebuild (make -C effocr_amd/csrc)")
+            # the override keeps the ABI check: an older-or-equal version only behind a second, explicit flag (A/B runs against the
+            # previous round's build), and never a newer or foreign one
+            got = handle.effocr_abi_version()
+            older_ok = bool(os.environ.get("EFFOCR_HIP_LIB")) and os.environ.get("EFFOCR_HIP_ALLOW_OLDER_ABI") == "1" and 0 < got <= ABI_VERSION
+            if got != ABI_VERSION and not older_ok:
+                raise EffOCRHipError(f"libeffocr_hip.so ABI version {got} != {ABI_VERSION} expected by this package: rebuild (make -C effocr_amd/csrc)")
             _lib = handle
     return _lib
 

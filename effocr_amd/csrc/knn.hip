@@ -852,7 +852,7 @@ struct ScreenWs { size_t part, qb, qnorm, adist, aidx, cnt, flag, cand, total; }
 ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   ScreenWs w; size_t off = 0;
   auto take = [&](size_t n) { const size_t o = off; off = align_up(off + n, 256); return o; };
-  w.part = take(knn_workspace_bytes(B, N, D, k));
+  w.part = take(knn_workspace_bytes(B, N, D, k < 16 ? 16 : k));   // pass 1 keeps >= 16-entry chunk lists (see knn_ip_topk_screened)
   w.qb = take((size_t)B * D * 2);
   w.qnorm = take((size_t)B * 4);
   w.adist = take((size_t)B * k * 4);
@@ -908,10 +908,14 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   a.B = (int)B; a.N = (int)N; a.D = D; a.k = k; a.ldo = k; a.ocol = 0; a.after_col = -1;
   a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
   a.pdist = reinterpret_cast<float*>(W + w.part);
-  a.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
   // pass 1: approximate top-k (only the k-th score is used)
+  // Its per-chunk lists are the candidate source below, and "the list is FULL of qualifying rows" is the overflow signal — with
+  // one-entry lists (k = 1: the driver's own call, infer_effocr_onnx_multi.py:372) the chunk that holds the approximate top-1 would
+  // always look full and every search would also run the gated exact pass.  Lists of >= 16 entries make a full list mean what it says.
+  const int kmax1 = (p.kmax < 16 && p.nchunks > 1 && !g_knn_two_pass) ? 16 : p.kmax;
+  a.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * kmax1 * 4, 128));
   a.q = qb; a.xb = xb16; a.dist = adist; a.idx = aidx;
-  if ((rc = launch_knn_k<__bf16>(p.kmax, a, s))) return rc;
+  if ((rc = launch_knn_k<__bf16>(kmax1, a, s))) return rc;
   // pass 2: every row whose approximate score is within 2*eps of the k-th approximate score.
   // |s^ - s| <= eps = c * |q| * |x|: operand rounding (2^-8 + 2^-16) plus fp32 accumulation of both chains (4 d 2^-24),
   // 1e-4 relative slack for the fp32 norms.  A true top-k row has s >= s_(k), hence s^ >= s_(k) - eps >= s^_(k) - 2 eps.
@@ -919,8 +923,7 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   a.adist = adist; a.qnorm = qnorm; a.eps_scale = 2.0f * c * xnorm_max; a.cand = cand; a.cnt = cnt; a.cap = RR_CAP;
   if (p.nchunks > 1 && !g_knn_two_pass) {                  // the candidates are already in pass 1's per-chunk lists
     const dim3 cg((unsigned)((B + 3) / 4));
-    switch (p.kmax) {
-      case 1: hipLaunchKernelGGL((knn_collect_lists_kernel<1>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+    switch (kmax1) {
       case 16: hipLaunchKernelGGL((knn_collect_lists_kernel<16>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
       default: hipLaunchKernelGGL((knn_collect_lists_kernel<32>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
     }

@@ -377,6 +377,7 @@ int effocr_letterbox(const uint8_t* image_dev, int height, int width, int64_t ro
 }
 
 size_t effocr_nms_workspace_bytes(int n, int max_nms) { return nms_workspace_bytes(n, max_nms); }
+size_t effocr_nms_batch_workspace_bytes(int n, int max_det, int max_nms) { return nms_greedy_applies(n, max_det, max_nms) ? 0 : nms_workspace_bytes(n, max_nms); }
 
 int effocr_nms(const float* pred_dev, int n, int num_classes, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
                float* out_dev, int* count_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {

@@ -552,7 +552,10 @@ int nms_yolo(const float* pred, int n, int nc, float conf_thres, float iou_thres
 
 // B images, pred [B][n][5 + nc] -> out [B][max_det][6], count [B].  One launch of the greedy kernel when it applies (every candidate of an
 // image fits one workgroup and few boxes are kept), else the three-kernel path image by image (one workspace, stream order).
-bool nms_greedy_applies(int n, int max_det, int max_nms) { return n <= NG_T * NG_PER && n <= max_nms && max_det <= 128; }
+// (Round 4: no max_det bound any more — the reference's own max_det is 1000 (localizer_engine.py:62) and the product default must take this
+// path.  Cost is kept x one pass (~2-3 us): a text line keeps tens of boxes; a pathological image that keeps all 1000 costs ~3 ms for the
+// whole batch, images side by side, where the per-image path takes 0.24 ms per image one after the other.)
+bool nms_greedy_applies(int n, int max_det, int max_nms) { (void)max_det; return n <= NG_T * NG_PER && n <= max_nms; }
 
 int nms_yolo_batch(const float* pred, int B, int n, int nc, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
                    float* out, int* count, void* ws, size_t ws_bytes, hipStream_t s) {

@@ -253,7 +253,7 @@ class HipLocalizer:
 
     def nms_batch_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False, out=None, cnt=None):
         """pred [B, n, 5 + nc] (the images of one network call) -> (rows [B, max_det, 6], counts [B] int32) on the device, no
-        synchronisation: effocr_nms_batch — one launch for all images when max_det <= 128 and n <= 25600 (text lines), else the
+        synchronisation: effocr_nms_batch — one launch for all images when n <= 25600 (any max_det; no workspace), else the
         per-image kernels back to back.  ``out`` / ``cnt``: slices of a caller's result to fill."""
         if not (0 <= conf_thres <= 1):
             raise AssertionError(f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0")
@@ -266,9 +266,9 @@ class HipLocalizer:
         if cnt is None:
             cnt = torch.zeros(B, dtype=torch.int32, device=self.device)
         assert out.is_contiguous() and cnt.is_contiguous() and out.shape == (B, max_det, 6) and cnt.shape == (B,)
-        need = int(self._L.effocr_nms_workspace_bytes(n, MAX_NMS))
+        need = int(self._L.effocr_nms_batch_workspace_bytes(n, int(max_det), MAX_NMS))      # 0: the one-launch greedy path
         with self._lock, torch.cuda.device(self.device):
-            ws = self._workspace("nms", need)
+            ws = self._workspace("nms", max(need, 256))
             _lib.check(self._L.effocr_nms_batch(_lib.ptr(pred), B, n, self.nc, float(conf_thres), float(iou_thres), int(max_det), MAX_NMS, MAX_WH,
                                                 1 if agnostic else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(),
                                                 _lib.current_stream(self.device)), "effocr_nms_batch")

@@ -217,6 +217,7 @@ def word_end_indices(char_rights, word_lefts):
     return out
 
 
+_PINNED_GUARD = threading.Lock()
 _PINNED = {}          # (device, bytes rounded up) -> pinned uint8 staging buffer of run_effocr's uploads (grow-only, one per size class)
 
 
@@ -240,23 +241,28 @@ def _upload_lines(imgs, dev):
     L, shape = len(imgs), tuple(imgs[0].shape)
     n = int(np.prod(shape))
     key = (str(dev), 1 << max(20, (L * n - 1).bit_length()))
-    ent = _PINNED.get(key)
-    if ent is None:
-        ent = _PINNED[key] = [torch.empty(key[1], dtype=torch.uint8).pin_memory(), None]
-    if ent[1] is not None:
-        ent[1].synchronize()                                                  # previous call's transfers (normally long done)
-    stage = ent[0][: L * n].view((L,) + shape)
-    stage_np = stage.numpy()
+    with _PINNED_GUARD:
+        ent = _PINNED.get(key)
+        if ent is None:
+            ent = _PINNED[key] = [torch.empty(key[1], dtype=torch.uint8).pin_memory(), None, threading.Lock()]
     out = torch.empty((L,) + shape, dtype=torch.uint8, device=dev)
-    # the pageable -> pinned memcpy is the slow leg (3 MB per 4096 x 256 line at one core's rate): four helper threads copy lines side
-    # by side (numpy releases the GIL for large copies), the DMA of line j goes out as soon as ITS copy has landed, in order
-    futs = [_copiers().submit(np.copyto, stage_np[j], im.cpu().numpy() if isinstance(im, torch.Tensor) else im) for j, im in enumerate(imgs)]
-    for j, f in enumerate(futs):
-        f.result()
-        out[j].copy_(stage[j], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    ent[1] = ev
+    # One caller at a time per staging buffer, from the wait for the previous call's transfers until THIS call's last DMA is enqueued
+    # and its event recorded: the engines are shareable across threads (a-8), and two run_effocr calls on one device must not memcpy
+    # into the buffer while the other's DMAs are still reading it.
+    with ent[2]:
+        if ent[1] is not None:
+            ent[1].synchronize()                                              # previous call's transfers (normally long done)
+        stage = ent[0][: L * n].view((L,) + shape)
+        stage_np = stage.numpy()
+        # the pageable -> pinned memcpy is the slow leg (3 MB per 4096 x 256 line at one core's rate): four helper threads copy lines
+        # side by side (numpy releases the GIL for large copies), the DMA of line j goes out as soon as ITS copy has landed, in order
+        futs = [_copiers().submit(np.copyto, stage_np[j], im.cpu().numpy() if isinstance(im, torch.Tensor) else im) for j, im in enumerate(imgs)]
+        for j, f in enumerate(futs):
+            f.result()
+            out[j].copy_(stage[j], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        ent[1] = ev
     return out
 
 

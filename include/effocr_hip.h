@@ -29,7 +29,7 @@ extern "C" {
 /* bumped whenever an exported signature or the meaning of an argument changes (round 1: 1; round 2 added
  * arguments to effocr_op_mlp_blocked without a bump — callers must treat 1 as "unknown layout"); a caller built
  * against another value must refuse to call into the library (effocr_amd/_lib.py does) */
-#define EFFOCR_ABI_VERSION 4
+#define EFFOCR_ABI_VERSION 5
 
 enum effocr_status {
   EFFOCR_OK = 0,
@@ -230,9 +230,11 @@ int effocr_nms(const float* pred_dev, int n, int num_classes, float conf_thres, 
                int agnostic, float* out_dev, int* count_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* The same for the `batch` images of one network call (the reference loops `for xi, x in enumerate(prediction)`,
  * localizer_engine.py:212): pred_dev [batch, n, 5 + num_classes] -> out_dev [batch, max_det, 6], count_dev [batch].
- * n <= 25600, n <= max_nms and max_det <= 128 (a text line: tens of glyphs out of thousands of anchors): ONE launch, one workgroup
- * per image, no workspace (workspace_dev may be NULL); otherwise the per-image path above, image after image on the stream, with
- * one workspace of effocr_nms_workspace_bytes(n, max_nms).  Identical rows either way. */
+ * n <= 25600 and n <= max_nms (any max_det since ABI 5: the reference's default is 1000): ONE launch, one workgroup per image, greedy
+ * keep-best / kill-overlaps rounds (cost = kept boxes x one pass over the candidates; a text line keeps tens), no workspace
+ * (workspace_dev may be NULL); otherwise the per-image path above, image after image on the stream, with one workspace.
+ * effocr_nms_batch_workspace_bytes says which: 0 = the one-launch path.  Identical rows either way. */
+size_t effocr_nms_batch_workspace_bytes(int n, int max_det, int max_nms);
 int effocr_nms_batch(const float* pred_dev, int batch, int n, int num_classes, float conf_thres, float iou_thres, int max_det, int max_nms,
                      float max_wh, int agnostic, float* out_dev, int* count_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 

@@ -174,6 +174,41 @@ def test_screened_search_non_unit_rows_ties_and_overflow(dev):
     assert Is[0, 0].item() == 100 and Is[2, 0].item() == 100 and Is[0, 1].item() == 5000      # duplicates: ascending id
 
 
+def _screen_flag(idx, n, k):
+    """Device overflow flag of the index's last screened search (the gated exact pass ran iff it is non-zero)."""
+    L = _lib.lib()
+    need = int(L.effocr_knn_screen_workspace_bytes(n, idx.ntotal, idx.d, k))
+    off = int(L.effocr_knn_screen_flag_offset(n, idx.ntotal, idx.d, k))
+    ws = idx._workspace(need)
+    torch.cuda.synchronize()
+    return int(ws[off:off + 4].view(torch.int32).item())
+
+
+@pytest.mark.parametrize("k", [1, 10, 16])
+def test_screened_search_does_not_fall_back_on_benign_queries(dev, k):
+    """k = 1 is the ONNX driver's own call (infer_effocr_onnx_multi.py:372) and run_effocr's: a benign screened search (every query a
+    noisy copy of one row, no near-duplicate clusters) must finish WITHOUT raising the overflow flag — i.e. without also running the
+    gated exact pass — and 'auto' screening must stay on over many calls."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator(device=dev).manual_seed(11 + k)
+    N, D, B = 150_000, 384, 256
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    pick = torch.randint(0, N, (B,), generator=g, device=dev)
+    Q = torch.nn.functional.normalize(X[pick] + 0.05 * torch.randn(B, D, generator=g, device=dev), dim=1)
+    idx = IndexFlatIP(D, device=dev, screen="auto")
+    idx.add(X)
+    assert idx._use_screen(k, B)
+    ex = IndexFlatIP(D, device=dev, screen=False)
+    ex.add(X)
+    De, Ie = ex.search_device(Q, k)
+    for _ in range(6):
+        Ds, Is = idx.search_device(Q, k)
+        assert _screen_flag(idx, B, k) == 0
+        assert torch.equal(Ie, Is) and torch.equal(De.view(torch.int32), Ds.view(torch.int32))
+    idx._poll_overflow()
+    assert idx.screen == "auto" and idx.screen_overflows == 0
+
+
 def test_screened_auto_threshold_and_invalidation(dev):
     from effocr_amd.knn import IndexFlatIP
     idx = IndexFlatIP(128, device=dev)
