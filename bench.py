@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel-class table to stderr")
+    ap.add_argument("--verify", action="store_true", help="N>1: check the all-gathered ids against rank 0 encoding every slice itself (exit 1 on mismatch)")
     return ap.parse_args()
 
 
@@ -227,10 +228,17 @@ def main():
     knn.train(index_cpu)
     from effocr_amd.dist import shard_bounds
     scaling = a.scaling if a.scaling != "auto" else ("strong" if world > 1 else "weak")
-    gx = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x_full = torch.randn(a.batch, 3, 224, 224, generator=gx, device=dev)     # resident in HBM
+    # strong scaling (BASELINE configs[2]): THE SAME 1024 crops on every rank (rank-independent seed), rank r encodes rows
+    # shard_bounds(1024, r, N) of them; weak scaling: 1024 crops of its own per rank (seed + rank)
+    gx = torch.Generator(device=dev).manual_seed(1000)
+    x_same = torch.randn(a.batch, 3, 224, 224, generator=gx, device=dev)     # resident in HBM
     lo, hi = shard_bounds(a.batch, rank, world)
-    x_shard = x_full[lo:hi]                                                  # strong: this rank's slice of the 1024 crops
+    x_shard = x_same[lo:hi]                                                  # strong: this rank's slice of the 1024 crops
+    if world > 1:
+        gw = torch.Generator(device=dev).manual_seed(1000 + rank)
+        x_full = torch.randn(a.batch, 3, 224, 224, generator=gw, device=dev)
+    else:
+        x_full = x_same
 
     def make_step(x, n_total):
         def step():
@@ -295,6 +303,28 @@ def main():
         other = {"scaling": "weak" if scaling == "strong" else "strong", "value": round(on * a.steps / odt, 1), "unit": "glyph-crops/s",
                  "ms_per_step": round(1e3 * odt / a.steps, 3), "global_batch": on}
 
+    verify = None
+    if a.verify and world > 1:
+        # the gathered ids of the STRONG step against rank 0 alone: rank 0 encodes every rank's slice by itself, at that slice's own call
+        # size (kernel selection follows the call size, so the per-slice results are reproducible bit for bit), in rank order
+        sstep = step if scaling == "strong" else make_step(x_shard, a.batch)
+        got = sstep()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            parts = []
+            for r in range(world):
+                l, h = shard_bounds(a.batch, r, world)
+                parts.append(knn(enc.forward(x_same[l:h], normalize=True), k=a.k)[1])
+            want = torch.cat(parts)
+            whole = knn(enc.forward(x_same, normalize=True), k=a.k)[1]
+            verify = {"gathered_ids_equal_rank0_per_slice": bool(torch.equal(got, want)), "rows": int(got.shape[0]),
+                      "top1_agreement_with_one_1024_crop_call": round(float((got[:, 0] == whole[:, 0]).float().mean().item()), 4)}
+        flag = torch.tensor([1 if (verify is None or verify["gathered_ids_equal_rank0_per_slice"]) else 0], device=dev)
+        dist.broadcast(flag, src=0)
+        verify_ok = bool(flag.item())
+    else:
+        verify_ok = True
+
     if rank == 0:
         value = n_total * a.steps / dt
         per_rank = f"{hi - lo} of {a.batch} crops per GPU (rows shard_bounds(B, rank, N))" if scaling == "strong" else f"{a.batch} crops per GPU"
@@ -312,6 +342,8 @@ def main():
         }
         if other:
             line[other["scaling"]] = other
+        if verify is not None:
+            line["verify"] = verify
         if dom and dom in prof and prof[dom]["launches"]:
             p = prof[dom]
             sec = p["ms"] * 1e-3 / p["launches"]
@@ -337,7 +369,7 @@ def main():
                 line["c3_shard_proxy"] = shard_proxy_extras(a, enc, knn, dev)
                 line["small_batch"] = small_batch_extras(a, enc, knn, sd, dev)
                 if a.arch == "vit_small_patch16_224":
-                    del enc, x_full, x_shard
+                    del enc, x_full, x_shard, x_same
                     torch.cuda.empty_cache()
                     line["c1"] = c1_extras(a, dev)
                     line["c4"] = c4_extras(a, dev)
@@ -351,6 +383,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not verify_ok:
+        raise SystemExit("bench.py --verify: the gathered ids differ from rank 0's own per-slice results")
 
 
 def _time_gpu(fn, dev, iters, warm=2):
@@ -453,8 +487,39 @@ def small_batch_extras(a, enc, knn, sd, dev):
         by = N * D * 4.0
         rows[f"B{B}"] = {"exact_ms": round(1e3 * te, 3), "exact_hbm_frac": round(by / te / 8.0e12, 4),
                          "exact_mfma_fp32_frac": round(2.0 * B * N * D / te / 157.3e12, 4),
-                         "screened_ms": round(1e3 * ts, 3), "screened_hbm_frac_bf16_two_passes": round(2 * N * D * 2.0 / ts / 8.0e12, 4)}
+                         "screened_ms": round(1e3 * ts, 3), "screened_hbm_frac_bf16_one_scan": round(N * D * 2.0 / ts / 8.0e12, 4)}
     out["knn_1M_rows"] = {"index": f"{N} x {D} fp32 ({N * D * 4 / 1e9:.2f} GB)", "k": a.k, "hbm_peak_GBps": 8000, **rows}
+    out["knn_roofline"] = knn_stream_roofline(idx, a.k, dev)
+    return out
+
+
+def knn_stream_roofline(idx, k, dev, batches=(1, 16)):
+    """Roofline-shaped records of the HBM-bound k-NN regime (B <= 16 against a large index; north_star's ">= 60 % of HBM peak on
+    the k-NN kernel"): the exact streaming search (`knn_stream_kernel`, 16-query tile + its merge) over an index resident in HBM, timed with
+    events ON THE LAUNCH STREAM (torch's current stream is the stream the library launches on) around each of `iters` searches.
+    achieved = algorithmic bytes (index once: N * D * 4; + queries + results) / mean search time; peak 8 TB/s."""
+    was = idx.screen
+    idx.screen = False
+    N, D = idx.ntotal, idx.d
+    g = torch.Generator(device=dev).manual_seed(5)
+    out = []
+    for B in batches:
+        q = torch.nn.functional.normalize(torch.randn(B, D, generator=g, device=dev), dim=1)
+        for _ in range(3):
+            idx.search_device(q, k)
+        iters = 20
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for e0, e1 in evs:
+            e0.record()
+            idx.search_device(q, k)
+            e1.record()
+        torch.cuda.synchronize(dev)
+        us = sum(e0.elapsed_time(e1) for e0, e1 in evs) / iters * 1e3
+        by = N * D * 4.0 + B * D * 4.0 + B * k * 12.0
+        out.append({"bound": "hbm", "kernel": "knn_stream_kernel<16-query tile> + merge (exact fp32 search)", "queries": B, "index": f"{N} x {D} fp32",
+                    "bytes_per_launch": by, "avg_launch_us": round(us, 1), "launches": iters, "achieved": round(by / us / 1e3, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(by / (us * 1e-6) / 8.0e12, 4)})
+    idx.screen = was
     return out
 
 
@@ -514,7 +579,9 @@ def c4_extras(a, dev):
             "encoder_mfma_frac": round(1024 * (FLOP_PER_CROP[arch] - (PRUNED_FLOP_PER_CROP[arch] if "cls_fc1_gelu" in table else 0.0)) / te / MFMA_PEAK[a.precision], 4),
             "encoder_mfma_frac_at_model_flops": round(1024 * FLOP_PER_CROP[arch] / te / MFMA_PEAK[a.precision], 4),
             "kernel_TFLOPs": lin, "knn_ms": round(1e3 * tk, 3),
-            "knn_hbm_frac_bf16_two_passes": round(2 * N * D * 2.0 / tk / 8.0e12, 4), "knn_mfma_bf16_frac": round(2 * 2.0 * 1024 * N * D / tk / 2.5e15, 4)}
+            # the screened search is ONE bf16 scan of the index (1.536 GB, 1.573 TFLOP) + candidate collection + exact re-rank
+            "knn_hbm_frac_bf16_one_scan": round(N * D * 2.0 / tk / 8.0e12, 4), "knn_mfma_bf16_frac": round(2.0 * 1024 * N * D / tk / 2.5e15, 4),
+            "knn_roofline": knn_stream_roofline(knn.index, a.k, dev)}
 
 
 YOLO_STRIDE = {0: 2, 1: 4, 2: 4, 3: 8, 4: 8, 5: 16, 6: 16, 7: 32, 8: 32, 9: 32, 10: 32, 13: 16, 14: 16, 17: 8, 18: 16, 20: 16, 21: 32, 23: 32}
@@ -540,8 +607,10 @@ def c5_extras(a, dev):
     """BASELINE configs[4] (full pipeline) on ONE GPU through the PRODUCT function effocr_amd.pipeline.run_effocr
     (infer_effocr_onnx_multi.py:227-397): 16 synthetic 4096 x 256 uint8 text-line images per call -> EffLocalizer (device letterbox to
     640 x 640, YOLOv5s, device NMS) -> character boxes parsed / scaled / double-clipped on the device -> one batched crop-transform
-    launch -> ViT-S/16 + k-NN (k = 1) -> line strings + en_postprocess.  Seeded random localizer weights with the Detect biases
-    raised so that every line yields boxes (max_det 64 per line: a text line has tens of glyphs).  Median of 7 calls."""
+    launch -> ViT-S/16 + k-NN (k = 1) -> line strings (lang "jp": characters joined, no en_postprocess — the localizer is random-init,
+    there are no word boxes to space by).  Seeded random localizer weights with the Detect biases raised so that every line yields boxes.
+    max_det is the reference's default 1000 (localizer_engine.py:62), i.e. the product default — round 3 measured max_det=64.
+    Median of 7 calls."""
     import numpy as np
     from effocr_amd.knn import FaissKNN, IndexFlatIP
     from effocr_amd.localizer_engine import EffLocalizer, init_yolov5s_state_dict
@@ -570,12 +639,12 @@ def c5_extras(a, dev):
 
     def call(inp=None):
         t0 = time.perf_counter()
-        res, _ = run_effocr(lines if inp is None else inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=64)
+        res, _ = run_effocr(lines if inp is None else inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars)
         return time.perf_counter() - t0, res
 
     def loc_only():
         t0 = time.perf_counter()
-        rows, counts = loc.run_device(lines, max_det=64)
+        rows, counts = loc.run_device(lines)
         counts.cpu()
         return time.perf_counter() - t0
 
@@ -599,7 +668,7 @@ def c5_extras(a, dev):
     loc._eng_net.set_option("bf16_operands", 0)
     fl = yolov5s_flops(nc, 640, 640)
     return {"workload": "BASELINE configs[4] on 1 GPU, product function run_effocr: 16 x 4096x256 uint8 text-line images per call -> YOLOv5s localizer "
-                        f"(640x640 letterbox, fp32 MFMA, device NMS, max_det 64) -> device box parsing + ONE crop-transform launch -> {arch} ({a.precision}) "
+                        f"(640x640 letterbox, fp32 MFMA, device NMS, max_det 1000 = the default) -> device box parsing + ONE crop-transform launch -> {arch} ({a.precision}) "
                         f"-> {a.index_rows}-row IndexFlatIP, k=1 -> strings; host uint8 images in, strings out (PCIe-inclusive); seeded random weights",
             "lines_per_s": round(nl / t, 2), "ms_per_call_median_of_7": round(1e3 * t, 3), "ms_per_call_min": round(1e3 * ts[0], 3),
             "chars_per_line": round(nb, 1),

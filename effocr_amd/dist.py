@@ -22,11 +22,14 @@ def shard_sizes(n, world_size):
     return [shard_bounds(n, r, world_size)[1] - shard_bounds(n, r, world_size)[0] for r in range(world_size)]
 
 
-def all_gather_rows(local, n_total, group=None):
+def all_gather_rows(local, n_total, group=None, always_collective=False):
     """All-gather row blocks of unequal length: ``local`` [n_r, k] -> [n_total, k] on every rank, in
     rank order (= original crop order for ``shard_bounds`` slices).  Blocks are padded to the
-    largest shard so that one fixed-size collective is used."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    largest shard so that one fixed-size collective is used.  A group of one rank returns ``local``
+    without a collective unless ``always_collective`` (tests: the RCCL call on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dist.get_world_size(group) == 1 and not always_collective:
         return local
     world = dist.get_world_size(group)
     sizes = shard_sizes(n_total, world)

@@ -155,6 +155,79 @@ def test_sharded_recognizer_two_processes_on_gpu(dev, tmp_path):
     assert torch.equal(d.cpu(), d0)                     # same kernels, same rows: bit-identical however the batch is split
 
 
+def _nccl_rank_main(rank, world, port, out_dir):
+    """One process per GPU over RCCL ("nccl"): the product's ShardedRecognizer + the id all-gather exactly as bench.py --gpus N runs it."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from effocr_amd.dist import ShardedRecognizer, all_gather_rows, shard_bounds
+        from effocr_amd.encoders import AutoEncoderFactory
+        from effocr_amd.knn import FaissKNN, IndexFlatIP
+        from effocr_amd.pipeline import Recognizer
+        arch = "vit_tiny_test"
+        enc = AutoEncoderFactory("timm", arch, precision="fp32", img_size=64)()
+        enc.load_state_dict(init_state_dict(arch, seed=8, img_size=64))
+        enc.to(dev).eval()
+        g = torch.Generator().manual_seed(9)
+        index = torch.nn.functional.normalize(torch.randn(300, 128, generator=g), dim=1)
+        knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
+        knn.train(index)
+        rec = Recognizer(enc, knn, ["x"] * 300, knn=10)
+        x = torch.randn(37, 3, 64, 64, generator=g)
+        d, i = ShardedRecognizer(rec.neighbors)(x)
+        # the raw collective with a ragged int64 block, forced even for a one-rank group: all_gather_into_tensor over RCCL
+        lo, hi = shard_bounds(37, rank, world)
+        rows = torch.arange(37 * 10, dtype=torch.int64, device=dev).view(37, 10)
+        full = all_gather_rows(rows[lo:hi].contiguous(), 37, always_collective=True)
+        assert torch.equal(full, rows)
+        torch.save((d.cpu(), i.cpu()), os.path.join(out_dir, f"n{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_process_reference(dev):
+    from effocr_amd.encoders import AutoEncoderFactory
+    from effocr_amd.knn import FaissKNN, IndexFlatIP
+    from effocr_amd.pipeline import Recognizer
+    arch = "vit_tiny_test"
+    enc = AutoEncoderFactory("timm", arch, precision="fp32", img_size=64)()
+    enc.load_state_dict(init_state_dict(arch, seed=8, img_size=64))
+    enc.to(dev).eval()
+    g = torch.Generator().manual_seed(9)
+    index = torch.nn.functional.normalize(torch.randn(300, 128, generator=g), dim=1)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False)
+    knn.train(index)
+    rec = Recognizer(enc, knn, ["x"] * 300, knn=10)
+    return rec.neighbors(torch.randn(37, 3, 64, 64, generator=g))
+
+
+def test_rccl_all_gather_single_rank_group(dev, tmp_path):
+    """The RCCL leg on the one-GPU test box: a "nccl" process group of ONE rank (its own process), the product's ShardedRecognizer and
+    a forced ``all_gather_into_tensor`` of int64 id rows — so the collective call, dtype and padding logic have executed on RCCL at
+    least once before the driver's multi-GPU bench does."""
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_rank_main, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    d0, i0 = torch.load(tmp_path / "n0.pt")
+    d, i = _single_process_reference(dev)
+    assert torch.equal(i.cpu(), i0) and torch.equal(d.cpu(), d0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+def test_sharded_recognizer_two_processes_over_rccl(dev, tmp_path):
+    """BASELINE configs[2] in miniature: two processes, one per GPU, "nccl" = RCCL over xGMI; gathered ids / scores == single process."""
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    d0, i0 = torch.load(tmp_path / "n0.pt")
+    d1, i1 = torch.load(tmp_path / "n1.pt")
+    d, i = _single_process_reference(dev)
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    assert torch.equal(i.cpu(), i0) and torch.equal(d.cpu(), d0)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
 def test_recognizer_follows_the_encoder_device():
     """the engines derive their device from the encoder / current device, not a literal cuda:0."""
