@@ -254,13 +254,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    from effocr_amd import _lib as L_
+    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    clock_ghz = [None]
+
     def timed(step, steps):
         fence()
         t0 = time.perf_counter()
+        L_.check(L_.lib().effocr_clock_sample(L_.ptr(clk), L_.current_stream(dev)), "clock_sample")          # (inside the fences: two 1-thread kernels)
         for _ in range(steps):
             out = step()
+        L_.check(L_.lib().effocr_clock_sample(L_.ptr(clk[2:]), L_.current_stream(dev)), "clock_sample")
         fence()
         dt = time.perf_counter() - t0
+        c = clk.cpu().tolist()
+        if c[3] > c[1]:
+            clock_ghz[0] = round((c[2] - c[0]) / (c[3] - c[1]) * 0.1, 3)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -289,6 +298,7 @@ def main():
     if dom:
         enc.profile_begin(only=dom)
     dt, out = timed(step, a.steps)
+    clock_main = clock_ghz[0]
     prof = enc.profile_collect() if dom else {}
     assert tuple(out.shape) == (n_total, a.k)
     other = None
@@ -344,6 +354,7 @@ def main():
             line[other["scaling"]] = other
         if verify is not None:
             line["verify"] = verify
+        line["shader_clock_GHz_in_timed_region"] = clock_main     # s_memtime / s_memrealtime over the K timed steps (power-managed: 2.4 GHz max)
         if dom and dom in prof and prof[dom]["launches"]:
             p = prof[dom]
             sec = p["ms"] * 1e-3 / p["launches"]
@@ -365,7 +376,7 @@ def main():
                                      "encoder_mfma_frac_at_model_flops": round(value / world * FLOP_PER_CROP[a.arch] / MFMA_PEAK[a.precision], 4)}
         if world == 1 and not a.no_extras:
             try:
-                line["precision"] = precision_extras(a, enc, knn, sd, dev, x_full)
+                line["precision"] = precision_extras(a, enc, knn, sd, dev, x_full, dom)
                 line["c3_shard_proxy"] = shard_proxy_extras(a, enc, knn, dev)
                 line["small_batch"] = small_batch_extras(a, enc, knn, sd, dev)
                 if a.arch == "vit_small_patch16_224":
@@ -398,11 +409,12 @@ def _time_gpu(fn, dev, iters, warm=2):
     return (time.perf_counter() - t0) / iters
 
 
-def precision_extras(a, enc, knn, sd, dev, x):
+def precision_extras(a, enc, knn, sd, dev, x, dom=None):
     """Embedding error of every operand mode against the library's exact-fp32 mode on 64 of the step's crops, and the step rate of the
     16-bit modes on the whole batch (same kernels, other MFMA operand type)."""
     from effocr_amd.encoders import HipEncoder
-    out = {"tolerance_north_star": 1e-3,
+    from effocr_amd.encoders import DEFAULT_PRECISION
+    out = {"tolerance_north_star": 1e-3, "engines_default_precision": DEFAULT_PRECISION,
            "reference": "the library's fp32 mode (v_mfma_f32_32x32x2_f32, exact fp32; 1.4e-6 from oracle A in tests/test_gpu_encoder.py), 64 crops; "
                         "rel_err = max|e - e_ref| / max|e_ref| over L2-normalised embeddings"}
     xs = x[:64].contiguous()
@@ -415,6 +427,16 @@ def precision_extras(a, enc, knn, sd, dev, x):
         t = _time_gpu(lambda: knn(e.forward(x, normalize=True), k=a.k), dev, 10, warm=3)
         out[prec] = {"rel_err": float(f"{rel:.3e}"), "meets_tolerance": bool(rel <= 1e-3), "crops_per_s": round(x.shape[0] / t, 1),
                      "ms_per_step": round(1e3 * t, 3), "top1_identical_to_fp32_mode": bool(torch.equal(knn(emb, k=1)[1], top1_ref))}
+        if dom:                                            # the dominant kernel's roofline record in THIS mode (in-stream events, 5 steps)
+            e.profile_begin(only=dom)
+            for _ in range(5):
+                e.forward(x, normalize=True)
+            p = e.profile_collect().get(dom)
+            if p and p["launches"]:
+                sec, fl = p["ms"] * 1e-3 / p["launches"], p["flops"] / p["launches"]
+                out[prec]["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_PEAK[prec] / 1e12,
+                                         "unit": "TFLOP/s", "frac": round(fl / sec / MFMA_PEAK[prec], 4), "avg_launch_us": round(sec * 1e6, 2),
+                                         "launches": p["launches"]}
         if e is not enc:
             del e
     torch.cuda.empty_cache()

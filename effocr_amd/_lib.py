@@ -56,6 +56,8 @@ def _declare(lib):
         "effocr_encoder_upload": (i32, [vp, vp, sz]),
         "effocr_encoder_workspace_bytes": (sz, [vp, i32]),
         "effocr_encoder_forward": (i32, [vp, f32p, i32, f32p, i32, vp, sz, vp]),
+        "effocr_encoder_check_status": (i32, [vp, vp, vp]),
+        "effocr_clock_sample": (i32, [vp, vp]),
         "effocr_encoder_set_chunk": (i32, [vp, i32]),
         "effocr_encoder_set_option": (i32, [vp, c.c_char_p, i32]),
         "effocr_op_ln_linear": (i32, [i32, i32, f32p, f32p, f32p, c.c_float, vp, f32p, f32p, vp, i32, i32, i32, vp]),

@@ -368,12 +368,13 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
   return rc;
 }
 
-struct VitWs { size_t x, xn, qkv, att, h, total, rows, hbytes; };
+struct VitWs { size_t status, x, xn, qkv, att, h, total, rows, hbytes; };
 VitWs vit_ws(const effocr_encoder* e, int B) {
   // rows padded to the panel height (128) so that the row-panel kernels store without bounds checks
   const size_t M = align_up((size_t)B * e->T, 128), D = e->vit.D, es = prec_esize(e->prec);
   Alloc a; VitWs w;
   w.rows = M;
+  w.status = a.take(256);                    // int32 status word at workspace offset 0 (effocr_encoder_check_status)
   w.x = a.take(M * D * 4);
   w.xn = a.take(M * D * es);
   w.qkv = a.take(M * 3 * D * es);
@@ -385,7 +386,7 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
   return w;
 }
 
-int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, char* ws, hipStream_t s) {
+int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, char* ws, bool first_chunk, hipStream_t s) {
   const VitWs w = vit_ws(e, B);
   const int D = e->vit.D, T = e->T, Pn = e->P, M = B * T, prec = e->prec;
   const char* wb = e->wdev;
@@ -410,7 +411,8 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   const bool patchf = blk && e->use_patchf && patch_embed_fused_supported(prec, D);
   if (!patchf && (rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
-  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, s))) return rc;
+  int* status = reinterpret_cast<int*>(ws + w.status);
+  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, first_chunk ? status : nullptr, s))) return rc;
   GemmArgs g{};
   if (patchf) {                                          // pixels -> tokens in one kernel: the patch rows never exist in HBM
     PatchArgs pa{};
@@ -555,8 +557,8 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
     if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] {
           return g3 ? gemm3_nt(prec, EPI_BIAS_RESID, g, s) : g2 ? gemm2_nt(prec, EPI_BIAS_RESID, g, s) : gemm_nt(prec, EPI_BIAS_RESID, g, s); }))) return rc;
   }
-  if (cls_x) return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(cls_x, B, 1, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, 1, emb, s); });
-  return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, blk, emb, s); });
+  if (cls_x) return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(cls_x, B, 1, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, 1, emb, status, s); });
+  return timed(e, "final_cls_norm", 0.0, s, [&] { return final_cls_norm(xs, B, T, D, F(e->off_normw), F(e->off_normb), 1e-6f, l2, blk, emb, status, s); });
 }
 
 constexpr size_t CONV_SPLIT_BYTES = (size_t)16 << 20;  // split-K scratch of conv2d_nhwc: <= 256 partial tiles of 128 x 128 fp32
@@ -767,9 +769,28 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
   const size_t img_elems = (size_t)3 * enc->img * enc->img;
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int cb = (batch - b0 < chunk) ? batch - b0 : chunk;
-    const int rc = vit_forward(enc, x_dev + (size_t)b0 * img_elems, cb, emb_dev + (size_t)b0 * enc->D, l2_normalize, ws, S(stream));
+    const int rc = vit_forward(enc, x_dev + (size_t)b0 * img_elems, cb, emb_dev + (size_t)b0 * enc->D, l2_normalize, ws, b0 == 0, S(stream));
     if (rc) return rc;
   }
+  return EFFOCR_OK;
+}
+
+int effocr_clock_sample(void* out_dev, void* stream) {
+  if (!out_dev) return fail(EFFOCR_EINVAL, "clock_sample: NULL pointer");
+  return clock_sample(static_cast<unsigned long long*>(out_dev), S(stream));
+}
+
+int effocr_encoder_check_status(const effocr_encoder_t* enc, const void* workspace_dev, void* stream) {
+  if (!enc || !workspace_dev) return fail(EFFOCR_EINVAL, "check_status: NULL argument");
+  if (!enc->is_vit) return EFFOCR_OK;                     // the CNN path computes in fp32 throughout
+  int st = 0;
+  hipError_t er = hipStreamSynchronize(S(stream));
+  if (er == hipSuccess) er = hipMemcpy(&st, workspace_dev, sizeof(int), hipMemcpyDeviceToHost);   // VitWs::status = offset 0
+  if (er != hipSuccess) return fail(EFFOCR_EHIP, std::string("check_status: ") + hipGetErrorString(er));
+  if (st != 0)
+    return fail(EFFOCR_EOVERFLOW, enc->prec == PREC_FP16
+                    ? "forward: non-finite embedding — an f16 operand overflowed (|q|, |k|, |v| or an fc1 pre-activation beyond 65504) or the input was not finite; use precision bf16 or fp32 for this checkpoint"
+                    : "forward: non-finite embedding — the input crops or the weights hold inf / nan");
   return EFFOCR_OK;
 }
 

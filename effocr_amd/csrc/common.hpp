@@ -104,15 +104,30 @@ template <int N> __device__ __forceinline__ void gelu_erf_fast_n(float (&x)[N]) 
   }
 }
 
-// GELU with the constants folded: gelu(x) = x * (0.5 + u*q(u^2)), u = clamp(x, +-L), u*q(u^2) ~ 0.5*erf(u/sqrt2)
-// (minimax fits, tools in DESIGN.md).  16-bit bf16 outputs (8-bit mantissa) take the degree-6 fit (|gelu err| <=
-// 3.2e-4, L = 3.9), everything else the degree-8 fit (<= 4.3e-5, L = 4.2): 9 / 11 plain VALU per value.
+// GELU with the constants folded: gelu(x) = x * (0.5 + u*q(u^2)), u = clamp(x, +-L), u*q(u^2) ~ 0.5*erf(u/sqrt2); q = minimax fit of the
+// weighted error |x| |Phi~(x) - Phi(x)| over |x| <= 12 (linear program on a dense grid, tools/fit_gelu.py — round 4 refit: the degree-6
+// polynomial went from 3.9e-4 to 1.45e-4).  bf16 outputs (8-bit mantissa) take degree 6 (|gelu err| <= 1.5e-4, L = 3.9); f16 outputs
+// GELU_DEG_F16: 6 (default), 7 (<= 6.9e-5, L = 4.1) or 8 (<= 6.4e-5, L = 4.2) — every degree is 4 VALU instructions per quad of values
+// in the fused MLP's hand-over list, where ~6 issue slots per MFMA gap are free (mlp_kernel.hpp).  Same-box A/B (gpurun_out/f16ab*.txt):
+// f16 step 11.43 / 11.35 / 11.22 ms at degree 8 / 7 / 6, embedding error 7.2-7.8e-4 at every degree (the f16 operand roundings dominate).
+#ifndef GELU_DEG_F16
+#define GELU_DEG_F16 6
+#endif
+template <typename E> struct GeluFit {
+  static constexpr bool lo = sizeof(E) == 2 && !__is_same(E, _Float16);
+  static constexpr int DEG = lo ? 6 : (sizeof(E) == 2 ? GELU_DEG_F16 : 8);
+  static constexpr float L = DEG == 6 ? 3.9f : DEG == 7 ? 4.1f : 4.2f;
+  static __device__ __forceinline__ constexpr float c(int k) {
+    constexpr float c6[7] = {3.980856134e-01f, -6.486948046e-02f, 8.913788161e-03f, -8.445121550e-04f, 5.123729042e-05f, -1.770496053e-06f, 2.627150211e-08f};
+    constexpr float c7[8] = {3.985286087e-01f, -6.563282613e-02f, 9.356159468e-03f, -9.656455460e-04f, 6.894064765e-05f, -3.190561829e-06f, 8.525671410e-08f, -9.917594109e-10f};
+    constexpr float c8[9] = {3.989074382e-01f, -6.636037144e-02f, 9.830130026e-03f, -1.114147779e-03f, 9.457434347e-05f, -5.760762241e-06f, 2.343669162e-07f, -5.633299462e-09f, 5.998041464e-11f};
+    return DEG == 6 ? c6[k < 7 ? k : 6] : DEG == 7 ? c7[k < 8 ? k : 7] : c8[k];
+  }
+};
 template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (&x)[N]) {
-  constexpr bool lo = sizeof(E) == 2 && !__is_same(E, _Float16);
-  constexpr float L = lo ? 3.9f : 4.2f;
-  constexpr int DEG = lo ? 6 : 8;
-  constexpr float c6[7] = {3.986083969e-01f, -6.556460269e-02f, 9.218763890e-03f, -9.056357457e-04f, 5.740218682e-05f, -2.075315505e-06f, 3.214920233e-08f};
-  constexpr float c8[9] = {3.989074382e-01f, -6.636037144e-02f, 9.830130026e-03f, -1.114147779e-03f, 9.457434347e-05f, -5.760762241e-06f, 2.343669162e-07f, -5.633299462e-09f, 5.998041464e-11f};
+  typedef GeluFit<E> GF;
+  constexpr float L = GF::L;
+  constexpr int DEG = GF::DEG;
   if constexpr (N == 8 || N == 16) {
     constexpr int NCH = N / 2;                           // packed chains in lock step (8 of them: a dependent pair is 8 issues apart, no wait states at all)
     // Eight values = FOUR packed chains kept in lock step.  A v_pk_fma_f32 consuming the previous packed result needs a wait
@@ -125,7 +140,7 @@ template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (
     for (int i = 0; i < NCH; ++i) {
       u[i] = f32x2{__builtin_amdgcn_fmed3f(x[2 * i], -L, L), __builtin_amdgcn_fmed3f(x[2 * i + 1], -L, L)};
       t[i] = u[i] * u[i];
-      const float ch = lo ? c6[DEG] : c8[DEG], cl = lo ? c6[DEG - 1] : c8[DEG - 1];
+      const float ch = GF::c(DEG), cl = GF::c(DEG - 1);
       p[i] = __builtin_elementwise_fma(f32x2{ch, ch}, t[i], f32x2{cl, cl});
     }
     // join: every chain is at the same step before any moves on.  INPUT-only operands — an asm that (re)defines the chain registers
@@ -137,7 +152,7 @@ template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (
 #pragma unroll
     for (int k = DEG - 2; k >= 0; --k) {
       join(p);
-      const float ck = lo ? c6[k] : c8[k];
+      const float ck = GF::c(k);
 #pragma unroll
       for (int i = 0; i < NCH; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{ck, ck});
     }
@@ -158,28 +173,16 @@ template <typename E, int N> __device__ __forceinline__ void gelu_fold_n(float (
   for (int i = 0; i < N; ++i) {
     u[i] = __builtin_amdgcn_fmed3f(x[i], -L, L);
     t[i] = u[i] * u[i];
-    p[i] = lo ? fmaf(c6[DEG], t[i], c6[DEG - 1]) : fmaf(c8[DEG], t[i], c8[DEG - 1]);
+    p[i] = fmaf(GF::c(DEG), t[i], GF::c(DEG - 1));
   }
 #pragma unroll
   for (int k = DEG - 2; k >= 0; --k)
 #pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = fmaf(p[i], t[i], lo ? c6[k] : c8[k]);
+    for (int i = 0; i < N; ++i) p[i] = fmaf(p[i], t[i], GF::c(k));
 #pragma unroll
   for (int i = 0; i < N; ++i) x[i] = x[i] * fmaf(u[i], p[i], 0.5f);
 }
 
-// The same fit as constants + single steps, for kernels that slice the evaluation into the issue slots beside their MFMAs
-// (mlp_kernel.hpp): value for value the arithmetic of gelu_fold_n.
-template <typename E> struct GeluFit {
-  static constexpr bool lo = sizeof(E) == 2 && !__is_same(E, _Float16);
-  static constexpr int DEG = lo ? 6 : 8;
-  static constexpr float L = lo ? 3.9f : 4.2f;
-  static __device__ __forceinline__ constexpr float c(int k) {
-    constexpr float c6[7] = {3.986083969e-01f, -6.556460269e-02f, 9.218763890e-03f, -9.056357457e-04f, 5.740218682e-05f, -2.075315505e-06f, 3.214920233e-08f};
-    constexpr float c8[9] = {3.989074382e-01f, -6.636037144e-02f, 9.830130026e-03f, -1.114147779e-03f, 9.457434347e-05f, -5.760762241e-06f, 2.343669162e-07f, -5.633299462e-09f, 5.998041464e-11f};
-    return lo ? c6[k < 7 ? k : 6] : c8[k];
-  }
-};
 // two floats -> one 32-bit word of two 16-bit values (first value in the low half), and back
 template <typename E> __device__ __forceinline__ uint32_t pack2(float a, float b) {
   typedef __attribute__((__vector_size__(2 * sizeof(E)))) E V2;

@@ -117,12 +117,13 @@ int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, co
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                    float eps, void* out, hipStream_t s);
 int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s);
-int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, hipStream_t s);
+int clock_sample(unsigned long long* out, hipStream_t s);
+int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, int* status_zero, hipStream_t s);
 // rows img*T of x (fp32 blocked) and att (16-bit blocked) -> compact blocked buffers of B rows (last block: class tokens only)
 int gather_cls_rows_blocked(const float* x, const void* att, int B, int T, int D, float* xc, void* ac, hipStream_t s);
 int attention(int prec, const void* qkv, void* out, int B, int T, int heads, int blocked, hipStream_t s);
 int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, const float* beta, float eps,
-                   int l2norm, int blocked, float* emb, hipStream_t s);
+                   int l2norm, int blocked, float* emb, int* status, hipStream_t s);
 
 // knn.hip
 size_t knn_workspace_bytes(int64_t B, int64_t N, int D, int k);

@@ -62,7 +62,9 @@ constexpr int QA_RING = 6;
 
 // CLS: the LAST transformer block — only the class token's attention row reaches the output (the rest of the block then runs
 // on B gathered rows, api.hip): k and v of every token as usual, q and the attention only for token tile 0 (wave 0).
-template <typename E, int D, int NTT, bool CLS = false>
+// NPV: P.V steps of 16 keys per query tile — 2 * NTT, or 2 * NTT - 1 when the last 16 keys of the last key tile are all padding
+// (T <= 32 * NTT - 16: ViT-S/16 at 224 has 197 tokens, keys 208..223 do not exist): 3 MFMAs + 8 exponentials per query tile less.
+template <typename E, int D, int NTT, bool CLS = false, int NPV = 2 * NTT>
 __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   typedef typename Op16<E>::V8 V8;
   constexpr int HEADS = D / 64;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       qa_for<0, (CLS ? 1 : NT)>([&](auto TT_) {
         constexpr int tt = decltype(TT_)::value;
         if constexpr (CLS) { if (w != 0) return; }       // (wave-uniform; the other waves go on to the next head's weight stream)
+        if (2 * w + tt >= NTT) return;                   // the dummy tile (wave 3's second tile of a 197-token image) has no queries
         __builtin_amdgcn_sched_barrier(0);               // one query tile at a time (two score rows do not fit)
         const int tq = (2 * w + tt) * 32 + r31;
         f32x16 s[NTT];
@@ -378,9 +381,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         };
         qa_for<0, 3>([&](auto P_) { p_part(std::integral_constant<int, 0>{}, P_); });
         __builtin_amdgcn_sched_barrier(0);
-        qa_for<0, 2 * NTT>([&](auto ST_) {
+        qa_for<0, NPV>([&](auto ST_) {
           constexpr int st = decltype(ST_)::value, cur = st & 1, nxt = cur ^ 1;
-          constexpr bool more = st + 1 < 2 * NTT;
+          constexpr bool more = st + 1 < NPV;
           if constexpr (more) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) vf[nxt][db] = *reinterpret_cast<const V8*>(vb + ((st + 1) * 2 + db) * 1024);
@@ -470,7 +473,10 @@ int launch_qkvattn(const QkvAttnArgs& a, hipStream_t s) {
   ah.hsplit = hs;
   const QkvAttnArgs& a2 = ah;
   const dim3 grid((unsigned)(hs > 1 ? a.B * hs : (a.B < cus ? a.B : cus))), blk(256);
-  if (a.D == 384 && ntt == 7 && a.cls_only) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true>), grid, blk, 0, s, a2);
+  const bool short_tail = a.T <= 32 * ntt - 16;          // the last 16 keys are all padding
+  if (a.D == 384 && ntt == 7 && a.cls_only && short_tail) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true, 13>), grid, blk, 0, s, a2);
+  else if (a.D == 384 && ntt == 7 && a.cls_only) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true>), grid, blk, 0, s, a2);
+  else if (a.D == 384 && ntt == 7 && short_tail) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, false, 13>), grid, blk, 0, s, a2);
   else if (a.D == 384 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7>), grid, blk, 0, s, a2);
   else if (a.D == 384 && ntt <= 2) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 2>), grid, blk, 0, s, a2);
   else if (a.D == 128 && ntt == 7) hipLaunchKernelGGL((qkvattn_kernel<E, 128, 7>), grid, blk, 0, s, a2);

@@ -122,7 +122,7 @@ template <int G, int V>
 __global__ __launch_bounds__(256) void cls_norm_kernel(const float* __restrict__ x, int B, int T,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int l2norm,
-                                                       int blocked, float* __restrict__ emb) {
+                                                       int blocked, float* __restrict__ emb, int* __restrict__ status) {
   constexpr int D = 4 * G * V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63, sub = lane % G;
@@ -150,8 +150,17 @@ __global__ __launch_bounds__(256) void cls_norm_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) y[i][e] = y[i][e] / nrm;
   }
   if (img < B) {
+    // status word (effocr_encoder_check_status): a non-finite embedding = an inf / nan reached the class-token row — a 16-bit operand
+    // overflowed on the way (f16: |q|, |k|, |v|, |fc1 pre-activation| > 65504 rounds to inf, and an inf anywhere in a block turns the
+    // next LayerNorm / softmax of every row it feeds into nan) or the input itself was not finite.
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < V; ++i) *reinterpret_cast<f32x4*>(emb + (int64_t)img * D + (sub + G * i) * 4) = y[i];
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bad |= !(fabsf(y[i][e]) <= 3.0e38f);
+      *reinterpret_cast<f32x4*>(emb + (int64_t)img * D + (sub + G * i) * 4) = y[i];
+    }
+    if (status && bad) atomicOr(status, 1);
   }
 }
 
@@ -202,8 +211,9 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict
 }
 
 // token 0 of every image = cls_token + pos_embed[0] (pre-added on the host at weight upload)
-__global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D, int blocked) {
+__global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D, int blocked, int* __restrict__ status_zero) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id == 0 && status_zero) *status_zero = 0;          // first kernel of a forward: the status word starts clean
   if (id >= (int64_t)B * D) return;
   const int d = (int)(id % D);
   const int64_t img = id / D;
@@ -559,10 +569,10 @@ int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out,
   return fail(EFFOCR_EINVAL, "im2col: unknown precision");
 }
 
-int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, hipStream_t s) {
+int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, int* status_zero, hipStream_t s) {
   const int64_t total = (int64_t)B * D;
   if (total <= 0) return EFFOCR_OK;
-  hipLaunchKernelGGL(set_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls_pos0, x, B, T, D, blocked);
+  hipLaunchKernelGGL(set_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls_pos0, x, B, T, D, blocked, status_zero);
   return check_launch("set_cls_rows");
 }
 
@@ -585,15 +595,25 @@ int attention(int prec, const void* qkv, void* out, int B, int T, int heads, int
   return fail(EFFOCR_EINVAL, "attention: unknown precision");
 }
 
+// (s_memtime ticks at the shader clock on gfx950, s_memrealtime at the constant 100 MHz reference: two samples give the average
+// shader clock over the interval between them — bench.py brackets its timed region with it)
+__global__ void clock_sample_kernel(unsigned long long* out) {
+  if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime(); out[1] = __builtin_amdgcn_s_memrealtime(); }
+}
+int clock_sample(unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, s, out);
+  return check_launch("clock_sample");
+}
+
 int final_cls_norm(const float* x, int B, int T, int D, const float* gamma, const float* beta, float eps,
-                   int l2norm, int blocked, float* emb, hipStream_t s) {
+                   int l2norm, int blocked, float* emb, int* status, hipStream_t s) {
   if (B <= 0) return EFFOCR_OK;
   if (D == 384) {
-    hipLaunchKernelGGL((cls_norm_kernel<32, 3>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb);
+    hipLaunchKernelGGL((cls_norm_kernel<32, 3>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb, status);
   } else if (D == 768) {
-    hipLaunchKernelGGL((cls_norm_kernel<64, 3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb);
+    hipLaunchKernelGGL((cls_norm_kernel<64, 3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb, status);
   } else if (D == 128) {
-    hipLaunchKernelGGL((cls_norm_kernel<32, 1>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb);
+    hipLaunchKernelGGL((cls_norm_kernel<32, 1>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, x, B, T, gamma, beta, eps, l2norm, blocked, emb, status);
   } else {
     return fail(EFFOCR_EUNSUPPORTED, "final norm: embed dim must be 128, 384 or 768");
   }

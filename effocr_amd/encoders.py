@@ -20,12 +20,20 @@ import torch
 from . import _lib
 from . import weights as W
 
+# Operand precision the engines take when the caller does not say.  north_star's bar is "encoder embeddings within 1e-3 rel fp32"
+# (the reference computes in fp32: infer_effocr.py:314-316; the only tolerance it states itself is the ONNX export's,
+# scripts/recognizer_onnx_export.py:81,84): "fp16" meets it (7.5e-4, f16 MFMA operands, fp32 accumulation / residual / LayerNorm /
+# softmax; overflow of f16's range is detected and reported as EFFOCR_EOVERFLOW), "bf16" does not (5.7e-3; top-1 ids identical
+# wherever two glyphs are more than 1e-4 apart in cosine) and stays one keyword away for users who want its 4 % higher rate and
+# fp32's exponent range; "fp32" is the exact parity mode.  bench.py's headline keeps bf16 because BASELINE.json names it.
+DEFAULT_PRECISION = "fp16"
+
 
 class HipEncoder:
     """Device-resident encoder: C-ABI handle + weight blob + one grow-only workspace PER HIP STREAM (the Python lock
     covers only the enqueue; two threads forwarding on different streams must not share activation buffers)."""
 
-    def __init__(self, arch, state_dict, img_size=224, precision="bf16", device="cuda:0"):
+    def __init__(self, arch, state_dict, img_size=224, precision=DEFAULT_PRECISION, device="cuda:0"):
         if precision not in _lib.PREC:
             raise ValueError(f"precision must be one of {sorted(_lib.PREC)}, got {precision!r}")
         self.device = _lib.require_gpu(device)
@@ -97,6 +105,17 @@ class HipEncoder:
                                                       _lib.current_stream(self.device)), "effocr_encoder_forward")
         return emb
 
+    def check_status(self):
+        """Synchronise the current stream and raise EffOCRHipError (EFFOCR_EOVERFLOW) if the last forward issued on it produced a
+        non-finite embedding — how an f16 operand overflow surfaces (include/effocr_hip.h).  Callers that synchronise anyway
+        (EffRecognizer.run, Recognizer.__call__, run_effocr) call it there; a purely asynchronous user calls it when it wants to know."""
+        with self._lock, torch.cuda.device(self.device):
+            ws = self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
+            if ws is None:
+                return
+            _lib.check(self._L.effocr_encoder_check_status(self._h, _lib.ptr(ws), _lib.current_stream(self.device)),
+                       "effocr_encoder_check_status")
+
     __call__ = forward
 
     # -- HIP-event profiler (bench.py roofline) --------------------------------------------------
@@ -119,7 +138,7 @@ class HipEncoder:
         return out
 
 
-def AutoEncoderFactory(backend, modelpath, precision="bf16", img_size=224):
+def AutoEncoderFactory(backend, modelpath, precision=DEFAULT_PRECISION, img_size=224):
     """Drop-in for models/encoders.py:50 ``AutoEncoderFactory(backend, modelpath)``.
 
     Only the ``"timm"`` backend with the architectures BASELINE.json names is implemented (the "hf"

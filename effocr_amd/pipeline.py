@@ -86,6 +86,15 @@ def encoder_device(encoder):
     return getattr(eng, "device", None)
 
 
+def check_encoder_status(encoder):
+    """Raise (EFFOCR_EOVERFLOW) if the encoder's last forward on the current stream produced a non-finite embedding — an f16
+    operand overflow cannot hide behind plausible ids.  No-op for encoders that are not of this package."""
+    eng = getattr(encoder, "engine", None) or getattr(encoder, "_eng_net", None) or encoder
+    chk = getattr(eng, "check_status", None)
+    if chk is not None:
+        chk()
+
+
 class Recognizer:
     """The kNN branch of ``EffOCR.infer`` (infer_effocr.py:310-319) as one object:
     crops -> encoder -> L2 normalise (fused) -> IP top-k -> characters, everything on one GPU."""
@@ -107,7 +116,9 @@ class Recognizer:
 
     def __call__(self, crops):
         _, indices = self.neighbors(crops)
-        return indices_to_chars(indices, self.candidate_chars)
+        out = indices_to_chars(indices, self.candidate_chars)      # (.cpu(): the call's synchronisation point)
+        check_encoder_status(self.recongizer_encoder)
+        return out
 
     def recognize_boxes(self, image, char_bboxes, char_transform=None, double_clipped=True, vertical=False):
         """infer_effocr.py:281-319 with the crop loop moved to the device: `image` is the HWC uint8 page /
@@ -370,6 +381,7 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
         # sync 2: everything the string stage needs, in one go
         is_word = valid & (labels == 1)
         ids_h, boxes_h, n_h = ids.cpu().tolist(), boxes.cpu(), n_chars.cpu().tolist()
+        check_encoder_status(recognizer_engine)
         rows_h, word_h = (rows.cpu(), is_word.cpu()) if lang == "en" else (None, None)
         off = 0
         for j, li in enumerate(members):

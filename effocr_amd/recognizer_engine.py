@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import weights as W
-from .encoders import HipEncoder
+from .encoders import DEFAULT_PRECISION, HipEncoder
 
 
 class _Lane:
@@ -41,7 +41,7 @@ class _Lane:
 
 class EffRecognizer:
 
-    def __init__(self, model, num_cores=None, providers=None, arch=None, precision="bf16", img_size=224,
+    def __init__(self, model, num_cores=None, providers=None, arch=None, precision=DEFAULT_PRECISION, img_size=224,
                  device="cuda:0", lanes=2):
         # num_cores / providers are ORT knobs (recognizer_engine.py:10-15): accepted and ignored.
         self.num_cores, self.providers = num_cores, providers
@@ -117,7 +117,10 @@ class EffRecognizer:
                 emb = eng.forward(x, normalize=False)
                 h_out.view(B, D).copy_(emb, non_blocking=True)
                 lane.stream.synchronize()
-            out = h_out.view(B, D).numpy().copy()               # fresh ndarray owned by the caller
+                out = h_out.view(B, D).numpy().copy()           # fresh ndarray owned by the caller
+                if not np.isfinite(out).all():                  # f16 operand overflow / non-finite input: EFFOCR_EOVERFLOW, never silent
+                    eng.check_status()
+                    raise ValueError("EffRecognizer.run: non-finite embedding")
         finally:
             self._lanes.put(lane)
         return [out]

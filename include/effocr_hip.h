@@ -37,7 +37,8 @@ enum effocr_status {
   EFFOCR_EUNSUPPORTED = -2,  /* valid request outside what the kernels implement            */
   EFFOCR_EWORKSPACE = -3,    /* caller-provided workspace / blob too small                  */
   EFFOCR_EHIP = -4,          /* HIP runtime error (launch failure, memcpy failure)          */
-  EFFOCR_ESTATE = -5         /* call order violated (e.g. forward before upload)            */
+  EFFOCR_ESTATE = -5,        /* call order violated (e.g. forward before upload)            */
+  EFFOCR_EOVERFLOW = -6      /* non-finite result: a 16-bit operand overflowed (f16 mode) or the input was not finite */
 };
 
 /* arithmetic type of the encoder's MFMA operands (accumulation, LayerNorm, softmax, the residual
@@ -84,6 +85,21 @@ size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch);
  * emb_dev: [B,D] fp32.  l2_normalize != 0 fuses F.normalize(p=2,dim=1) (infer_effocr.py:316). */
 int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev,
                            int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Measurement aid (bench.py): one tiny kernel on `stream` that stores { s_memtime (shader-clock ticks), s_memrealtime (100 MHz) } into
+ * out_dev[0..1] (uint64).  Two samples bracket an interval: d(memtime) / d(memrealtime) x 100 MHz = the average shader clock under
+ * that load — the chip is power-managed: tools/ubench/mfma_f16_vs_bf16.hip measures 2.37 GHz idle-data, 1.73 GHz (bf16) / 1.58 GHz (f16)
+ * under saturated MFMA load with random operands. */
+int effocr_clock_sample(void* out_dev, void* stream);
+
+/* Status of the LAST forward issued with this workspace on `stream` (ViT; the CNN path is fp32 throughout and always reports OK):
+ * synchronises the stream, reads the int32 status word the forward keeps at workspace offset 0 (zeroed by its first kernel, OR-ed by
+ * its last) and returns EFFOCR_EOVERFLOW if an embedding came out non-finite.  In f16 mode that is how operand overflow surfaces:
+ * q / k / v and the fc1 pre-activations are rounded to f16 (max 65504), an overflow becomes inf, and an inf anywhere in a block turns
+ * the LayerNorm / softmax of every row it feeds into nan — it cannot stay hidden in a finite embedding.  (The reference computes in
+ * fp32, infer_effocr.py:314-316; precision "bf16" / "fp32" have fp32's exponent range.)  Not on the hot path: call it where the
+ * caller synchronises anyway. */
+int effocr_encoder_check_status(const effocr_encoder_t* enc, const void* workspace_dev, void* stream);
 
 /* ViT only: run the forward in internal sub-batches of `crops_per_chunk` crops (0 = whole batch) so
  * that the activations between consecutive kernels stay in the 256 MiB Infinity Cache.  Results

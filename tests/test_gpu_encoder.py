@@ -253,3 +253,74 @@ def test_resnet_and_localizer_do_not_depend_on_the_call_size(dev):
     im = torch.rand(16, 3, 640, 640, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
     p16, p1 = loc.forward(im), loc.forward(im[:1].contiguous())
     assert ((p16[:1] - p1).abs().max() / p1.abs().max()).item() <= 2e-6
+
+
+# ---------------------------------------------------------------- f16 range safety (round 4: f16 is the engines' default 16-bit mode)
+def _trained_magnitudes(arch, img, seed, resid=64.0, q_gain=6.0, fc1_gain=400.0):
+    """Seeded weights pushed to the magnitudes trained ViT checkpoints show: a residual stream in the tens-to-hundreds (patch
+    embedding, class token and position embedding x `resid`), sharp attention (norm1 gain), fc1 pre-activations in the hundreds
+    (norm2 gain), i.e. GELU outputs and fc2 updates of the same order."""
+    sd = init_state_dict(arch, seed=seed, img_size=img)
+    for k in list(sd):
+        if k in ("cls_token", "pos_embed") or k.startswith("patch_embed.proj."):
+            sd[k] = sd[k] * resid
+        elif k.endswith("norm1.weight"):
+            sd[k] = sd[k] * q_gain
+        elif k.endswith("norm2.weight"):
+            sd[k] = sd[k] * fc1_gain
+    return sd
+
+
+@pytest.mark.parametrize("arch,img,B", [("vit_small_patch16_224", 224, 40), ("vit_tiny_test", 64, 70)])
+def test_f16_range_safety_at_trained_checkpoint_magnitudes(dev, arch, img, B):
+    """Finiteness and the error of the f16 mode where f16's range (65504) could matter, not only on unit-scale random weights.
+    Reference = the library's exact-fp32 mode (within 1e-5 of oracle A above, at every magnitude — tools/f16_gain_sweep.py).
+      * residual stream x64, norm1 x2, fc1 pre-activations in the tens-to-hundreds (norm2 x50): within north_star's 1e-3;
+      * fc1 pre-activations in the hundreds (norm2 x200; x3 sharper attention): no overflow, and the error grows to 1.1-1.3e-3 — by
+        the SAME factor as bf16's (5.7e-3 -> 7e-3): that is the conditioning of a random network at those gains (every rounding error is
+        amplified the same way), not f16's range.  Asserted: finite, no status flag, <= 2e-3 and at least 4x below bf16."""
+    from effocr_amd.encoders import HipEncoder
+    x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(6)).to(dev)
+    for (resid, qg, fg), bound in (((64.0, 2.0, 50.0), 1e-3), ((64.0, 3.0, 200.0), 2e-3)):
+        sd = _trained_magnitudes(arch, img, seed=5, resid=resid, q_gain=qg, fc1_gain=fg)
+        ref = HipEncoder(arch, sd, img_size=img, precision="fp32", device=dev).forward(x, normalize=True)
+        enc = HipEncoder(arch, sd, img_size=img, precision="fp16", device=dev)
+        got = enc.forward(x, normalize=True)
+        enc.check_status()                               # no overflow flag
+        assert torch.isfinite(got).all()
+        e = rel_err(got.cpu(), ref.cpu())
+        e16 = rel_err(HipEncoder(arch, sd, img_size=img, precision="bf16", device=dev).forward(x, normalize=True).cpu(), ref.cpu())
+        print(f"{arch} residual x{resid:g} norm1 x{qg:g} norm2 x{fg:g}: f16 rel err {e:.3e} (bf16 {e16:.3e})")
+        assert e <= bound and e <= e16 / 4
+    # the scaled weights really produce those magnitudes (fc1 pre-activations in the hundreds at norm2 x200)
+    if arch == "vit_tiny_test":
+        from oracle.encoders_ref import strip_prefix
+        w = strip_prefix(_trained_magnitudes(arch, img, seed=5, fc1_gain=200.0))
+        xn = torch.randn(64, 128, generator=torch.Generator().manual_seed(1)) * w["blocks.0.norm2.weight"]
+        assert (xn @ w["blocks.0.mlp.fc1.weight"].T).abs().max() > 100
+
+
+def test_f16_overflow_is_reported_not_hidden(dev):
+    """fc1 pre-activations beyond 65504 overflow the f16 operand: the embedding comes out non-finite and the status word turns it
+    into EFFOCR_EOVERFLOW at every synchronising entry point (check_status, EffRecognizer.run, Recognizer.__call__); bf16 (fp32's
+    exponent range) runs the same weights without complaint."""
+    from effocr_amd import _lib
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.recognizer_engine import EffRecognizer
+    arch, img = "vit_tiny_test", 64
+    sd = _trained_magnitudes(arch, img, seed=5, fc1_gain=4.0e5)
+    x = torch.randn(9, 3, img, img, generator=torch.Generator().manual_seed(6))
+    enc = HipEncoder(arch, sd, img_size=img, precision="fp16", device=dev)
+    got = enc.forward(x.to(dev), normalize=True)
+    with pytest.raises(_lib.EffOCRHipError, match="code -6"):
+        enc.check_status()
+    assert not torch.isfinite(got).all()
+    with pytest.raises(_lib.EffOCRHipError, match="overflow"):
+        EffRecognizer(sd, arch=arch, precision="fp16", img_size=img, device=dev).run(x.numpy())
+    ok = HipEncoder(arch, sd, img_size=img, precision="bf16", device=dev)
+    assert torch.isfinite(ok.forward(x.to(dev), normalize=True)).all()
+    ok.check_status()
+    # the flag is per forward: a clean call on the same engine clears it
+    good = HipEncoder(arch, init_state_dict(arch, seed=5, img_size=img), img_size=img, precision="fp16", device=dev)
+    good.forward(x.to(dev))
+    good.check_status()

@@ -32,6 +32,29 @@ def test_encoder_matches_golden(dev, arch, prec):
     assert np.abs(emb - g["emb"]).max() <= tol * np.abs(g["emb"]).max()
 
 
+@pytest.mark.parametrize("arch", ["vit_small_patch16_224", "vit_base_patch16_224"])
+def test_default_engines_meet_the_north_star_tolerance(dev, arch, tmp_path):
+    """The engines AS A USER GETS THEM (no precision keyword) against the committed golden embeddings: within north_star's
+    "1e-3 rel fp32" — HipEncoder, the AutoEncoderFactory twin and EffRecognizer.run."""
+    from effocr_amd.encoders import DEFAULT_PRECISION, AutoEncoderFactory, HipEncoder
+    from effocr_amd.recognizer_engine import EffRecognizer
+    g = load(f"enc_{arch}.npz")
+    sd = init_state_dict(arch, seed=int(g["seed"]), img_size=int(g["img"]))
+    x = torch.from_numpy(g["x"].astype(np.float32))
+    bound = 1e-3 * np.abs(g["emb"]).max()
+    assert DEFAULT_PRECISION == "fp16"
+    a = HipEncoder(arch, sd, device=dev).forward(x.to(dev)).cpu().numpy()
+    enc = AutoEncoderFactory("timm", arch)()
+    enc.load_state_dict(sd)
+    enc.to(dev).eval()
+    b = enc(x.to(dev)).cpu().numpy()
+    c = EffRecognizer(sd, arch=arch, device=dev).run(x.numpy())[0]
+    for name, e in (("HipEncoder", a), ("AutoEncoder", b), ("EffRecognizer", c)):
+        err = np.abs(e - g["emb"]).max()
+        assert err <= bound, (name, err / np.abs(g["emb"]).max())
+    assert np.array_equal(a, b) and np.array_equal(a, c)      # one kernel sequence behind all three
+
+
 def test_knn_matches_golden_bit_exact(dev):
     from effocr_amd.knn import IndexFlatIP
     for name in ("knn_c2small.npz", "knn_ties.npz"):

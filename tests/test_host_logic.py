@@ -348,6 +348,12 @@ def test_engines_default_to_the_reference_conventions():
     from effocr_amd.postprocess import LineRecognizer
     assert inspect.signature(LineRecognizer.__init__).parameters["double_clipped"].default is True
     assert inspect.signature(Recognizer.recognize_boxes).parameters["double_clipped"].default is True
+    # round 4: the default operand precision is the one that meets north_star's 1e-3 tolerance
+    from effocr_amd.encoders import DEFAULT_PRECISION, AutoEncoderFactory, HipEncoder
+    from effocr_amd.recognizer_engine import EffRecognizer
+    assert DEFAULT_PRECISION == "fp16"
+    for fn in (HipEncoder.__init__, AutoEncoderFactory, EffRecognizer.__init__):
+        assert inspect.signature(fn).parameters["precision"].default == "fp16"
     assert inspect.signature(Recognizer.recognize_boxes).parameters["vertical"].default is False
 
     class Trunk:
