@@ -12,6 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 # EFFOCR_HIP_LIB: A/B experiments only (tools/): another build of the SAME library; the product default is the in-tree .so
 SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip.so")
+# the product library + the kernels only A/B switches reach (row-panel GEMM, fused MLP without the projection phase): `make AB=1`.
+# Never loaded by the engines on their own; tests that compare those paths switch to it with use_library().
+SO_PATH_AB = os.path.join(_HERE, "libeffocr_hip_ab.so")
 
 ABI_VERSION = 5          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
@@ -19,24 +22,39 @@ EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
 _lock = threading.Lock()
 _lib = None
+_loaded = {}             # path -> handle (use_library switches between them)
 
 
 class EffOCRHipError(RuntimeError):
     pass
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into effocr_amd/libeffocr_hip.so (hipcc cross-compiles
-    without a GPU).  Returns the path of the shared library."""
-    cmd = ["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1))]
-    if force:
-        cmd.append("-B")
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if verbose or res.returncode != 0:
-        print(res.stdout)
-    if res.returncode != 0 or not os.path.exists(SO_PATH):
-        raise EffOCRHipError("building libeffocr_hip.so failed:\n" + res.stdout[-4000:])
-    return SO_PATH
+def build(force=False, verbose=False, ab=True):
+    """Compile every HIP source for gfx950 into effocr_amd/libeffocr_hip.so (hipcc cross-compiles without a GPU) and, with ``ab``,
+    the A/B build effocr_amd/libeffocr_hip_ab.so the tests of the alternative kernel paths load.  Returns the product library's path."""
+    so = os.path.join(_HERE, "libeffocr_hip.so")
+    for extra, target in (([], so),) + (((["AB=1"], SO_PATH_AB),) if ab else ()):
+        cmd = ["make", "-C", _CSRC, "-j", str(min(16, os.cpu_count() or 1))] + extra
+        if force:
+            cmd.append("-B")
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if verbose or res.returncode != 0:
+            print(res.stdout)
+        if res.returncode != 0 or not os.path.exists(target):
+            raise EffOCRHipError(f"building {os.path.basename(target)} failed:\n" + res.stdout[-4000:])
+    return so
+
+
+def use_library(path=None):
+    """Switch the process to another build of the library (tests: SO_PATH_AB) — or back to the default with ``None``.  Engine objects
+    keep the handle they were created with, so objects made before and after a switch do not mix.  Returns the previous path."""
+    global _lib, SO_PATH, EXPORTS
+    with _lock:
+        prev = SO_PATH
+        SO_PATH = path or os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip.so")
+        if SO_PATH != prev:
+            _lib = _loaded.get(SO_PATH)
+    return prev
 
 
 def _declare(lib):
@@ -140,7 +158,7 @@ def lib():
             older_ok = bool(os.environ.get("EFFOCR_HIP_LIB")) and os.environ.get("EFFOCR_HIP_ALLOW_OLDER_ABI") == "1" and 0 < got <= ABI_VERSION
             if got != ABI_VERSION and not older_ok:
                 raise EffOCRHipError(f"libeffocr_hip.so ABI version {got} != {ABI_VERSION} expected by this package: rebuild (make -C effocr_amd/csrc)")
-            _lib = handle
+            _lib = _loaded[SO_PATH] = handle
     return _lib
 
 

@@ -10,6 +10,13 @@ int mlp_launch_bf16p(const MlpArgs& a, hipStream_t s);
 int mlp_launch_f16(const MlpArgs& a, hipStream_t s);
 int mlp_launch_f16p(const MlpArgs& a, hipStream_t s);
 
+// Width class of the row-panel / per-image / fused-MLP kernels (ViT-S and the miniature test width): 16-bit operands, K in {128, 384}.
+// Declared next to panel_gemm (kernels.hpp) because the A/B row-panel GEMM has exactly this domain; the forward uses it to choose
+// the ViT-S kernel family.
+bool panel_gemm_supported(int prec, int N, int K) {
+  return (prec == PREC_BF16 || prec == PREC_FP16) && (K == 384 || K == 128) && N > 0 && N % 128 == 0 && N <= 4 * K;
+}
+
 bool mlp_fused_supported(int prec, int D, int H) {
   return (prec == PREC_BF16 || prec == PREC_FP16) && ((D == 384 && H == 1536) || (D == 128 && H == 512));
 }

@@ -501,10 +501,8 @@ int launch_panel_full(int pro, int epi, const PanelArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool panel_gemm_supported(int prec, int N, int K) {
-  return (prec == PREC_BF16 || prec == PREC_FP16) && (K == 384 || K == 128) && N > 0 && N % 128 == 0 && N <= 4 * K;
-}
-
+// (panel_gemm_supported — the width predicate the forward also uses to pick the ViT-S class of kernels — lives in mlp.hip, which
+// is part of BOTH builds; this translation unit is linked into the A/B build only: make AB=1)
 int panel_gemm(int prec, int pro, int epi, const PanelArgs& a, hipStream_t s) {
   if (a.M <= 0) return EFFOCR_OK;
   if (!panel_gemm_supported(prec, a.N, a.K)) return fail(EFFOCR_EUNSUPPORTED, "panel_gemm: needs bf16/fp16, K in {128,384}, N % 128 == 0, N <= 4K");

@@ -104,7 +104,8 @@ class IndexFlatIP:
         if nq is None:
             return self.ntotal >= self.SCREEN_MIN_ROWS
         stream_cap = 64 if self.d <= 384 else 32
-        return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512)
+        # (k = 1 on a small index: the exact kernel keeps one-entry lists — 98 vs 111 us at 10 k rows x 1024 queries, tools/knn_c2_sweep.py)
+        return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512 and k > 1)
 
     def _screen_copy(self):
         if self._xb16 is None:

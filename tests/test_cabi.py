@@ -30,6 +30,29 @@ def test_every_declared_symbol_is_exported_and_bound(hip_lib):
     assert hip_lib.effocr_abi_version() == declared == _lib.ABI_VERSION
 
 
+def test_product_and_ab_builds(hip_lib):
+    """`make` = the product library (only what the default dispatch and the documented modes can reach: about 4 MB); `make AB=1` = the
+    same + the row-panel GEMM and the fused MLP without the projection phase for the A/B tests.  Same exported ABI; in the product
+    build the A/B-only entry points fail loudly with EFFOCR_EUNSUPPORTED instead of not existing."""
+    assert os.path.getsize(os.path.join(ROOT, "effocr_amd", "libeffocr_hip.so")) < 4.2e6
+    assert os.path.exists(_lib.SO_PATH_AB), "build the A/B library: python -c 'import __graft_entry__ as g; g.build()'"
+    assert os.path.getsize(_lib.SO_PATH_AB) > os.path.getsize(os.path.join(ROOT, "effocr_amd", "libeffocr_hip.so")) + 2e6
+    ab = ctypes.CDLL(_lib.SO_PATH_AB)
+    for n in declared_functions():
+        assert hasattr(ab, n), f"{n} missing from the A/B build"
+    assert ab.effocr_abi_version() == hip_lib.effocr_abi_version()
+    # an A/B-only operator through the PRODUCT library: a 16-bit linear at a ViT-S width dispatches to the row-panel GEMM (no GPU needed:
+    # the stub fails before any launch)
+    assert hip_lib.effocr_op_linear(0, 0, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, ctypes.c_void_p(16), 4, 384, 384, None) == -2
+    assert b"A/B path" in hip_lib.effocr_last_error()
+    prev = _lib.use_library(_lib.SO_PATH_AB)
+    try:
+        assert _lib.lib() is not hip_lib and _lib.SO_PATH == _lib.SO_PATH_AB
+    finally:
+        _lib.use_library(None if prev.endswith("libeffocr_hip.so") else prev)
+    assert _lib.lib() is hip_lib
+
+
 @pytest.mark.parametrize("arch,img,D", [("vit_small_patch16_224", 224, 384), ("vit_base_patch16_224", 224, 768),
                                         ("resnet18", 32, 512), ("vit_tiny_test", 64, 128)])
 def test_encoder_handle_param_table(hip_lib, arch, img, D):

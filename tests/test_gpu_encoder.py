@@ -90,7 +90,7 @@ def test_batch_invariance_and_determinism(dev):
         assert torch.equal(enc.forward(x[lo:hi].contiguous()), full[lo:hi])
 
 
-def test_panel_and_streaming_paths_agree(dev):
+def test_panel_and_streaming_paths_agree(dev, ab_lib):
     """The row-panel (fused LayerNorm) path and the K-streaming + LayerNorm-kernel path are two
     implementations of the same arithmetic; both must sit within the bf16 bound of the oracle and
     within operand-rounding noise of each other."""
@@ -131,7 +131,7 @@ def test_input_validation(dev):
 
 
 @pytest.mark.parametrize("B", [1, 3, 70])
-def test_every_switchable_path_matches_the_oracle(dev, B):
+def test_every_switchable_path_matches_the_oracle(dev, ab_lib, B):
     """Default path (fused im2col + patch embedding, fused qkv + attention with the heads of an image split over workgroups for small
     batches, projection fused into the fused MLP kernel) and every A/B switch of the library — unfused MLP, projection as its own
     row-panel launch, gemm2 instead of gemm3, no tail split, im2col kernel + GEMM, no head split,
@@ -161,7 +161,7 @@ def test_every_switchable_path_matches_the_oracle(dev, B):
             assert rel_err(o, ref) <= REL[prec], (name, prec, B, rel_err(o, ref))
 
 
-def test_fused_attention_default_dispatch_and_full_batch(dev):
+def test_fused_attention_default_dispatch_and_full_batch(dev, ab_lib):
     """From 192 crops on the default path is the fused qkv+attention kernel (persistent workgroups: 300 crops = 2 images on
     44 of 256 workgroups) with the MLP kernel's second output feeding it; it must agree with the panel path on the same
     batch at the precision mode's noise, be deterministic, and match oracle A on sampled rows."""

@@ -36,7 +36,8 @@ def op_linear(L, dev, prec, epi, x, w, bias, resid=None):
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("epi", ["bias", "bias_gelu", "bias_resid"])
 @pytest.mark.parametrize("shape", [(197 * 3, 384, 384), (100, 128, 1536), (256, 1152, 384), (1, 128, 128)])
-def test_linear(hip_lib, dev, prec, epi, shape):
+def test_linear(ab_lib, dev, prec, epi, shape):
+    hip_lib = ab_lib                                    # A/B build: this entry point reaches kernels outside the product library
     M, N, K = shape
     g = torch.Generator().manual_seed(M * 7 + N + K)
     x = torch.randn(M, K, generator=g).to(TDT[prec])
@@ -77,7 +78,8 @@ def test_layernorm(hip_lib, dev, prec, D, rows):
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("epi", ["bias", "bias_gelu", "bias_resid"])
 @pytest.mark.parametrize("shape", [(197 * 5, 1152, 384), (300, 384, 384), (129, 1536, 384), (77, 384, 128), (128, 512, 128)])
-def test_ln_linear_fused(hip_lib, dev, prec, epi, shape):
+def test_ln_linear_fused(ab_lib, dev, prec, epi, shape):
+    hip_lib = ab_lib                                    # A/B build: this entry point reaches kernels outside the product library
     """Row-panel kernel with the LayerNorm fused into the operand load vs LN -> round -> linear."""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K)
@@ -138,7 +140,8 @@ def test_attention(hip_lib, dev, prec, B, T, heads):
     assert err <= tol * ref.abs().max().item(), f"err {err:.3e} vs scale {ref.abs().max().item():.3e}"
 
 
-def test_unsupported_shapes_fail_loudly(hip_lib, dev):
+def test_unsupported_shapes_fail_loudly(ab_lib, dev):
+    hip_lib = ab_lib                                    # A/B build: this entry point reaches kernels outside the product library
     x = torch.zeros(4, 100, device=dev, dtype=torch.bfloat16)
     w = torch.zeros(128, 100, device=dev, dtype=torch.bfloat16)
     b = torch.zeros(128, device=dev)
@@ -242,7 +245,8 @@ def perm16_columns(w):
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("scratch", [False, True])
 @pytest.mark.parametrize("shape", [(197 * 5, 384, 1536), (100, 128, 512), (1, 384, 1536), (128 * 3, 128, 512), (40000, 384, 1536), (128 * 140, 384, 1536)])
-def test_mlp_fused_blocked(hip_lib, dev, prec, shape, scratch):
+def test_mlp_fused_blocked(ab_lib, dev, prec, shape, scratch):
+    hip_lib = ab_lib                                    # A/B build: this entry point reaches kernels outside the product library
     """mlp.hip: x + fc2(gelu(fc1(LN(x)))) in one kernel vs an fp64 restatement with the same operand rounding points
     (LN output and GELU output rounded to the operand type, as the unfused path does)."""
     M, D, H = shape
@@ -373,7 +377,8 @@ def test_qkv_attn_fused_argument_checks(hip_lib, dev):
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("scratch", [False, True])
 @pytest.mark.parametrize("shape", [(197 * 5, 384, 1536), (100, 128, 512), (40000, 384, 1536)])
-def test_mlp_fused_second_output(hip_lib, dev, prec, shape, scratch):
+def test_mlp_fused_second_output(ab_lib, dev, prec, shape, scratch):
+    hip_lib = ab_lib                                    # A/B build: this entry point reaches kernels outside the product library
     """mlp.hip with the next block's norm1 as a second output (xn = LN(x_new), 16-bit blocked): both the in-kernel epilogue
     (whole panels) and the blocked-LayerNorm launch over the split tail panels (scratch given: 40000 rows = 256 + 57 panels)."""
     M, D, H = shape
