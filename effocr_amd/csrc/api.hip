@@ -43,7 +43,8 @@ struct Param { std::string name; std::vector<int64_t> shape; int64_t numel; std:
 
 struct VitCfg { int D, depth, heads, mlp; };
 struct VitLayerOff { size_t ln1w, ln1b, qkvb, projb, ln2w, ln2b, fc1b, fc2b, qkvw, projw, fc1w, fc2w;
-                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, projw_pp, fc2w_pp, projb_p, fc2b_p, qkvw_bv, qkvb_v; };   // qkvw_bv / qkvb_v: the v rows permuted per 32 (qkvattn.hip)   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // fc2w_pp: k also permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
+                     size_t qkvw_b, projw_b, fc1w_b, fc2w_b, projw_pp, fc2w_pp, projb_p, fc2b_p, qkvw_bv, qkvb_v;
+                     size_t qkvw_bf, qkv_s, qkv_c, fc1w_bf, fc1_s, fc1_c; };   // _bf: blocked copy of W . diag(gamma) of the LayerNorm in front; _s: its row sums; _c: b + W beta (gemm3's folded LayerNorm)   // qkvw_bv / qkvb_v: the v rows permuted per 32 (qkvattn.hip)   // _pp / b_p: + rows permuted per 32 (proj fused into the MLP kernel)   // fc2w_pp: k also permuted per 16 (fused MLP)   // *_b: fragment-blocked copies (gemm3), 16-bit modes only
 struct ConvSpec { std::string w, bn; int cin, cout, k, stride, pad; size_t w_off, b_off; };
 
 }  // namespace
@@ -79,6 +80,7 @@ struct effocr_encoder {
   int use_patchf = 1;               // fused im2col + patch-embed GEMM (patch.hip) on the blocked path (0: im2col kernel + gemm2, A/B switch)
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
+  int use_lnfold = 1;               // gemm3 path (ViT-B): LayerNorm folded into the residual producers' / qkv, fc1 consumers' epilogues (0: LayerNorm launches, A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
@@ -176,6 +178,8 @@ void build_vit(effocr_encoder* e) {
         L.qkvw_b = a.take((size_t)3 * D * D * es);
         L.projw_b = a.take((size_t)D * D * es);
         L.fc1w_b = a.take((size_t)mlp * D * es);
+        L.qkvw_bf = a.take((size_t)3 * D * D * es); L.qkv_s = a.take((size_t)3 * D * 4); L.qkv_c = a.take((size_t)3 * D * 4);
+        L.fc1w_bf = a.take((size_t)mlp * D * es); L.fc1_s = a.take((size_t)mlp * 4); L.fc1_c = a.take((size_t)mlp * 4);
       }
     }
   }
@@ -269,6 +273,30 @@ void put_f32_rowperm(std::vector<char>& blob, size_t off, const float* src, int 
 
 const std::vector<float>& P(const effocr_encoder* e, const std::string& n) { return e->params[e->index.at(n)].data; }
 
+// LayerNorm folded into the linear behind it (gemm3.hip, GemmArgs::lnf): y = W (gamma (x - mean) rstd + beta) + b
+//   = rstd (W' x - mean s) + c   with   W' = W diag(gamma) (rounded to the operand type, blocked),  s[n] = sum_k W'[n][k] (of the ROUNDED
+// values: exactly what the MFMAs multiply),  c = b + W beta (fp32).
+void put_lnfold(std::vector<char>& blob, size_t w_off, size_t s_off, size_t c_off, const float* W, const float* b, const float* gamma,
+                const float* beta, int N, int K, int prec) {
+  std::vector<float> wf((size_t)N * K);
+  float* sd = reinterpret_cast<float*>(blob.data() + s_off);
+  float* cd = reinterpret_cast<float*>(blob.data() + c_off);
+  for (int n = 0; n < N; ++n) {
+    double ss = 0.0, cc = b[n];
+    for (int k = 0; k < K; ++k) {
+      const float v = W[(size_t)n * K + k] * gamma[k];
+      wf[(size_t)n * K + k] = v;
+      float r;
+      if (prec == PREC_BF16) { const uint32_t u = (uint32_t)f32_to_bf16(v) << 16; memcpy(&r, &u, 4); }
+      else r = (float)(_Float16)v;
+      ss += (double)r;
+      cc += (double)W[(size_t)n * K + k] * (double)beta[k];
+    }
+    sd[n] = (float)ss; cd[n] = (float)cc;
+  }
+  put_op_blocked(blob, w_off, wf.data(), N, K, prec);
+}
+
 void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
   const int D = e->vit.D;
   std::vector<float> cp(D);
@@ -307,6 +335,10 @@ void pack_vit(const effocr_encoder* e, std::vector<char>& blob) {
         put_op_blocked(blob, L.qkvw_b, P(e, p + "attn.qkv.weight").data(), 3 * D, D, e->prec);
         put_op_blocked(blob, L.projw_b, P(e, p + "attn.proj.weight").data(), D, D, e->prec);
         put_op_blocked(blob, L.fc1w_b, P(e, p + "mlp.fc1.weight").data(), e->vit.mlp, D, e->prec);
+        put_lnfold(blob, L.qkvw_bf, L.qkv_s, L.qkv_c, P(e, p + "attn.qkv.weight").data(), P(e, p + "attn.qkv.bias").data(),
+                   P(e, p + "norm1.weight").data(), P(e, p + "norm1.bias").data(), 3 * D, D, e->prec);
+        put_lnfold(blob, L.fc1w_bf, L.fc1_s, L.fc1_c, P(e, p + "mlp.fc1.weight").data(), P(e, p + "mlp.fc1.bias").data(),
+                   P(e, p + "norm2.weight").data(), P(e, p + "norm2.bias").data(), e->vit.mlp, D, e->prec);
       }
     }
   }
@@ -368,7 +400,7 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
   return rc;
 }
 
-struct VitWs { size_t status, x, xn, qkv, att, h, total, rows, hbytes; };
+struct VitWs { size_t status, x, xn, qkv, att, h, stats, total, rows, hbytes; };
 VitWs vit_ws(const effocr_encoder* e, int B) {
   // rows padded to the panel height (128) so that the row-panel kernels store without bounds checks
   const size_t M = align_up((size_t)B * e->T, 128), D = e->vit.D, es = prec_esize(e->prec);
@@ -382,6 +414,7 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
   size_t hb = M * e->vit.mlp * es, pb = (size_t)B * e->P * 768 * es;
   w.hbytes = hb > pb ? hb : pb;
   w.h = a.take(w.hbytes);                   // patches (im2col rows) alias the MLP hidden buffer
+  w.stats = a.take(M * 64);                 // per-row (sum, sum of squares) slice partials of the folded LayerNorm (gemm3 path)
   w.total = a.off;
   return w;
 }
@@ -498,15 +531,25 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
       p.blk_a = blk; p.blk_out = blk;
       if ((rc = timed(e, "panel_ln_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return panel_gemm(prec, PRO_LN, EPI_BIAS_GELU, p, s); }))) return rc;
     } else if (blk) {
-      auto lin = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi) {
+      // LayerNorm folded into the linears either side of it (gemm3.hip): the residual producers (proj, fc2) also write the new row as 16-bit
+      // operands into xn + per-row slice sums into `stats`; qkv / fc1 read those and finish the normalisation in their epilogues.  Only block
+      // 0's norm1 (rows written by the patch embedding) is a LayerNorm launch: 1 instead of 24 per forward.
+      const bool fold = e->use_lnfold && g3 && gemm3_lnfold_supported(D);
+      float* stats = reinterpret_cast<float*>(ws + w.stats);
+      // fl: 0 plain, 1 consumer of a folded LayerNorm (X = xn as un-normalised operands), 2 producer (residual epilogue + xn + stats)
+      auto lin = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi, int fl = 0, const float* cs = nullptr) {
         GemmArgs q{};
         q.X = X; q.ldx = K; q.Wblk = wb + wblk; q.bias = bias; q.out = out; q.ldo = N; q.M = M; q.N = N; q.K = K;
         q.blk_x = 1; q.blk_out = 1; q.rows_alloc = (int)w.rows; q.no_tail_split = !e->tail_split;
         if (epi == EPI_BIAS_RESID) { q.resid = xs; q.ldr = N; }
+        if (fl == 1) { q.lnf = 1; q.lnf_stats = stats; q.lnf_s = cs; q.lnf_eps = 1e-6f; }
+        if (fl == 2) { q.stats = stats; q.x16 = xn; }
         return gemm3_nt(prec, epi, q, s);
       };
-      if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
-      if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] { return lin(xn, D, L.qkvw_b, F(L.qkvb), qkv, 3 * D, EPI_BIAS); }))) return rc;
+      const bool fold1 = fold && i > 0;                    // norm1 of this block was folded by the previous block's fc2
+      if (!fold1 && (rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
+      if ((rc = timed(e, "gemm_qkv", 2.0 * Md * 3.0 * Dd * Dd, s, [&] {
+            return fold1 ? lin(xn, D, L.qkvw_bf, F(L.qkv_c), qkv, 3 * D, EPI_BIAS, 1, F(L.qkv_s)) : lin(xn, D, L.qkvw_b, F(L.qkvb), qkv, 3 * D, EPI_BIAS); }))) return rc;
       if ((rc = timed(e, "attention", 4.0 * B * e->vit.heads * (double)T * T * 64.0, s, [&] { return attention(prec, qkv, att, B, T, e->vit.heads, 1, s); }))) return rc;
       const size_t Bp = align_up((size_t)B, 256);
       if (i + 1 == e->vit.depth && e->cls_only_last && g3 && Bp <= w.rows) {
@@ -515,24 +558,36 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         float* xc = reinterpret_cast<float*>(qkv);
         void* ac = static_cast<char*>(qkv) + Bp * D * 4;
         if ((rc = timed(e, "gather_cls", 0.0, s, [&] { return gather_cls_rows_blocked(xs, att, B, T, D, xc, ac, s); }))) return rc;
-        auto linc = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi) {
+        auto linc = [&](const void* X, int K, size_t wblk, const float* bias, void* out, int N, int epi, int fl = 0, const float* cs = nullptr) {
           GemmArgs q{};
           q.X = X; q.ldx = K; q.Wblk = wb + wblk; q.bias = bias; q.out = out; q.ldo = N; q.M = B; q.N = N; q.K = K;
           q.blk_x = 1; q.blk_out = 1; q.rows_alloc = (int)Bp; q.no_tail_split = !e->tail_split;
           if (epi == EPI_BIAS_RESID) { q.resid = xc; q.ldr = N; }
+          if (fl == 1) { q.lnf = 1; q.lnf_stats = stats; q.lnf_s = cs; q.lnf_eps = 1e-6f; }
+          if (fl == 2) { q.stats = stats; q.x16 = xn; }
           return gemm3_nt(prec, epi, q, s);
         };
         const double Bd = B;
-        if ((rc = timed(e, "cls_proj_resid", 2.0 * Bd * Dd * Dd, s, [&] { return linc(ac, D, L.projw_b, F(L.projb), xc, D, EPI_BIAS_RESID); }))) return rc;
-        if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xc, B, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
-        if ((rc = timed(e, "cls_fc1_gelu", 2.0 * Bd * Hd * Dd, s, [&] { return linc(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;
+        if ((rc = timed(e, "cls_proj_resid", 2.0 * Bd * Dd * Dd, s, [&] { return linc(ac, D, L.projw_b, F(L.projb), xc, D, EPI_BIAS_RESID, fold ? 2 : 0); }))) return rc;
+        if (!fold && (rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xc, B, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
+        if ((rc = timed(e, "cls_fc1_gelu", 2.0 * Bd * Hd * Dd, s, [&] {
+              return fold ? linc(xn, D, L.fc1w_bf, F(L.fc1_c), hb, e->vit.mlp, EPI_BIAS_GELU, 1, F(L.fc1_s)) : linc(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;
         if ((rc = timed(e, "cls_fc2_resid", 2.0 * Bd * Dd * Hd, s, [&] { return linc(hb, e->vit.mlp, L.fc2w_b, F(L.fc2b), xc, D, EPI_BIAS_RESID); }))) return rc;
         cls_x = xc;
         continue;
       }
-      if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return lin(att, D, L.projw_b, F(L.projb), xs, D, EPI_BIAS_RESID); }))) return rc;
-      if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
-      if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] { return lin(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;
+      if ((rc = timed(e, "gemm_proj_resid", 2.0 * Md * Dd * Dd, s, [&] { return lin(att, D, L.projw_b, F(L.projb), xs, D, EPI_BIAS_RESID, fold ? 2 : 0); }))) return rc;
+      if (!fold && (rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows_blocked(prec, xs, M, D, F(L.ln2w), F(L.ln2b), 1e-6f, xn, s); }))) return rc;
+      if ((rc = timed(e, "gemm_fc1_gelu", 2.0 * Md * Hd * Dd, s, [&] {
+            return fold ? lin(xn, D, L.fc1w_bf, F(L.fc1_c), hb, e->vit.mlp, EPI_BIAS_GELU, 1, F(L.fc1_s)) : lin(xn, D, L.fc1w_b, F(L.fc1b), hb, e->vit.mlp, EPI_BIAS_GELU); }))) return rc;
+      if (fold && g3 && i + 1 < e->vit.depth) {            // fc2 + residual, and the next block's norm1 folded: its rows + statistics
+        GemmArgs q{};
+        q.X = hb; q.ldx = e->vit.mlp; q.Wblk = wb + L.fc2w_b; q.bias = F(L.fc2b); q.out = xs; q.ldo = D; q.resid = xs; q.ldr = D;
+        q.M = M; q.N = D; q.K = e->vit.mlp; q.blk_x = 1; q.blk_out = 1; q.rows_alloc = (int)w.rows; q.no_tail_split = !e->tail_split;
+        q.stats = stats; q.x16 = xn;
+        if ((rc = timed(e, "gemm_fc2_resid", 2.0 * Md * Dd * Hd, s, [&] { return gemm3_nt(prec, EPI_BIAS_RESID, q, s); }))) return rc;
+        continue;
+      }
     } else {
       if ((rc = timed(e, "layernorm", 0.0, s, [&] { return layernorm_rows(prec, xs, M, D, F(L.ln1w), F(L.ln1b), 1e-6f, xn, s); }))) return rc;
       g = GemmArgs{};
@@ -731,6 +786,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "use_blocked") { enc->use_blocked = value; return EFFOCR_OK; }
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
+  if (n == "use_lnfold") { enc->use_lnfold = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
   if (n == "use_qkvattn") { enc->use_qkvattn = value; return EFFOCR_OK; }
   if (n == "qa_min_batch") { enc->qa_min_batch = value; return EFFOCR_OK; }

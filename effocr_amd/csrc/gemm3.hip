@@ -40,7 +40,11 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 
 // JT = 32-token tiles per wave: 4 (256-token workgroup tile, the main launch) or 1 / 2 (64 / 128-token tiles
 // for the leftover token tiles of the last, partially filled round of CUs — see gemm3_nt)
-template <typename E, int NT, int JT, int EPI, typename TO>
+// FOLD: the LayerNorm between a residual producer and the next linear is folded into both (GemmArgs::stats / lnf; api.hip): for
+// EPI_BIAS_RESID the kernel also writes the row as 16-bit operands + per-slice (sum, sum of squares); for the other epilogues it reads
+// those and finishes the normalisation.  Compile-time: a wave-uniform runtime flag put a branch around every store group of the epilogue
+// and the values held across them spilled next to the 256 accumulators.
+template <typename E, int NT, int JT, int EPI, typename TO, bool FOLD = false>
 __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs g) {
   constexpr int TN = NT * 64, G3M = JT * 64;
   constexpr int XS = G3M * 64, WS = TN * 64, STAGE = XS + WS;          // bytes per 32-k stage
@@ -66,6 +70,22 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   const int nst = g.K >> 5;
   const int kch = g.K >> 3;                                            // 16-byte chunks per operand row
   const int last_rb = (g.rows_alloc >> 5) - 1;                         // last addressable X row block
+
+  // Folded LayerNorm (consumer side): the row statistics of this lane's JT tokens are requested FIRST — oldest in the in-order VM queue, so
+  // they have landed when the ring's stage 0 has — and reduced to (rstd, -mean rstd) behind the first barrier.  (Loaded in the epilogue
+  // they were four dependent HBM round trips per tile, one per token tile: fc1 908 -> 863 TFLOP/s.)
+  constexpr bool LNF = EPI != EPI_BIAS_RESID && FOLD;
+  f32x4 stv[JT][4];
+  float rstd_j[JT], nmr_j[JT];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int m = m0 + wm * JT * 32 + j * 32 + r31;
+      const f32x4* st = reinterpret_cast<const f32x4*>(g.lnf_stats + (size_t)(m < g.M ? m : g.M - 1) * 16);
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) stv[j][p2] = st[p2];               // slices 2 p2, 2 p2 + 1: (sum, sum of squares) each
+    }
+  }
 
   // per-lane DMA sources; piece q (1 KB = two adjacent 16-B chunk cells of one 32-row block) lands at q KB
   const char* src[PP];
@@ -149,6 +169,25 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   __builtin_amdgcn_s_barrier();                                        // ... and everybody's
   asm volatile("" ::: "memory");
   static_for<0, NF>([&](auto N_) { load_one(fa, smem, 0, N_); });
+  if constexpr (LNF) {
+    const int np = g.K >> 7;                                           // 128-feature slices the producer cut the row into (<= 8)
+    const float invk = 1.0f / (float)g.K;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      float S = 0.f, SS = 0.f;
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        if (2 * p2 < np) { S += stv[j][p2][0]; SS += stv[j][p2][1]; }
+        if (2 * p2 + 1 < np) { S += stv[j][p2][2]; SS += stv[j][p2][3]; }
+      }
+      const float mean = S * invk;
+      float var = SS * invk - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      rstd_j[j] = 1.0f / sqrtf(var + g.lnf_eps);
+      nmr_j[j] = -mean * rstd_j[j];
+      asm volatile("" : "+v"(rstd_j[j]), "+v"(nmr_j[j]));              // pin the reduction HERE (sunk to its use in the epilogue, the 16 raw registers per token tile stayed live across the main loop and spilled)
+    }
+  }
 
   // One stage.  MORE: stage s+4 exists (DMA it), NEXT: stage s+1 exists (prefetch its fragments).  Both are
   // compile-time so that the steady state is ONE basic block: with a single wave per SIMD every scalar
@@ -182,28 +221,51 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
     stage(s, std::false_type{}, std::false_type{});
   }
 
-  // ---- epilogue: lane = token (m0 + (wm*JT + j)*32 + r31), 4 consecutive features per (i, q)
-  TO* out = static_cast<TO*>(g.out);
+  // ---- epilogue: lane = token (m0 + (wm*JT + j)*32 + r31), 4 consecutive features per (i, q): n = nb + 32 i + 8 q.
+  // Addresses: ONE 64-bit base per token tile j and operand, everything else is a compile-time offset — a lane's features (i, q) sit in
+  // fp32 chunk c4 + 8 i + 2 q and in 16-bit chunk c8 + 4 i + q (bytes 8 half .. 8 half + 7) of its row, chunks are 512 bytes apart.
+  // (blk_off per (i, q) cost a 64-bit multiply-add each and, next to 256 accumulators, spilled the bias registers.)
   constexpr int CH = 16 / (int)sizeof(TO);                             // elements per 16-byte output chunk
-  const int nb = n0 + wn * NT * 32 + 4 * half;
+  const int ns = n0 + wn * NT * 32;                                    // first feature of the wave's slice (a multiple of 32)
+  const int nb = ns + 4 * half;
   f32x4 bv[NT][4];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(g.bias + nb + i * 32 + 8 * q);
+  // LayerNorm folded into this linear (GemmArgs::lnf; wave-uniform): X holds the UN-normalised rows as 16-bit operands, W carries gamma,
+  // bias carries W.beta, and the row statistics arrive as per-slice partial sums written by the producer of the rows (below):
+  //     y = rstd (acc - mean s[n]) + bias[n],   s[n] = sum_k W'[n][k]
+  constexpr bool lnf = EPI != EPI_BIAS_RESID && FOLD;
+  constexpr bool do16 = EPI == EPI_BIAS_RESID && FOLD;                // producer: rows also as 16-bit operands ...
+  constexpr bool dost = do16;                                          // ... + per-slice (sum, sum of squares) of every row
+  f32x4 sv[NT][4];
+  if constexpr (lnf) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sv[i][q] = *reinterpret_cast<const f32x4*>(g.lnf_s + nb + i * 32 + 8 * q);
+  }
 #pragma unroll
   for (int j = 0; j < JT; ++j) {
     const int m = m0 + wm * JT * 32 + j * 32 + r31;
     const bool ok = m < g.M;
     const int mr = ok ? m : g.M - 1;
+    const int64_t rbi = mr >> 5;
+    const int rl = (mr & 31) * 16;
+    char* ob = static_cast<char*>(g.out) + (rbi * (g.N / CH) + ns / CH) * 512 + rl + (CH == 4 ? half * 512 : half * 8);
+    constexpr int OI = CH == 4 ? 8 * 512 : 4 * 512, OQ = CH == 4 ? 2 * 512 : 512;   // byte steps of i and q
+    float rstd = 1.f, nmr = 0.f;                                       // lnf: 1 / sqrt(var + eps), -mean * rstd of this lane's token
+    if constexpr (lnf) { rstd = rstd_j[j]; nmr = nmr_j[j]; }
     if constexpr (EPI == EPI_BIAS_RESID) {
+      const char* rp = reinterpret_cast<const char*>(g.resid) + (rbi * (g.N / 4) + ns / 4) * 512 + rl + half * 512;
       f32x4 rv[NT][4];
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rv[i][q] = GEMM3_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.resid) + blk_off(mr, (nb + i * 32 + 8 * q) >> 2, g.N >> 2)))
-                              : *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.resid) + blk_off(mr, (nb + i * 32 + 8 * q) >> 2, g.N >> 2));
+          rv[i][q] = GEMM3_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + i * OI + q * OQ))
+                              : *reinterpret_cast<const f32x4*>(rp + i * OI + q * OQ);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -211,13 +273,35 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[i][q][e];
     }
+    float psum = 0.f, psq = 0.f;                                       // producer: this lane's share of the slice's (sum, sum of squares)
+    char* x16b = do16 ? static_cast<char*>(g.x16) + (rbi * (g.N / 8) + ns / 8) * 512 + rl + half * 8 : nullptr;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       float v[16];
+      if constexpr (lnf) {
+        // as two-element vector FMAs (v_pk_fma_f32 with the row scalars duplicated): left to itself the GELU variant scalarised the 512
+        // FMAs of a (i, j) tile pair — +22 % epilogue instructions, fc1 908 -> 840 TFLOP/s
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 r2 = {rstd, rstd}, n2 = {nmr, nmr};
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + bv[i][q][e];
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 a2 = {acc[i][j][4 * q + e], acc[i][j][4 * q + e + 1]};
+            const f32x2 s2 = {sv[i][q][e], sv[i][q][e + 1]}, b2 = {bv[i][q][e], bv[i][q][e + 1]};
+            const f32x2 y2 = __builtin_elementwise_fma(a2, r2, __builtin_elementwise_fma(n2, s2, b2));
+            v[4 * q + e] = y2[0]; v[4 * q + e + 1] = y2[1];
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + bv[i][q][e];
+      }
+      if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { psum += v[e]; psq = __builtin_fmaf(v[e], v[e], psq); }
+      }
       if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = (float)(E)v[e];              // same argument rounding as panel.hip
@@ -226,8 +310,7 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
       if (ok) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = nb + i * 32 + 8 * q;
-          char* p = reinterpret_cast<char*>(out) + blk_off(mr, n / CH, g.N / CH) + (n % CH) * (int)sizeof(TO);
+          char* p = ob + i * OI + q * OQ;
           if constexpr (sizeof(TO) == 4) {
             const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             if (GEMM3_NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = o;
@@ -235,6 +318,20 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
             const u32x2 o2 = pack4<TO>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
             if (GEMM3_NT & 2) __builtin_nontemporal_store(o2, reinterpret_cast<u32x2*>(p)); else *reinterpret_cast<u32x2*>(p) = o2;
           }
+          if constexpr (EPI == EPI_BIAS_RESID) {
+            if constexpr (do16)                                          // the new residual row as 16-bit operands of the next (LayerNorm-folded) linear
+              *reinterpret_cast<u32x2*>(x16b + (i * 4 + q) * 512) = pack4<E>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          }
+        }
+      }
+    }
+    if constexpr (EPI == EPI_BIAS_RESID) {
+      if constexpr (dost) {                                              // slice (column tile, wave half) of the row: both half-waves' shares, one writer
+        psum += __shfl_xor(psum, 32, 64);
+        psq += __shfl_xor(psq, 32, 64);
+        if (ok && half == 0) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<f32x2*>(g.stats + (size_t)mr * 16 + (nt * 2 + wn) * 2) = f32x2{psum, psq};
         }
       }
     }
@@ -245,10 +342,28 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
 template <typename E, int NT, int JT>
 int launch3_tile(int epi, const GemmArgs& g, hipStream_t s) {
   const int grid = ((g.M + JT * 64 - 1) / (JT * 64)) * (g.N / (NT * 64));
+  const bool fold = g.lnf != 0 || g.stats != nullptr;
+  if constexpr (NT != 4) {                                               // the folded LayerNorm is built for 256-wide tiles only (gemm3_nt checks)
+    switch (epi) {
+      case EPI_BIAS:       hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS, E>), dim3(grid), dim3(256), 0, s, g); break;
+      case EPI_BIAS_GELU:  hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_GELU, E>), dim3(grid), dim3(256), 0, s, g); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_RESID, float>), dim3(grid), dim3(256), 0, s, g); break;
+      default: return fail(EFFOCR_EINVAL, "gemm3: unknown epilogue");
+    }
+  } else
   switch (epi) {
-    case EPI_BIAS:       hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS, E>), dim3(grid), dim3(256), 0, s, g); break;
-    case EPI_BIAS_GELU:  hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_GELU, E>), dim3(grid), dim3(256), 0, s, g); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_RESID, float>), dim3(grid), dim3(256), 0, s, g); break;
+    case EPI_BIAS:
+      if (fold) hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS, E, true>), dim3(grid), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS, E>), dim3(grid), dim3(256), 0, s, g);
+      break;
+    case EPI_BIAS_GELU:
+      if (fold) hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_GELU, E, true>), dim3(grid), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_GELU, E>), dim3(grid), dim3(256), 0, s, g);
+      break;
+    case EPI_BIAS_RESID:
+      if (fold) hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_RESID, float, true>), dim3(grid), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm3_kernel<E, NT, JT, EPI_BIAS_RESID, float>), dim3(grid), dim3(256), 0, s, g);
+      break;
     default: return fail(EFFOCR_EINVAL, "gemm3: unknown epilogue");
   }
   return check_launch("gemm3");
@@ -277,6 +392,9 @@ int launch3(int epi, const GemmArgs& g, hipStream_t s) {
     t.X = static_cast<const char*>(g.X) + rb * (g.K / 8) * 512;
     t.out = static_cast<char*>(g.out) + rb * (g.N * osz / 16) * 512;
     if (g.resid) t.resid = reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.resid) + rb * (g.N / 4) * 512);
+    if (g.stats) t.stats = g.stats + rb * 32 * 16;
+    if (g.x16) t.x16 = static_cast<char*>(g.x16) + rb * (g.N / 8) * 512;
+    if (g.lnf) t.lnf_stats = g.lnf_stats + rb * 32 * 16;
     t.M = g.M - main_mt * 256;
     t.rows_alloc = g.rows_alloc - main_mt * 256;
     rc = (tail_wgs * 4 <= slots) ? launch3_tile<E, NT, 1>(epi, t, s) : launch3_tile<E, NT, 2>(epi, t, s);
@@ -285,6 +403,9 @@ int launch3(int epi, const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace
+
+// LayerNorm folded between a gemm3 producer of D-wide rows and its consumer: the row statistics travel as <= 8 slice partials
+bool gemm3_lnfold_supported(int D) { return D % 256 == 0 && D / 128 <= 8; }   // (256-wide tiles on both sides: ViT-B 768, ViT-L 1024)
 
 bool gemm3_supported(int prec, int N, int K) {
   return (prec == PREC_BF16 || prec == PREC_FP16) && N > 0 && (N % 256 == 0 || N % 192 == 0) && K >= 128 && K % 32 == 0;
@@ -297,6 +418,10 @@ int gemm3_nt(int prec, int epi, const GemmArgs& g_in, hipStream_t s) {
   GemmArgs g = g_in;
   if (g.rows_alloc <= 0) g.rows_alloc = ((g.M + 31) / 32) * 32;
   if (g.rows_alloc % 32 != 0 || g.rows_alloc < g.M) return fail(EFFOCR_EINVAL, "gemm3: rows_alloc must be a multiple of 32 covering M");
+  if ((g.stats || g.x16) && (epi != EPI_BIAS_RESID || !g.stats || !g.x16 || !gemm3_lnfold_supported(g.N)))
+    return fail(EFFOCR_EINVAL, "gemm3: row statistics / 16-bit row copy belong to the residual epilogue, both or neither, N in <= 8 slices");
+  if (g.lnf && (epi == EPI_BIAS_RESID || !g.lnf_stats || !g.lnf_s || !gemm3_lnfold_supported(g.K) || g.N % 256 != 0))
+    return fail(EFFOCR_EINVAL, "gemm3: folded LayerNorm needs the statistics, the column sums, a non-residual epilogue and K in <= 8 slices");
   const bool wide = g.N % 256 == 0;
   if (prec == PREC_BF16) return wide ? launch3<__bf16, 4>(epi, g, s) : launch3<__bf16, 3>(epi, g, s);
   return wide ? launch3<_Float16, 4>(epi, g, s) : launch3<_Float16, 3>(epi, g, s);

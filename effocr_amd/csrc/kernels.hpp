@@ -23,6 +23,12 @@ struct GemmArgs {
   const void* Wblk;                 // gemm3: W in the fragment-blocked layout [N/32][K/8][32][16 B]
   int rows_alloc;                   // gemm3: rows addressable in X / out / resid (multiple of 32; 0 = round M up)
   int no_tail_split;                // gemm3: 1 = one launch of 256-token tiles only (A/B switch)
+  // gemm3, LayerNorm folded into the linears either side of it (ViT-B path, api.hip): the producer of a residual row (EPI_BIAS_RESID)
+  // also writes the row as 16-bit operands (x16) and per-row partial (sum, sum of squares) of its 128-feature slices (stats: [row][8][2]
+  // fp32, slice = 2 * column tile + wave half); the consumer (lnf = 1: X = that x16, Wblk = W . diag(gamma), bias = b + W beta,
+  // lnf_s[n] = sum_k Wblk[n][k]) finishes y = rstd (acc - mean s) + bias in its epilogue — no LayerNorm launch, no fp32 re-read of x.
+  float* stats; void* x16;          // producer outputs (NULL: none)
+  const float* lnf_stats; const float* lnf_s; int lnf; float lnf_eps;   // consumer inputs
 };
 
 // gemm.hip
@@ -34,6 +40,7 @@ int gemm2_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 
 // gemm3.hip — 256 x {192,256} tiles, 128-row wave tiles, all operands fragment-blocked (fc2; every ViT-B linear)
 bool gemm3_supported(int prec, int N, int K);
+bool gemm3_lnfold_supported(int D);                    // D-wide rows: LayerNorm can be folded between a gemm3 producer and consumer
 int gemm3_nt(int prec, int epi, const GemmArgs& g, hipStream_t s);
 
 // mlp.hip — fused LayerNorm + fc1 + GELU + fc2 + residual over the blocked residual stream (hidden stays on chip)

@@ -42,6 +42,77 @@ __device__ __forceinline__ bool before(float s1, int i1, float s2, int i2) {
   return (s1 > s2) || (s1 == s2 && i1 < i2);
 }
 
+// ---- wave-wide "best of 64" in the compound order (score desc, id asc), on the DPP cross-lane paths --------------------------------
+// (the ds_bpermute form — two LDS-crossbar round trips per step, six steps, once per output — was most of the merge kernels' time).
+// Scores map to order-preserving unsigned keys (-0 folded onto +0 so that key equality is float equality); the winner is the lane with
+// the largest key and, among equal keys, the smallest id: one max-reduction and one min-reduction, 6 DPP steps each, result in lane 63.
+__device__ __forceinline__ unsigned f32_key(float f) {
+  unsigned u = __float_as_uint(f);
+  u = (u == 0x80000000u) ? 0u : u;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+template <bool MAX> __device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
+  constexpr int ident = MAX ? 0 : -1;                       // lanes without a source (row starts / unselected rows) contribute the identity
+#define KNN_DPP_STEP(ctrl, rows)                                                                            \
+  {                                                                                                         \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp(ident, (int)v, ctrl, rows, 0xf, false);       \
+    v = MAX ? (v > t_ ? v : t_) : (v < t_ ? v : t_);                                                        \
+  }
+  KNN_DPP_STEP(0x111, 0xf)                                   // row_shr:1
+  KNN_DPP_STEP(0x112, 0xf)                                   // row_shr:2
+  KNN_DPP_STEP(0x114, 0xf)                                   // row_shr:4
+  KNN_DPP_STEP(0x118, 0xf)                                   // row_shr:8   -> lane 15 of every row holds the row's result
+  KNN_DPP_STEP(0x142, 0xa)                                   // row_bcast:15 into rows 1, 3
+  KNN_DPP_STEP(0x143, 0xc)                                   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's result
+#undef KNN_DPP_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// every lane offers one candidate (s, i); returns the wave's best in (ws, wi) (uniform); true on the lane that offered it (ids of real
+// candidates are unique; all-sentinel waves return (-FLT_MAX, ID_NONE) and no winner)
+__device__ __forceinline__ bool wave_best(float s, int i, float& ws, int& wi) {
+  const unsigned key = f32_key(s);
+  const unsigned kmax = wave_reduce_u32<true>(key);
+  const unsigned imin = wave_reduce_u32<false>(key == kmax ? (unsigned)i : 0xffffffffu);
+  ws = key_f32(kmax); wi = (int)imin;
+  return key == kmax && i == wi && wi != ID_NONE;
+}
+
+// One wave merges `nl` sorted lists resident in LDS (entry t of list l at s[l * stride + t], `len` entries each, (score desc, id asc))
+// into the best `nout` of their union, in order: lane L owns lists L, L + 64, ... (LPL of them), keeps their heads in registers and
+// re-reads only the winner's next entry per output — one LDS round trip per output instead of one per list.  out(o, score, id) is called
+// by every lane with the same values.
+template <int LPL, typename F>
+__device__ __forceinline__ void wave_merge_lds(const float* s, const int* ix, int nl, int len, int stride, int nout, int lane, F&& out) {
+  float hs[LPL]; int hi[LPL]; int ptr[LPL];
+#pragma unroll
+  for (int c = 0; c < LPL; ++c) {
+    const int l = lane + 64 * c;
+    ptr[c] = 0;
+    hs[c] = -FLT_MAX; hi[c] = ID_NONE;
+    if (l < nl && len > 0) { hs[c] = s[l * stride]; hi[c] = ix[l * stride]; }
+  }
+  for (int o = 0; o < nout; ++o) {
+    float bs = hs[0]; int bi = hi[0]; int bc = 0;
+#pragma unroll
+    for (int c = 1; c < LPL; ++c)
+      if (before(hs[c], hi[c], bs, bi)) { bs = hs[c]; bi = hi[c]; bc = c; }
+    float ws; int wi;
+    const bool won = wave_best(bs, bi, ws, wi);
+    if (won) {
+#pragma unroll
+      for (int c = 0; c < LPL; ++c)
+        if (c == bc) {
+          const int l = lane + 64 * c;
+          ++ptr[c];
+          if (ptr[c] < len) { hs[c] = s[l * stride + ptr[c]]; hi[c] = ix[l * stride + ptr[c]]; }
+          else { hs[c] = -FLT_MAX; hi[c] = ID_NONE; }
+        }
+    }
+    out(o, ws, wi);
+  }
+}
+
 // sorted-list insert, statically indexed (register resident).  Candidates arrive in ascending id
 // order per lane, so a strict score compare keeps the lower id ahead on ties.
 template <int KMAX>
@@ -71,7 +142,8 @@ struct KnnArgs {
   const float* adist; const float* qnorm; float eps_scale;   // tau[q] = adist[q][k-1] - eps_scale * qnorm[q]
   int* cand; int* cnt; int cap;     // candidate ids [B][cap], counters [B]
   const int* run_flag;              // non-NULL: the launch is a no-op unless *run_flag != 0 (fallback after an overflow)
-  int ring;                         // knn_stream_kernel: LDS-DMA stages per wave
+  int ring;                         // knn_stream_kernel: transpose stages per wave (1 | 2)
+  int ctl_off;                      // knn_stream_kernel: LDS offset of the control words (block counter, shared score bounds)
   // k > 32: the result is produced 32 columns at a time.  Pass p writes columns [ocol, ocol + k) of the [B][ldo] outputs and
   // (AFTER) only ranks rows that come strictly AFTER the previous pass's last result (after_col) in the (score desc, id asc) order.
   int ldo, ocol, after_col;
@@ -257,49 +329,42 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
   }
 }
 
-// merge the per-chunk sorted lists of one query: one wave per query, lane L owns chunks L, L+64, ...
+// merge the per-chunk sorted lists of one query: one wave (= one workgroup) per query.  The query's lists — only their first
+// min(k, KMAX) entries can reach the output — are staged into LDS with every load in flight at once, then merged by wave_merge_lds
+// (lane L owns chunks L, L + 64, ...).  (Round 3's form re-read each head from global memory inside the output loop: one dependent
+// round trip per output, 9-14 us per call.)
 template <int KMAX>
-__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
-                                                        int B, int nchunks, int k, float* __restrict__ dist,
-                                                        int64_t* __restrict__ idx, const int* __restrict__ run_flag, int ldo, int ocol) {
+__global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
+                                                       int B, int nchunks, int k, float* __restrict__ dist,
+                                                       int64_t* __restrict__ idx, const int* __restrict__ run_flag, int ldo, int ocol) {
   if (run_flag != nullptr && *run_flag == 0) return;
+  extern __shared__ __attribute__((aligned(16))) char msm[];
   constexpr int LPL = MAX_CHUNKS / 64;
-  const int lane = threadIdx.x & 63;
-  const int qg = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qg >= B) return;                                   // whole wave exits together
-  int ptr[LPL];
-#pragma unroll
-  for (int c = 0; c < LPL; ++c) ptr[c] = 0;
-  for (int o = 0; o < k; ++o) {
-    float bs = -FLT_MAX; int bi = ID_NONE; int bc = -1;
-    if (o < KMAX) {
-#pragma unroll
-      for (int c = 0; c < LPL; ++c) {
-        const int chunk = lane + 64 * c;
-        if (chunk < nchunks && ptr[c] < KMAX) {
-          const int64_t off = ((int64_t)chunk * B + qg) * KMAX + ptr[c];
-          const float s = pdist[off]; const int i = pidx[off];
-          if (bc < 0 || before(s, i, bs, bi)) { bs = s; bi = i; bc = c; }
-        }
-      }
-    }
-    // wave argmax with the compound order; real ids are unique, so the owner is identifiable
-    float ws = bs; int wi = bi;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float os = __shfl_xor(ws, off, 64);
-      const int oi = __shfl_xor(wi, off, 64);
-      if (before(os, oi, ws, wi)) { ws = os; wi = oi; }
-    }
-    if (wi != ID_NONE && bc >= 0 && bi == wi) {
-#pragma unroll
-      for (int c = 0; c < LPL; ++c) ptr[c] += (c == bc);
-    }
+  const int lane = threadIdx.x;
+  const int qg = blockIdx.x;
+  const int kk = k < KMAX ? k : KMAX;                    // entries of a list that can matter
+  float* mS = reinterpret_cast<float*>(msm);             // [nchunks][kk]
+  int* mI = reinterpret_cast<int*>(msm) + nchunks * kk;
+  const int total = nchunks * kk;
+  for (int e = lane; e < total; e += 64) {
+    const int c = e / kk, t = e - c * kk;
+    const int64_t off = ((int64_t)c * B + qg) * KMAX + t;
+    mS[e] = pdist[off]; mI[e] = pidx[off];
+  }
+  __syncthreads();
+  wave_merge_lds<LPL>(mS, mI, nchunks, kk, kk, k, lane, [&](int o, float ws, int wi) {
     if (lane == 0) {
-      dist[(int64_t)qg * ldo + ocol + o] = ws;
+      dist[(int64_t)qg * ldo + ocol + o] = (wi == ID_NONE) ? -FLT_MAX : ws;
       idx[(int64_t)qg * ldo + ocol + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
     }
-  }
+  });
+}
+template <int KMAX>
+void launch_knn_merge(const float* pdist, const int* pidx, int B, int nchunks, int k, float* dist, int64_t* idx, const int* run_flag,
+                      int ldo, int ocol, hipStream_t s) {
+  const int kk = k < KMAX ? k : KMAX;
+  hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)B), dim3(64), (size_t)nchunks * kk * 8, s,
+                     pdist, pidx, B, nchunks, k, dist, idx, run_flag, ldo, ocol);
 }
 
 // y = x / max(||x||_2, 1e-12) row-wise (F.normalize, infer_effocr.py:316); one wave per row
@@ -354,8 +419,7 @@ int launch_knn(const KnnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((knn_partial_kernel<KMAX, E, false>), dim3((unsigned)(a.nqt * a.nchunks)), dim3(256), 0, s, a);
   int rc = check_launch("knn_partial");
   if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
-  hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
-                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol);
+  launch_knn_merge<KMAX>(a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol, s);
   return check_launch("knn_merge");
 }
 template <typename E>
@@ -459,20 +523,15 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < PER; ++t)
       if (before(ls[t], li[t], bs, bi)) { bs = ls[t]; bi = li[t]; }
-    float ws = bs; int wi = bi;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float os = __shfl_xor(ws, off, 64);
-      const int oi = __shfl_xor(wi, off, 64);
-      if (before(os, oi, ws, wi)) { ws = os; wi = oi; }
-    }
+    float ws; int wi;
+    wave_best(bs, bi, ws, wi);                             // (wave 0 is whole here: tid < 64)
     if (wi != ID_NONE) {
 #pragma unroll
       for (int t = 0; t < PER; ++t)
         if (li[t] == wi) { ls[t] = -FLT_MAX; li[t] = ID_NONE; }   // ids are unique: exactly one owner
     }
     if (lane == 0) {
-      dist[(int64_t)qg * k + o] = ws;
+      dist[(int64_t)qg * k + o] = (wi == ID_NONE) ? -FLT_MAX : ws;
       idx[(int64_t)qg * k + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
     }
   }
@@ -504,6 +563,15 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
 #define KNN_STREAM_NT 1                                  // the index rows pass once: non-temporal loads
 #endif
 constexpr int KS_THREADS = 512;
+// -DKNN_STAMP (tools/ab_build.sh variant, never shipped): every workgroup of the streaming kernel records s_memtime at its milestones;
+// tools/knn_timeline.py reads the last launch's table through effocr_debug_knn_stamps.
+#ifdef KNN_STAMP
+constexpr int KNN_STAMP_WGS = 256, KNN_STAMP_N = 8;
+__device__ unsigned long long knn_stamps[KNN_STAMP_WGS * KNN_STAMP_N];
+#define KNN_STAMP_AT(k) if (tid == 0) knn_stamps[(blockIdx.x & (KNN_STAMP_WGS - 1)) * KNN_STAMP_N + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define KNN_STAMP_AT(k)
+#endif
 // Q16 (<= 16 queries; NQT = 1): the query tile is 16 wide and the products run on v_mfma_f32_16x16x4_f32 — half the matrix time per index
 // byte of the 32-wide tile, which at <= 32 queries costs as much as the HBM stream itself (16 B/clk/CU); the instruction adds its four k
 // products in ascending k with one rounding each (tools/ubench/mfma16_order.hip: 256 of 256 results bit-identical to the fmaf chain), so
@@ -520,22 +588,46 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   const float* Q = static_cast<const float*>(a.q);
   const float* X = static_cast<const float*>(a.xb);
   f32x2* sQ = reinterpret_cast<f32x2*>(smem);                       // [NQT][nm][2][32]
-  if constexpr (Q16) {
-    float* sQ1 = reinterpret_cast<float*>(smem);                    // [D / 4][4][16]
-    for (int id = tid; id < D * 16; id += KS_THREADS) {
-      const int q = id & 15, kk = id >> 4;                          // kk = 4 m + kq
-      sQ1[id] = q < a.B ? Q[(int64_t)q * D + kk] : 0.f;
-    }
-  } else {
-    for (int id = tid; id < NQT * nm * 64; id += KS_THREADS) {
-      const int qt = id / (nm * 64), rem = id - qt * nm * 64;
-      const int q = qt * 32 + (rem & 31), h = (rem >> 5) & 1, m = rem >> 6;
-      f32x2 v = {0.f, 0.f};
-      if (q < a.B) { v[0] = Q[(int64_t)q * D + 4 * m + h]; v[1] = Q[(int64_t)q * D + 4 * m + 2 + h]; }
-      sQ[id] = v;
+  KNN_STAMP_AT(0)
+  // Query image: every thread takes whole 16-byte pieces of the query rows (coalesced), FOUR loads in flight before the first LDS write
+  // (round 3 read one float per thread and iteration: 12-24 dependent round trips in front of the first index byte).
+  {
+    constexpr int QW_ = Q16 ? 16 : 32 * NQT;                        // query slots of the image
+    const int total = QW_ * nm;                                     // 16-byte pieces: (query slot, m)
+    for (int base = 0; base < total; base += KS_THREADS * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int id = base + u * KS_THREADS + tid;
+        const int q = id / nm, m = id - q * nm;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (id < total && q < a.B) v[u] = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * D + 4 * m);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int id = base + u * KS_THREADS + tid;
+        const int q = id / nm, m = id - q * nm;
+        if (id < total) {
+          if constexpr (Q16) {
+            float* sQ1 = reinterpret_cast<float*>(smem);            // [D / 4][4][16]: element k = 4 m + kq of query q at (4 m + kq) * 16 + q
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sQ1[(4 * m + e) * 16 + q] = v[u][e];
+          } else {
+            const int qt = q >> 5, ql = q & 31;                     // [qt][m][half][query]: (Q[4m + h], Q[4m + 2 + h])
+            sQ[(qt * nm + m) * 64 + ql] = f32x2{v[u][0], v[u][2]};
+            sQ[(qt * nm + m) * 64 + 32 + ql] = f32x2{v[u][1], v[u][3]};
+          }
+        }
+      }
     }
   }
+  {
+    unsigned* ctl = reinterpret_cast<unsigned*>(smem + a.ctl_off);
+    if (tid < 4) ctl[tid] = 0u;                                     // [0]: block counter
+    if (tid < (Q16 ? 16 : 32 * NQT)) ctl[4 + tid] = 0u;             // shared score bounds: key 0 = below every score
+  }
   __syncthreads();
+  KNN_STAMP_AT(1)
 
   float ls[NQT][KMAX];
   int li[NQT][KMAX];
@@ -553,18 +645,28 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   constexpr int STG = 4096;                                         // one stage: 32 rows x 128 bytes (32 k)
   constexpr int P = 4;                                              // stages in flight per wave, in REGISTERS (16 KB per wave, 128 KB per CU)
   const int nsl = D / 32;                                           // stages (k slabs) per row block; D % 128 == 0 -> P divides it
-  constexpr int NBUF = NQT == 1 ? 2 : 1;                            // transpose stages per wave
-  char* stg = smem + (size_t)D * 128 * NQT + (size_t)w * NBUF * STG;   // the wave's private transpose buffer
+  const int nbuf = a.ring;                                          // transpose stages per wave: 2, or 1 where the LDS has no room for two (launcher)
+  char* stg = smem + (size_t)D * 128 * NQT + (size_t)w * nbuf * STG;   // the wave's private transpose buffer
   // stream of this wave: stage t = (block t / nsl, slab t % nsl).  A stage is fetched by 4 fully coalesced 16-byte loads per
   // lane (lane -> row 8i + lane / 8, chunk lane % 8: 8 rows x 128 contiguous bytes per instruction), parked in registers
   // while P - 1 older stages are consumed, then transposed through the wave's LDS buffer into the row-per-lane MFMA layout.
   // The chunk position is XOR-swizzled with the row so that both the writes and the fragment reads spread over the banks.
   // Everything is wave-private: no workgroup barrier in the loop, and ordinary loads let the compiler count vmcnt itself.
-  const int nblk = row_lo + w * 32 < row_hi ? (row_hi - row_lo - w * 32 + WSTEP - 1) / WSTEP : 0;
-  const int nst = nblk * nsl;
+  // Row blocks are handed out DYNAMICALLY inside the workgroup (round 4): an LDS counter, one atomic per 32-row block and wave.  With the
+  // static round-robin of round 3 wave 0 sat 8 % of the kernel at the final barrier waiting for the other waves (s_memtime timeline,
+  // tools/knn_timeline.py) — the waves of a CU do not get equal shares of the memory pipeline.  A wave's block numbers still ascend, so
+  // its lanes still see their rows in ascending id order (the tie rule of topk_insert).
+  const int nblk_wg = (row_hi - row_lo + 31) / 32;                   // 32-row blocks of this workgroup's chunk (<= 0: none)
+  unsigned* sNext = reinterpret_cast<unsigned*>(smem + a.ctl_off);   // block counter (behind the stages; Q16: in the unused half of the image region)
+  unsigned* sThr = sNext + 4;                                        // [QW * NQT] shared score bounds (f32_key), see below
+  auto next_block = [&]() __attribute__((always_inline)) -> int {    // wave-uniform: row base of the wave's next block (>= row_hi: none)
+    unsigned b = 0;
+    if (lane == 0) b = __hip_atomic_fetch_add(sNext, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+    return (int)b < nblk_wg ? row_lo + (int)b * 32 : INT_MAX - 64;
+  };
   f32x4 rg[P][4];
-  auto fetch = [&](f32x4 (&r)[4], int blk, int sl) __attribute__((always_inline)) {
-    const int r0i = row_lo + w * 32 + blk * WSTEP;
+  auto fetch = [&](f32x4 (&r)[4], int r0i, int sl) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int row = r0i + 8 * i + (lane >> 3);
@@ -576,11 +678,23 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
 #endif
     }
   };
-  int fb = 0, fs = 0;                                               // (block, slab) of the next stage to fetch
+  int frow = next_block(), fs = 0;                                  // (row base, slab) of the next stage to fetch
+  int r0 = frow;                                                    // row base of the block being consumed
+  // blocks acquired by the fetch side and not yet begun by the consuming side (the fetch runs P stages = up to one whole block ahead): a
+  // two-entry queue of row bases; the end-of-chunk sentinel is queued once
+  int q0 = 0, q1 = 0, pend = 0;
+  auto fetch_wrap = [&]() __attribute__((always_inline)) {
+    fs = 0;
+    if (frow < row_hi) {
+      frow = next_block();
+      if (pend == 0) q0 = frow; else q1 = frow;
+      ++pend;
+    }
+  };
 #pragma unroll
   for (int u = 0; u < P; ++u) {
-    if (fb < nblk) fetch(rg[u], fb, fs);
-    if (++fs == nsl) { fs = 0; ++fb; }
+    if (frow < row_hi) fetch(rg[u], frow, fs);
+    if (++fs == nsl) fetch_wrap();
   }
   f32x16 acc[NQT];
 #pragma unroll
@@ -590,19 +704,28 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // Q16: row groups 0-15 / 16-31 of the block
   const int q16 = lane & 15, kq = lane >> 4;
   const float* qp16 = reinterpret_cast<const float*>(smem) + kq * 16 + q16;
-  int sl = 0, r0 = row_lo + w * 32;
+  int sl = 0;
   const int wr = lane >> 3, wc = lane & 7;
-  for (int t0 = 0; t0 < nst; t0 += P) {
+  // Shared score bounds (round 4).  A lane's list only sees 1/16 .. 1/32 of the workgroup's rows, so its own KMAX-th score is a loose
+  // filter: at 64 queries about every second (block, slot) ran an insertion.  Any list's KMAX-th entry is a lower bound of the final k-th
+  // score of that query (>= KMAX >= k rows score at least that), so the lists of a query publish theirs with an LDS atomic max
+  // (order-preserving keys) once per block and filter with the workgroup's best bound: a row below it cannot reach the output; rows
+  // EQUAL to it still can (ties rank by id) and pass.  The lists are then no longer each chunk part's complete top-KMAX, but their union
+  // still holds the chunk's top-k, which is all the merges need.
+  float sthr[NQT];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) sthr[qt] = -FLT_MAX;
+  while (r0 < row_hi) {
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-      char* buf = stg + (u % NBUF) * STG;
+      char* buf = stg + (u & (nbuf - 1)) * STG;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rl = 8 * i + wr;
         *reinterpret_cast<f32x4*>(buf + rl * 128 + ((wc ^ (rl & 7)) << 4)) = rg[u][i];
       }
-      if (fb < nblk) fetch(rg[u], fb, fs);                           // the slot's next stage (P stages ahead)
-      if (++fs == nsl) { fs = 0; ++fb; }
+      if (frow < row_hi) fetch(rg[u], frow, fs);                     // the slot's next stage (P stages ahead)
+      if (++fs == nsl) fetch_wrap();
       if constexpr (Q16) {
         float xa[2][8];
 #pragma unroll
@@ -638,13 +761,13 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
       if constexpr (Q16) {
         // C layout: col = query (lane & 15), rows 16 g + 4 (lane >> 4) + r, ascending with (g, r)
         uint32_t hits = 0;
-        const float thr = ls[0][KMAX - 1];
+        const float thr = ls[0][KMAX - 1], thg = sthr[0];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int n = r0 + 16 * g + 4 * kq + r;
-            hits |= (n < a.N && acc16[g][r] > thr) ? (1u << (4 * g + r)) : 0u;
+            hits |= (n < a.N && acc16[g][r] > thr && acc16[g][r] >= thg) ? (1u << (4 * g + r)) : 0u;
           }
         if (__any(hits != 0)) {
 #pragma unroll
@@ -658,16 +781,21 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
           }
         }
         acc16[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc16[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+          const unsigned own = f32_key(ls[0][KMAX - 1]);
+          const unsigned old = __hip_atomic_fetch_max(sThr + q16, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          sthr[0] = key_f32(old > own ? old : own);
+        }
       } else {
       // C layout: col = query (r31), rows = index rows (r & 3) + 8 (r >> 2) + 4 half, ascending with r
 #pragma unroll
       for (int qt = 0; qt < NQT; ++qt) {
         uint32_t hits = 0;
-        const float thr = ls[qt][KMAX - 1];
+        const float thr = ls[qt][KMAX - 1], thg = sthr[qt];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          hits |= (n < a.N && acc[qt][r] > thr) ? (1u << r) : 0u;
+          hits |= (n < a.N && acc[qt][r] > thr && acc[qt][r] >= thg) ? (1u << r) : 0u;
         }
         if (__any(hits != 0)) {
           float cand[16];
@@ -685,24 +813,36 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
+        {
+          const unsigned own = f32_key(ls[qt][KMAX - 1]);
+          const unsigned old = __hip_atomic_fetch_max(sThr + qt * 32 + r31, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          sthr[qt] = key_f32(old > own ? old : own);
+        }
       }
       }
-      sl = 0; r0 += WSTEP;
+      sl = 0; r0 = q0; q0 = q1; --pend;                               // (the fetch side is ahead: the next block, or the sentinel, is queued)
     }
   }
 
-  // ---- merge the 16 partial lists of every query through LDS (the query image is dead)
+  // ---- merge the partial lists of every query through LDS (the query image is dead): the lists go to LDS as before, then ONE WAVE per
+  // query merges them with wave_merge_lds (lane = list) — round 3 had one THREAD per query walk 16-32 lists with a dependent LDS
+  // round trip per list and output (~20 us of a 0.3 ms search).  Chunks keep min(k, KMAX) entries: what the chunk merge can use.
+  KNN_STAMP_AT(2)
   __syncthreads();
+  KNN_STAMP_AT(3)
   constexpr int NSRC = (KS_THREADS / 64) * (Q16 ? 4 : 2);
   constexpr int QW = Q16 ? 16 : 32;                                 // queries per tile
-  float* mS = reinterpret_cast<float*>(smem);                       // [QW * NQT][NSRC][KMAX]
-  int* mI = reinterpret_cast<int*>(smem + QW * NQT * NSRC * KMAX * 4);
+  // odd strides: list stride KMAX + 1, query stride NSRC (KMAX + 1) + 1 words — the lanes of a wave write entry t of 64 different lists
+  // and wave_merge_lds reads the heads of 16-32 lists at once; with power-of-two strides both were 16-way bank conflicts (4.7 us)
+  constexpr int LS = KMAX + 1, QS = NSRC * LS + 1;
+  float* mS = reinterpret_cast<float*>(smem);                       // [QW * NQT][NSRC][KMAX] with those strides
+  int* mI = reinterpret_cast<int*>(smem) + QW * NQT * QS;
   if constexpr (Q16) {
     const int src = w * 4 + kq;
 #pragma unroll
     for (int t = 0; t < KMAX; ++t) {
-      mS[(q16 * NSRC + src) * KMAX + t] = ls[0][t];
-      mI[(q16 * NSRC + src) * KMAX + t] = li[0][t];
+      mS[q16 * QS + src * LS + t] = ls[0][t];
+      mI[q16 * QS + src * LS + t] = li[0][t];
     }
   } else {
     const int src = w * 2 + half;
@@ -710,49 +850,46 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
     for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
       for (int t = 0; t < KMAX; ++t) {
-        mS[((qt * 32 + r31) * NSRC + src) * KMAX + t] = ls[qt][t];
-        mI[((qt * 32 + r31) * NSRC + src) * KMAX + t] = li[qt][t];
+        mS[(qt * 32 + r31) * QS + src * LS + t] = ls[qt][t];
+        mI[(qt * 32 + r31) * QS + src * LS + t] = li[qt][t];
       }
   }
   __syncthreads();
-  if (tid < QW * NQT && tid < a.B) {
-    const float* s0 = mS + tid * NSRC * KMAX;
-    const int* i0 = mI + tid * NSRC * KMAX;
-    int ptr[NSRC];
-#pragma unroll
-    for (int c = 0; c < NSRC; ++c) ptr[c] = 0;
-    const int nout = (a.nchunks == 1) ? a.k : KMAX;
-    for (int o = 0; o < nout; ++o) {
-      float bs = -FLT_MAX; int bi = ID_NONE; int bsrc = -1;
-      if (o < KMAX) {
-#pragma unroll
-        for (int c = 0; c < NSRC; ++c) {
-          if (ptr[c] < KMAX) {
-            const float sc = s0[c * KMAX + ptr[c]]; const int ic = i0[c * KMAX + ptr[c]];
-            if (bsrc < 0 || before(sc, ic, bs, bi)) { bs = sc; bi = ic; bsrc = c; }
-          }
+  KNN_STAMP_AT(4)
+  const int kk = a.k < KMAX ? a.k : KMAX;
+  const int nout = (a.nchunks == 1) ? a.k : kk;
+  const int nq = a.B < QW * NQT ? a.B : QW * NQT;
+  for (int q = w; q < nq; q += NWAVE) {                              // wave-uniform: whole waves enter wave_merge_lds
+    wave_merge_lds<1>(mS + q * QS, mI + q * QS, NSRC, KMAX, LS, nout, lane, [&](int o, float ws, int wi) {
+      if (lane == 0) {
+        if (a.nchunks == 1) {
+          a.dist[(int64_t)q * a.ldo + a.ocol + o] = (wi == ID_NONE) ? -FLT_MAX : ws;
+          a.idx[(int64_t)q * a.ldo + a.ocol + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
+        } else {
+          const int64_t off = ((int64_t)chunk * a.B + q) * KMAX + o;
+          a.pdist[off] = (wi == ID_NONE) ? -FLT_MAX : ws;
+          a.pidx[off] = wi;
         }
-#pragma unroll
-        for (int c = 0; c < NSRC; ++c) ptr[c] += (c == bsrc);
       }
-      if (a.nchunks == 1) {
-        a.dist[(int64_t)tid * a.ldo + a.ocol + o] = bs;
-        a.idx[(int64_t)tid * a.ldo + a.ocol + o] = (bi == ID_NONE) ? (int64_t)-1 : (int64_t)bi;
-      } else {
-        const int64_t off = ((int64_t)chunk * a.B + tid) * KMAX + o;
-        a.pdist[off] = bs;
-        a.pidx[off] = bi;
-      }
-    }
+    });
   }
+  KNN_STAMP_AT(5)
 }
 
 template <int KMAX, int NQT, bool Q16 = false>
 int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   KnnArgs a = a_in;
-  constexpr int NBUF = NQT == 1 ? 2 : 1;
-  const size_t q_bytes = (size_t)a.D * 128 * NQT, m_bytes = (size_t)32 * NQT * (KS_THREADS / 64) * 2 * KMAX * 8;
-  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * NBUF * 4096;
+  constexpr int NSRC = (KS_THREADS / 64) * (Q16 ? 4 : 2), QW = Q16 ? 16 : 32;
+  const size_t q_bytes = (size_t)a.D * 128 * NQT, m_bytes = (size_t)QW * NQT * (NSRC * (KMAX + 1) + 1) * 8;
+  // control words (block counter + shared bounds): the 16-query image fills only half of its region — they live in the other half;
+  // otherwise behind the stages.  Two transpose stages per wave where they fit next to one query tile's image, else one (LDS operations
+  // of a wave execute in order, so re-writing a stage behind its reads is safe): 1M x 768 at 17..32 queries, and every two-tile launch.
+  const size_t c_bytes = Q16 ? 0 : 16 + (size_t)QW * NQT * 4;
+  int nbuf = NQT == 1 ? 2 : 1;
+  if (q_bytes + (size_t)(KS_THREADS / 64) * nbuf * 4096 + c_bytes > 160 * 1024) nbuf = 1;
+  const size_t s_bytes = q_bytes + (size_t)(KS_THREADS / 64) * nbuf * 4096 + c_bytes;
+  a.ring = nbuf;
+  a.ctl_off = Q16 ? a.D * 64 : (int)(s_bytes - c_bytes);
   if (s_bytes > 160 * 1024 || m_bytes > 160 * 1024) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim / k too large for the LDS image");
   const size_t lds = s_bytes > m_bytes ? s_bytes : m_bytes;
   // per launch: the attribute belongs to the (function, device) pair and a process may search on several GPUs; the call is cheap
@@ -761,8 +898,7 @@ int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   hipLaunchKernelGGL((knn_stream_kernel<KMAX, NQT, Q16>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
   int rc = check_launch("knn_stream");
   if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
-  hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s,
-                     a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol);
+  launch_knn_merge<KMAX>(a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol, s);
   return check_launch("knn_merge");
 }
 int launch_knn_stream_k(int kmax, int nqt, const KnnArgs& a, hipStream_t s) {
@@ -959,3 +1095,11 @@ int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* 
 }
 
 }  // namespace effocr
+
+#ifdef KNN_STAMP
+extern "C" int effocr_debug_knn_stamps(unsigned long long* out, int n) {
+  const int m = effocr::KNN_STAMP_WGS * effocr::KNN_STAMP_N;
+  if (n < m) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(effocr::knn_stamps), (size_t)m * 8) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -42,12 +42,28 @@
 #ifndef QA_NT
 #define QA_NT 0                                          // non-temporal: 1 row loads, 2 output stores (both measured slower: the fused MLP reads the output next)
 #endif
+#ifndef QA_ZERO_PAD
+#define QA_ZERO_PAD 0                                    // 1: rows past the image's last token are zero fragments instead of copies of the last token (same-box A/B: 1.1 % SLOWER, twice)
+#endif
+#ifndef QA_TWOSET
+#define QA_TWOSET 0                                      // 1: two static W-fragment sets in the projection (reads a whole k-step ahead), see the k-step loop
+#endif
 #ifndef QA_BARRIER_DRAIN
 #define QA_BARRIER_DRAIN 0
 #endif
 
 namespace effocr {
 namespace {
+
+// -DQA_STAMP (tools/ab_build.sh variant, never shipped): every wave of every workgroup records s_memtime at the milestones of the head
+// it is in (the last head's values stay); tools/qa_timeline.py reads the table through effocr_debug_qa_stamps.  Branch-free: all lanes store.
+#ifdef QA_STAMP
+constexpr int QA_STAMP_WGS = 256, QA_STAMP_N = 16;
+__device__ unsigned long long qa_stamps[QA_STAMP_WGS * 4 * QA_STAMP_N];
+#define QA_STAMP_AT(k) qa_stamps[((blockIdx.x & (QA_STAMP_WGS - 1)) * 4 + w) * QA_STAMP_N + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define QA_STAMP_AT(k)
+#endif
 
 template <int I, int N, typename F> __device__ __forceinline__ void qa_for(F&& f) {
   if constexpr (I < N) {
@@ -159,19 +175,27 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     constexpr int NA = NT > 0 ? NT : 1;
     V8 xf[NA][NXF];                                      // LayerNorm(x) operand fragments, resident for the whole kernel
 
-    // lane = (row r31, half): operand fragment t of its row = 16-byte chunk 2t+half.  Rows past the image's last token
-    // re-read the last token (their keys are masked, their query rows never stored).
+    // lane = (row r31, half): operand fragment t of its row = 16-byte chunk 2t+half.  Rows past the image's last token (their keys
+    // are masked, their query rows never stored) re-read the last token.  (QA_ZERO_PAD = 1 makes them zero fragments — 59 of the 256
+    // row slots of a 197-token image would then feed the matrix pipe operands that do not toggle the multipliers, and the chip runs this
+    // kernel power-limited at 2.09 GHz — but the build measured 1.1 % slower end to end, twice, same box: not the default.)
     auto load_frags = [&](int img) __attribute__((always_inline)) {
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        int t = (2 * w + tt) * 32 + r31;
-        t = t < T ? t : T - 1;
+        const int t0 = (2 * w + tt) * 32 + r31;
+        const int t = t0 < T ? t0 : T - 1;
         const int64_t tok = (int64_t)img * T + t;
         const char* xb = static_cast<const char*>(a.xn) + (tok >> 5) * (int64_t)KC * 512 + (tok & 31) * 16 + half * 512;   // + compile-time offsets only
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
           xf[tt][i] = (QA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const V8*>(xb + i * 1024)) : *reinterpret_cast<const V8*>(xb + i * 1024);
         }
+#if QA_ZERO_PAD
+        if (t0 >= T) {
+#pragma unroll
+          for (int i = 0; i < NXF; ++i) xf[tt][i] = V8{};
+        }
+#endif
       }
     };
     const int nimg = (a.B - slot0 + nslots - 1) / nslots;   // images of this workgroup (>= 1)
@@ -191,8 +215,12 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       constexpr bool LAST = decltype(LAST_)::value;        // last head of the workgroup's last image: the ring runs dry
       constexpr bool PRE = decltype(PRE_)::value;          // last head of an image that is not the last: request the next image's rows
       refresh_lane();
+      QA_STAMP_AT(0)
       V8 qf[NA][4];                                      // Q^T operand fragments of the wave's tiles (k-step = 16 head dims)
       V8 f0, f1;                                         // the k-step's two W fragments (row blocks 0 / 1 of the stage)
+#if QA_TWOSET
+      V8 fw[2][2];                                       // two static fragment sets: step ks consumes set ks & 1 while set (ks + 1) & 1 loads
+#endif
       qa_for<0, 3>([&](auto SEC_) {
         constexpr int sec = decltype(SEC_)::value;       // 0 q, 1 k, 2 v
         f32x16 acc[NA][2];
@@ -210,11 +238,57 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           const int nslot = slot + 1 == R ? 0 : slot + 1;
           const char* stn = sW + nslot * QA_STAGE + half * 512 + r31 * 16;
           if constexpr (sl == 0) {                       // later stages: requested under the previous stage's last MFMAs
+#if QA_TWOSET
+            fw[0][0] = *reinterpret_cast<const V8*>(st);
+            fw[0][1] = *reinterpret_cast<const V8*>(st + 16 * 512);
+#else
             f0 = *reinterpret_cast<const V8*>(st);
             f1 = *reinterpret_cast<const V8*>(st + 16 * 512);
+#endif
           }
           qa_for<0, 8>([&](auto KS_) {
             constexpr int ks = decltype(KS_)::value;
+#if QA_TWOSET
+            // The rolling form below (f0 = n0) lets the register allocator give the next step's fragment the register the current one
+            // vacates: the read can then only issue behind the MFMAs that still read it, two MFMAs (64 cycles) in front of its own use —
+            // less than an LDS round trip with four waves and the weight DMA on the LDS (ISA of the round-3 kernel).  Two static sets
+            // keep the read a whole step (four MFMAs) ahead.
+            if constexpr (ks == 4) {
+              if constexpr (SMALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              else if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
+              else if constexpr (ft >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((ft < R - 2 ? ft : R - 2) - 1) * 4) : "memory");
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+            }
+            if constexpr (ks < 7) {
+              fw[(ks + 1) & 1][0] = *reinterpret_cast<const V8*>(st + (2 * (ks + 1)) * 512);
+              fw[(ks + 1) & 1][1] = *reinterpret_cast<const V8*>(st + (16 + 2 * (ks + 1)) * 512);
+            } else if constexpr (sl + 1 < NSH) {
+              fw[0][0] = *reinterpret_cast<const V8*>(stn);
+              fw[0][1] = *reinterpret_cast<const V8*>(stn + 16 * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+              if constexpr (CLS && sec == 0) {
+                if (w == 0 && tt == 0) {
+                  acc[tt][0] = Op16<E>::mfma(fw[ks & 1][0], xf[tt][kt * 8 + ks], acc[tt][0]);
+                  acc[tt][1] = Op16<E>::mfma(fw[ks & 1][1], xf[tt][kt * 8 + ks], acc[tt][1]);
+                }
+              } else if constexpr (sec < 2) {
+                acc[tt][0] = Op16<E>::mfma(fw[ks & 1][0], xf[tt][kt * 8 + ks], acc[tt][0]);
+                acc[tt][1] = Op16<E>::mfma(fw[ks & 1][1], xf[tt][kt * 8 + ks], acc[tt][1]);
+              } else {
+                acc[tt][0] = Op16<E>::mfma(xf[tt][kt * 8 + ks], fw[ks & 1][0], acc[tt][0]);
+                acc[tt][1] = Op16<E>::mfma(xf[tt][kt * 8 + ks], fw[ks & 1][1], acc[tt][1]);
+              }
+            }
+            if constexpr (ks >= 4) {
+              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_piece_asm(std::integral_constant<int, ks - 4>{}); }
+              else if constexpr (!LAST || ft >= R - 1) issue_piece_asm(std::integral_constant<int, ks - 4>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#else
             if constexpr (ks == 4) {
               // middle of stage g: stage g+1 has landed (own pieces; the younger stages may stay in flight) and,
               // past the barrier, everybody's; every wave is done with stage g-1, whose slot takes stage g+R-1
@@ -255,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               else if constexpr (!LAST || ft >= R - 1) issue_piece_asm(std::integral_constant<int, ks - 4>{});
             }
             if constexpr (ks < 7 || sl + 1 < NSH) { f0 = n0; f1 = n1; }
+#endif
           });
           if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_advance(); }
           else if constexpr (!LAST || ft >= R - 1) issue_advance();
@@ -291,11 +366,13 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
             }
           }
         }
+        QA_STAMP_AT(1 + sec)
       });
       if constexpr (PRE) load_frags(img_next);           // the fragments are dead from here on: the loads land under the attention
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // K and V of every tile are in LDS
       asm volatile("" ::: "memory");
+      QA_STAMP_AT(4)
 
       // ---- attention of the wave's query tiles against all keys of the image.  K / V fragments are requested one
       // step ahead by hand (with one wave per SIMD nothing else hides the LDS latency; left to itself the compiler
@@ -327,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           for (int ks = 0; ks < 4; ++ks) s[kt] = Op16<E>::mfma(kf[cur][ks], qf[tt][ks], s[kt]);
           __builtin_amdgcn_sched_barrier(0);
         });
+        QA_STAMP_AT(5 + tt * 5)
         V8 vf[2][2];
 #pragma unroll
         for (int db = 0; db < 2; ++db) vf[0][db] = *reinterpret_cast<const V8*>(vb + db * 1024);
@@ -379,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
             pf[st & 1] = __builtin_bit_cast(V8, pw);
           }
         };
+        QA_STAMP_AT(6 + tt * 5)
         qa_for<0, 3>([&](auto P_) { p_part(std::integral_constant<int, 0>{}, P_); });
         __builtin_amdgcn_sched_barrier(0);
         qa_for<0, NPV>([&](auto ST_) {
@@ -403,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           if constexpr (more) p_part(std::integral_constant<int, st + 1>{}, std::integral_constant<int, 2>{});
           __builtin_amdgcn_sched_barrier(0);
         });
+        QA_STAMP_AT(7 + tt * 5)
         const float l = lsum[0];
         if (tq < T) {
           const float inv = 1.0f / l;
@@ -420,7 +500,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               if (QA_NT & 2) __builtin_nontemporal_store(v, op); else *op = v;
             }
         }
+        QA_STAMP_AT(8 + tt * 5)
       });
+      QA_STAMP_AT(15)
     };
 
     __syncthreads();                                     // parameters visible before the ring starts filling
@@ -501,3 +583,11 @@ int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s) {
 
 
 }  // namespace effocr
+
+#ifdef QA_STAMP
+extern "C" int effocr_debug_qa_stamps(unsigned long long* out, int n) {
+  const int m = effocr::QA_STAMP_WGS * 4 * effocr::QA_STAMP_N;
+  if (n < m) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(effocr::qa_stamps), (size_t)m * 8) == hipSuccess ? 0 : -2;
+}
+#endif

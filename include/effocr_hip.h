@@ -120,8 +120,17 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *                 reaches the embedding (global_pool = 'token'); proj / LayerNorm / MLP act per row, so the result is the same
  *                 (0: all tokens, A/B switch)
  *   "mlp_stagger" [3500] fused MLP kernel: the first round of workgroups starts spread over 32 x this many clock ticks, so
- *                 that the CUs do not request / store their rows all at the same moment (0 = off; used from 4 rounds of CUs on)
+ *                 that the CUs do not request / store their rows all at the same moment (0 = off)
+ *   "mlp_stagger_min_rounds" [2] ... for launches of at least this many rounds of CUs (512-crop calls: +7.7 %; no effect below two)
  *   "use_projf"   [1] attn.proj + residual fused in front of the fused MLP kernel (0: its own row-panel launch)
+ *   "use_patchf"  [1] fused im2col + patch-embedding GEMM (ViT-S / 128-wide); 0: im2col kernel + DMA-ring GEMM
+ *   "qa_min_batch" [1] fused qkv + attention kernel from this many crops per call on (below: row-panel qkv + attention kernels)
+ *   "qa_hsplit"   [0] fused qkv + attention: workgroups per image (heads split over them); 0 = launcher's choice (calls of less
+ *                 than a round of CUs split), 1 = never, n = at most n
+ *   "use_lnfold"  [1] gemm3 path (embed dims that are multiples of 256: ViT-B): LayerNorm folded into the linears either side of it —
+ *                 attn.proj / mlp.fc2 also write the new residual row as 16-bit operands + per-row partial sums, attn.qkv / mlp.fc1
+ *                 multiply by W . diag(gamma) and finish rstd (acc - mean s) + (b + W beta) in their epilogues: 1 LayerNorm launch
+ *                 per forward instead of 24 (0: LayerNorm launches, A/B switch)
  *   "panel_rows"  [128] row-panel height, 64 or 128;  "chunk" (= set_chunk);  "debug" (experiment hooks) */
 int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value);
 
@@ -158,7 +167,10 @@ size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int 
 /* Process-wide A/B switch of the exact search: "force_tile" [0] — 1 makes effocr_knn_ip_topk use the 128-query tile kernel
  * also for <= 32 queries (by default those go to the streaming kernel that reads the index at the HBM rate; results are
  * bit-identical either way).  "wg_target" [1024] — workgroups a tile-kernel launch aims for when it cuts the index into chunks
- * (set it before effocr_knn_workspace_bytes: the partial-list area follows the chunk count; results are bit-identical). */
+ * (set it before effocr_knn_workspace_bytes: the partial-list area follows the chunk count; results are bit-identical).
+ * "q16_tile" [1] — calls of <= 16 queries use the 16-wide query tile (v_mfma_f32_16x16x4_f32); 0: the 32-wide one.
+ * "two_pass_screen" [0] — 1: the screened search collects its candidates with a second bf16 scan of the index instead of reading
+ * them out of the first scan's per-chunk lists (A/B switches; results are bit-identical either way). */
 int effocr_knn_set_option(const char* name, int value);
 /* Byte offset, inside the screened search's workspace, of its int32 OVERFLOW FLAG: non-zero after a call in which some
  * query had more than 512 candidates within the error band, i.e. the call also ran the exact pass (results are
@@ -222,7 +234,9 @@ size_t effocr_localizer_weights_bytes(const effocr_localizer_t* loc);
 int effocr_localizer_upload(effocr_localizer_t* loc, void* weights_dev, size_t bytes);
 /* "bf16_operands" [0]: 1 = every convolution that carries an activation runs with bf16-rounded operands (weights rounded once at
  * upload, activations in the stage loader) on v_mfma_f32_32x32x16_bf16, fp32 accumulation / bias / SiLU / residual; Detect's 1x1
- * heads keep fp32 operands.  0 = fp32 operands everywhere (v_mfma_f32_32x32x2_f32: the oracle's arithmetic up to summation order). */
+ * heads keep fp32 operands.  0 = fp32 operands everywhere (v_mfma_f32_32x32x2_f32: the oracle's arithmetic up to summation order).
+ * "direct_stem" [1]: the stem Conv(3, 32, 6, 2, 2) as a direct kernel from the NCHW input; 0 = im2col rows + the implicit GEMM (A/B
+ * switch; set it before effocr_localizer_workspace_bytes — the im2col rows, 840 MB at 16 images, exist only on that path). */
 int effocr_localizer_set_option(effocr_localizer_t* loc, const char* name, int value);
 int64_t effocr_localizer_num_predictions(const effocr_localizer_t* loc);
 int effocr_localizer_num_outputs(const effocr_localizer_t* loc);             /* 5 + num_classes */

@@ -63,6 +63,52 @@ def test_vit_base(dev, prec):
     assert e <= REL[prec]
 
 
+def _nontrivial_norms(arch, seed):
+    """Seeded weights with every LayerNorm gain / shift and every linear bias moved off its init value (1 / 0 / 0), so that a
+    LayerNorm folded into the neighbouring linears (gemm3.hip) is checked on its whole algebra: W . diag(gamma), W . beta, row sums."""
+    sd = init_state_dict(arch, seed=seed, img_size=224)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in list(sd):
+        if "norm" in k and k.endswith(".weight"):
+            sd[k] = (1.0 + 0.3 * torch.randn(sd[k].shape, generator=g)).clamp_min(0.2)
+        elif "norm" in k and k.endswith(".bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith(".bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    sd = {k: v.contiguous() for k, v in sd.items()}
+    return sd
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_vit_base_folded_layernorm(dev, prec):
+    """ViT-B/16 (BASELINE configs[3]; every linear on gemm3): by default 23 of the 24 LayerNorms of a forward are folded into the
+    linears either side of them — the residual producers (attn.proj, mlp.fc2) write the new row as 16-bit operands + per-slice sums,
+    attn.qkv / mlp.fc1 multiply by W . diag(gamma) and finish rstd (acc - mean s) + (b + W beta) in their epilogues.  Against oracle A
+    with NON-trivial gains / shifts / biases, both ways (use_lnfold 1 / 0), on a call of tail tiles only (9 crops) and, fold vs
+    LayerNorm launches, on one with main + tail launches (300 crops)."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_base_patch16_224"
+    sd = _nontrivial_norms(arch, seed=7)
+    x = torch.randn(9, 3, 224, 224, generator=torch.Generator().manual_seed(8))
+    ref = l2_normalize(encoder_forward(arch, sd, x))
+    enc = HipEncoder(arch, sd, precision=prec, device=dev)
+    fold = enc.forward(x.to(dev), normalize=True).cpu()
+    enc.set_option("use_lnfold", 0)
+    plain = enc.forward(x.to(dev), normalize=True).cpu()
+    e1, e0 = rel_err(fold, ref), rel_err(plain, ref)
+    print(f"vit_base {prec}: folded LayerNorm {e1:.3e}, LayerNorm launches {e0:.3e}")
+    assert e1 <= REL[prec] and e0 <= REL[prec]
+    assert not torch.equal(fold, plain)                  # the switch really selects another path
+    xb = torch.randn(300, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(9), device=dev)
+    big0 = enc.forward(xb, normalize=True)
+    enc.set_option("use_lnfold", 1)
+    big1 = enc.forward(xb, normalize=True)
+    assert torch.isfinite(big1).all() and rel_err(big1.cpu(), big0.cpu()) <= REL[prec]
+    assert rel_err(big1[:9].cpu(), enc.forward(xb[:9].contiguous(), normalize=True).cpu()) <= REL[prec]
+    enc.set_option("cls_only_last", 0)                   # every token through the last block: the same embedding
+    assert rel_err(enc.forward(xb[:9].contiguous(), normalize=True).cpu(), big1[:9].cpu()) <= REL[prec]
+
+
 @pytest.mark.parametrize("img,B", [(32, 64), (32, 3), (64, 2), (224, 2)])
 def test_resnet18(dev, img, B):
     got, ref = run("resnet18", img, B, "fp32", dev)

@@ -104,6 +104,45 @@ def test_run_effocr_c5_lines_against_the_oracle_chain(dev, lang):
         assert same >= 0.85 * len(got[i]), (i, got16[i], got[i])
 
 
+def test_run_effocr_strings_fp32_vs_bf16_operand_localizer(dev):
+    """EffLocalizer(precision="bf16") rounds the operands of every activated convolution to bf16 (boxes within 0.3 px of the fp32
+    network, tests/test_gpu_localizer.py).  STRING-level evidence on 16 lines of BASELINE configs[4]'s shape: the same lines through
+    run_effocr with both localizers against one glyph index (the fp32 run's own crops + distractors, so every top-1 has a margin).
+    Measured (round 4): on these lines — a random-weight detector firing densely on noise, i.e. many boxes sitting on the confidence /
+    NMS thresholds — NONE of the 16 strings is identical: boxes appear / disappear and crop edges move by a pixel column.  The bf16-operand
+    localizer therefore stays an opt-in and fp32 operands (the reference's arithmetic) the default; this test pins the default and
+    records the agreement it sees (asserted only loosely: both runs read text of similar length)."""
+    loc_sd, loc, enc_sd, rec, tf = _setup(dev, seed=2)
+    loc16 = EffLocalizer(loc_sd, iou_thresh=0.05, conf_thresh=0.5, device=dev, precision="bf16")
+    lines = _lines(16, 256, 4096, seed=21)
+    res = loc.run(lines)
+    crops = []
+    for im, r in zip(lines, res):
+        for bb in sorted(r[r[:, 5] == 0][:, :4], key=lambda x: x[0]):
+            x0, _, x1, _ = torch.round(bb)
+            x0, x1 = int(round(x0.item() * 4096 / 640)), int(round(x1.item() * 4096 / 640))
+            if x1 > x0:
+                crops.append(im[0:256, max(x0, 0):x1, :])
+    crops = crops[:len(CHARS) - 30]
+    from oracle.crop_transform_ref import paired_transform
+    xs = np.stack([np.asarray(paired_transform(c, size=224), dtype=np.float32) for c in crops])
+    emb = np.concatenate([rec.run(xs[i:i + 64])[0] for i in range(0, len(xs), 64)])
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    rng = np.random.default_rng(5)
+    distract = rng.standard_normal((len(CHARS) - emb.shape[0], emb.shape[1])).astype(np.float32)
+    distract /= np.linalg.norm(distract, axis=1, keepdims=True)
+    knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
+    knn.train(torch.from_numpy(np.concatenate([emb, distract]).astype(np.float32)))
+    a, _ = run_effocr(lines, loc, rec, tf, "jp", knn_func=knn, candidate_chars=CHARS)
+    b, _ = run_effocr(lines, loc16, rec, tf, "jp", knn_func=knn, candidate_chars=CHARS)
+    same = [a[i] == b[i] for i in range(16)]
+    pos = sum(x == y for i in range(16) for x, y in zip(a[i], b[i])) / max(1, sum(min(len(a[i]), len(b[i])) for i in range(16)))
+    print(f"fp32- vs bf16-operand localizer: {sum(same)} / 16 strings identical, {100 * pos:.0f} % of the characters equal position by position")
+    assert loc._eng_net.precision == "fp32" and EffLocalizer(loc_sd, device=dev)._eng_net.precision == "fp32"   # the default
+    la, lb = sum(len(a[i]) for i in range(16)), sum(len(b[i]) for i in range(16))
+    assert la >= 16 * 20 and abs(la - lb) <= 0.3 * la
+
+
 def test_run_effocr_edge_cases(dev, tmp_path):
     """Mixed geometries (grouped), a path entry, a line without any box (en -> None as en_postprocess returns, jp -> ""),
     vertical text, the empty list, argument errors."""

@@ -9,6 +9,7 @@ mkdir -p ../../tools/ab /tmp/ab_$name
 objs=""
 for o in *.o; do
   src=${o%.o}.hip
+  case $o in panel.o|mlp_bf16.o|mlp_f16.o) continue;; esac   # A/B-only objects (make AB=1): the variant is a PRODUCT library (ab_stubs.o stands in)
   if [[ " $* " == *" $src "* ]]; then
     flags=""; [ "$src" = qkvattn.hip ] && flags="-mllvm -amdgpu-mfma-vgpr-form"
     [[ "$src" == mlp*.hip ]] && flags="-fno-slp-vectorize"
