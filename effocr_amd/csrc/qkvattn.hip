@@ -45,6 +45,9 @@
 #ifndef QA_ZERO_PAD
 #define QA_ZERO_PAD 0                                    // 1: rows past the image's last token are zero fragments instead of copies of the last token (same-box A/B: 1.1 % SLOWER, twice)
 #endif
+#ifndef QA_KDEPTH
+#define QA_KDEPTH 1                                      // key tiles of lookahead of the K fragment reads in Q K^T
+#endif
 #ifndef QA_TWOSET
 #define QA_TWOSET 0                                      // 1: two static W-fragment sets in the projection (reads a whole k-step ahead), see the k-step loop
 #endif
@@ -386,14 +389,22 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);               // one query tile at a time (two score rows do not fit)
         const int tq = (2 * w + tt) * 32 + r31;
         f32x16 s[NTT];
-        V8 kf[2][4];
+        // K fragments QA_KDEPTH key tiles ahead of their MFMAs (s_memtime timeline, tools/qa_timeline.py: with one tile of lookahead the
+        // 28 MFMAs of a query tile's Q K^T took 1.9 k ticks for 0.9 k of matrix time — the four reads of a tile have 128 cycles of MFMAs
+        // in front of them, less than an LDS round trip with four waves reading K / V and the weight DMA writing)
+        constexpr int KD = QA_KDEPTH + 1;                // fragment sets in the ring
+        V8 kf[KD][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[0][ks] = *reinterpret_cast<const V8*>(kb + ks * 1024);
+        for (int d = 0; d < QA_KDEPTH; ++d)
+          if (d < NTT) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[d][ks] = *reinterpret_cast<const V8*>(kb + (d * 4 + ks) * 1024);
+          }
         qa_for<0, NTT>([&](auto KT_) {
-          constexpr int kt = decltype(KT_)::value, cur = kt & 1, nxt = cur ^ 1;
-          if constexpr (kt + 1 < NTT) {
+          constexpr int kt = decltype(KT_)::value, cur = kt % KD, nxt = (kt + QA_KDEPTH) % KD;
+          if constexpr (kt + QA_KDEPTH < NTT) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[nxt][ks] = *reinterpret_cast<const V8*>(kb + ((kt + 1) * 4 + ks) * 1024);
+            for (int ks = 0; ks < 4; ++ks) kf[nxt][ks] = *reinterpret_cast<const V8*>(kb + ((kt + QA_KDEPTH) * 4 + ks) * 1024);
           }
           if constexpr (INITMASK && kt == NTT - 1) s[kt] = sinit;
           else {
