@@ -302,11 +302,7 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
 #pragma unroll
         for (int e = 0; e < 16; ++e) { psum += v[e]; psq = __builtin_fmaf(v[e], v[e], psq); }
       }
-      if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = (float)(E)v[e];              // same argument rounding as panel.hip
-        gelu_fold_n<E, 16>(v);
-      }
+      if constexpr (EPI == EPI_BIAS_GELU) gelu_fold_n<E, 16>(v);         // (on the fp32 pre-activation; rounding it to 16 bits first, as the row-panel kernel's hand-over does, cost a convert + shift per value: 18 % of this epilogue's instructions)
       if (ok) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

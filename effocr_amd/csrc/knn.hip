@@ -25,6 +25,7 @@
 #include "tile128.hpp"
 #include <float.h>
 #include <limits.h>
+#include <type_traits>
 
 namespace effocr {
 namespace {
@@ -144,6 +145,7 @@ struct KnnArgs {
   const int* run_flag;              // non-NULL: the launch is a no-op unless *run_flag != 0 (fallback after an overflow)
   int ring;                         // knn_stream_kernel: transpose stages per wave (1 | 2)
   int ctl_off;                      // knn_stream_kernel: LDS offset of the control words (block counter, shared score bounds)
+  int pB, pq0;                      // knn_stream_kernel: partial lists addressed as [chunk][pB][KMAX] at query pq0 + q (0: [chunk][B][KMAX]; slices of a larger call)
   // k > 32: the result is produced 32 columns at a time.  Pass p writes columns [ocol, ocol + k) of the [B][ldo] outputs and
   // (AFTER) only ranks rows that come strictly AFTER the previous pass's last result (after_col) in the (score desc, id asc) order.
   int ldo, ocol, after_col;
@@ -577,14 +579,22 @@ __device__ unsigned long long knn_stamps[KNN_STAMP_WGS * KNN_STAMP_N];
 // products in ascending k with one rounding each (tools/ubench/mfma16_order.hip: 256 of 256 results bit-identical to the fmaf chain), so
 // the scores stay those of oracle/flat_ip.c.  A: lane (row l & 15, k l >> 4) reads ITS 4 bytes of the transposed stage; B: LDS image
 // [m][k 0..3][16 queries]; C: lane holds query l & 15, rows 4 (l >> 4) + r of the 16-row group: four partial lists per query and wave.
-template <int KMAX, int NQT, bool Q16 = false>
+// E = __bf16 (round 4): the SCREENING pass of knn_ip_topk_screened for 17..128 queries against a large index — the same stream over the
+// bf16 copy of the index (half the bytes), v_mfma_f32_32x32x16_bf16 (a 32-row block x 32 queries x 64 k per stage and query tile: the matrix
+// pipe idles), approximate scores s^ into the same lists.  Query image [qt][k16 step][k half][query] of 16-byte B-operand fragments; a stage
+// is still 32 rows x 128 bytes (64 k), its A-operand fragments are the 16-byte chunks 2 ks + half of a row — one ds_read_b128 per k16 step.
+// The shared bound is relaxed by the query's 2 eps (every row within 2 eps of the final k-th approximate score must survive into the lists:
+// that is the candidate set of the exact re-rank), and chunk lists keep all KMAX entries (a full list of qualifying rows is the overflow signal).
+template <int KMAX, int NQT, bool Q16 = false, typename E = float>
 __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr bool BF = !std::is_same<E, float>::value;
+  static_assert(!(BF && Q16), "the 16-query tile is an exact-search kernel");
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
   const int chunk = blockIdx.x;
-  const int D = a.D, nm = D / 4;
+  const int D = a.D, nm = BF ? D / 8 : D / 4;                       // 16-byte pieces per query row
   const float* Q = static_cast<const float*>(a.q);
   const float* X = static_cast<const float*>(a.xb);
   f32x2* sQ = reinterpret_cast<f32x2*>(smem);                       // [NQT][nm][2][32]
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
         const int id = base + u * KS_THREADS + tid;
         const int q = id / nm, m = id - q * nm;
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (id < total && q < a.B) v[u] = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * D + 4 * m);
+        if (id < total && q < a.B) v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.q) + ((int64_t)q * nm + m) * 16);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -612,6 +622,9 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
             float* sQ1 = reinterpret_cast<float*>(smem);            // [D / 4][4][16]: element k = 4 m + kq of query q at (4 m + kq) * 16 + q
 #pragma unroll
             for (int e = 0; e < 4; ++e) sQ1[(4 * m + e) * 16 + q] = v[u][e];
+          } else if constexpr (BF) {
+            const int qt = q >> 5, ql = q & 31;                     // piece m = 8 k: k16 step m / 2, k half m % 2 -> [qt][m][query] 16 B
+            reinterpret_cast<f32x4*>(smem)[(qt * nm + m) * 32 + ql] = v[u];
           } else {
             const int qt = q >> 5, ql = q & 31;                     // [qt][m][half][query]: (Q[4m + h], Q[4m + 2 + h])
             sQ[(qt * nm + m) * 64 + ql] = f32x2{v[u][0], v[u][2]};
@@ -643,10 +656,11 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   constexpr int NWAVE = KS_THREADS / 64;
   constexpr int WSTEP = NWAVE * 32;                                 // rows between a wave's consecutive blocks
   constexpr int STG = 4096;                                         // one stage: 32 rows x 128 bytes (32 k)
-  constexpr int P = 4;                                              // stages in flight per wave, in REGISTERS (16 KB per wave, 128 KB per CU)
-  const int nsl = D / 32;                                           // stages (k slabs) per row block; D % 128 == 0 -> P divides it
+  constexpr int P = BF ? 3 : 4;                                     // stages in flight per wave, in REGISTERS (16 KB per wave, 128 KB per CU; bf16: 12 / 96 KB)
+  const int nsl = BF ? D / 64 : D / 32;                             // stages (128-byte k slabs) per row block; P divides it (fp32: D % 128 == 0, bf16: D % 192 == 0)
+  const int rowb = BF ? D * 2 : D * 4;                              // bytes per index row
   const int nbuf = a.ring;                                          // transpose stages per wave: 2, or 1 where the LDS has no room for two (launcher)
-  char* stg = smem + (size_t)D * 128 * NQT + (size_t)w * nbuf * STG;   // the wave's private transpose buffer
+  char* stg = smem + (size_t)D * (BF ? 64 : 128) * NQT + (size_t)w * nbuf * STG;   // the wave's private transpose buffer
   // stream of this wave: stage t = (block t / nsl, slab t % nsl).  A stage is fetched by 4 fully coalesced 16-byte loads per
   // lane (lane -> row 8i + lane / 8, chunk lane % 8: 8 rows x 128 contiguous bytes per instruction), parked in registers
   // while P - 1 older stages are consumed, then transposed through the wave's LDS buffer into the row-per-lane MFMA layout.
@@ -672,9 +686,9 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
       int row = r0i + 8 * i + (lane >> 3);
       row = row < a.N ? row : a.N - 1;                              // clamp: rows past the end are masked below
 #if KNN_STREAM_NT
-      r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + ((lane & 7) << 4)));
+      r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + (int64_t)row * rowb + sl * 128 + ((lane & 7) << 4)));
 #else
-      r[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X + (int64_t)row * D) + sl * 128 + ((lane & 7) << 4));
+      r[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + (int64_t)row * rowb + sl * 128 + ((lane & 7) << 4));
 #endif
     }
   };
@@ -712,9 +726,12 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   // (order-preserving keys) once per block and filter with the workgroup's best bound: a row below it cannot reach the output; rows
   // EQUAL to it still can (ties rank by id) and pass.  The lists are then no longer each chunk part's complete top-KMAX, but their union
   // still holds the chunk's top-k, which is all the merges need.
-  float sthr[NQT];
+  float sthr[NQT], eps2[NQT];                                       // eps2: screening only — the band below the bound that must survive (2 eps of the lane's query)
 #pragma unroll
-  for (int qt = 0; qt < NQT; ++qt) sthr[qt] = -FLT_MAX;
+  for (int qt = 0; qt < NQT; ++qt) {
+    sthr[qt] = -FLT_MAX; eps2[qt] = 0.f;
+    if constexpr (BF) { const int q = qt * 32 + r31; eps2[qt] = a.eps_scale * a.qnorm[q < a.B ? q : a.B - 1]; }
+  }
   while (r0 < row_hi) {
 #pragma unroll
     for (int u = 0; u < P; ++u) {
@@ -740,6 +757,20 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
           const float qv = qp16[((sl + u) * 8 + m) * 64];
           acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][m], qv, acc16[0], 0, 0, 0);
           acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][m], qv, acc16[1], 0, 0, 0);
+        }
+      } else if constexpr (BF) {
+        typedef typename Op16<__bf16>::V8 V8;
+        V8 xa[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xa[ks] = *reinterpret_cast<const V8*>(buf + r31 * 128 + (((2 * ks + half) ^ (r31 & 7)) << 4));
+        const V8* qb16 = reinterpret_cast<const V8*>(smem) + half * 32 + r31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) {
+            const V8 qv = qb16[(qt * nm + 2 * ((sl + u) * 4 + ks)) * 32];
+            acc[qt] = Op16<__bf16>::mfma(xa[ks], qv, acc[qt]);
+          }
         }
       } else {
       f32x4 xv[8];
@@ -791,7 +822,7 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
 #pragma unroll
       for (int qt = 0; qt < NQT; ++qt) {
         uint32_t hits = 0;
-        const float thr = ls[qt][KMAX - 1], thg = sthr[qt];
+        const float thr = ls[qt][KMAX - 1], thg = sthr[qt] - eps2[qt];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -856,7 +887,7 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   }
   __syncthreads();
   KNN_STAMP_AT(4)
-  const int kk = a.k < KMAX ? a.k : KMAX;
+  const int kk = BF ? KMAX : (a.k < KMAX ? a.k : KMAX);              // (screening: collect_lists reads whole lists)
   const int nout = (a.nchunks == 1) ? a.k : kk;
   const int nq = a.B < QW * NQT ? a.B : QW * NQT;
   for (int q = w; q < nq; q += NWAVE) {                              // wave-uniform: whole waves enter wave_merge_lds
@@ -866,7 +897,7 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
           a.dist[(int64_t)q * a.ldo + a.ocol + o] = (wi == ID_NONE) ? -FLT_MAX : ws;
           a.idx[(int64_t)q * a.ldo + a.ocol + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
         } else {
-          const int64_t off = ((int64_t)chunk * a.B + q) * KMAX + o;
+          const int64_t off = ((int64_t)chunk * (a.pB ? a.pB : a.B) + a.pq0 + q) * KMAX + o;
           a.pdist[off] = (wi == ID_NONE) ? -FLT_MAX : ws;
           a.pidx[off] = wi;
         }
@@ -876,11 +907,11 @@ __global__ __launch_bounds__(KS_THREADS, 1) void knn_stream_kernel(KnnArgs a) {
   KNN_STAMP_AT(5)
 }
 
-template <int KMAX, int NQT, bool Q16 = false>
-int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
+template <int KMAX, int NQT, bool Q16 = false, typename E = float>
+int launch_knn_stream(const KnnArgs& a_in, hipStream_t s, bool merge = true) {
   KnnArgs a = a_in;
   constexpr int NSRC = (KS_THREADS / 64) * (Q16 ? 4 : 2), QW = Q16 ? 16 : 32;
-  const size_t q_bytes = (size_t)a.D * 128 * NQT, m_bytes = (size_t)QW * NQT * (NSRC * (KMAX + 1) + 1) * 8;
+  const size_t q_bytes = (size_t)a.D * (std::is_same<E, float>::value ? 128 : 64) * NQT, m_bytes = (size_t)QW * NQT * (NSRC * (KMAX + 1) + 1) * 8;
   // control words (block counter + shared bounds): the 16-query image fills only half of its region — they live in the other half;
   // otherwise behind the stages.  Two transpose stages per wave where they fit next to one query tile's image, else one (LDS operations
   // of a wave execute in order, so re-writing a stage behind its reads is safe): 1M x 768 at 17..32 queries, and every two-tile launch.
@@ -893,11 +924,11 @@ int launch_knn_stream(const KnnArgs& a_in, hipStream_t s) {
   if (s_bytes > 160 * 1024 || m_bytes > 160 * 1024) return fail(EFFOCR_EUNSUPPORTED, "knn(stream): embedding dim / k too large for the LDS image");
   const size_t lds = s_bytes > m_bytes ? s_bytes : m_bytes;
   // per launch: the attribute belongs to the (function, device) pair and a process may search on several GPUs; the call is cheap
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX, NQT, Q16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_kernel<KMAX, NQT, Q16, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     return fail(EFFOCR_EHIP, "knn(stream): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-  hipLaunchKernelGGL((knn_stream_kernel<KMAX, NQT, Q16>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
+  hipLaunchKernelGGL((knn_stream_kernel<KMAX, NQT, Q16, E>), dim3((unsigned)a.nchunks), dim3(KS_THREADS), lds, s, a);
   int rc = check_launch("knn_stream");
-  if (rc != EFFOCR_OK || a.nchunks == 1) return rc;
+  if (rc != EFFOCR_OK || a.nchunks == 1 || !merge) return rc;
   launch_knn_merge<KMAX>(a.pdist, a.pidx, a.B, a.nchunks, a.k, a.dist, a.idx, a.run_flag, a.ldo, a.ocol, s);
   return check_launch("knn_merge");
 }
@@ -1051,11 +1082,31 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   const int kmax1 = (p.kmax < 16 && p.nchunks > 1 && !g_knn_two_pass) ? 16 : p.kmax;
   a.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * kmax1 * 4, 128));
   a.q = qb; a.xb = xb16; a.dist = adist; a.idx = aidx;
+  // 17..128 queries against a large index (at 256 the 128-query tile kernel is faster again: 1.0 vs 1.27 ms at 1M x 384; the ONNX driver's 64-crop calls against a jisx0213-scale index, infer_effocr_onnx_multi.py:372):
+  // the screening pass STREAMS the bf16 index once per 64 queries (knn_stream_kernel<.., __bf16>) instead of running the 128-query tile
+  // kernel; its chunk lists feed the same collect / re-rank / gated exact fallback.
+  const float c = (0.00390625f + 0.0000152587890625f + 4.0f * (float)D * 5.9604645e-8f) * 1.0001f;   // |s^ - s| <= c |q| |x|, see pass 2
+  const bool stream16 = B <= 128 && N >= 65536 && D % 192 == 0 && D <= 768 && p.nchunks > 1 && kmax1 >= 16 && !g_knn_two_pass && !g_knn_force_tile;
+  if (stream16) {
+    a.qnorm = qnorm;
+    a.eps_scale = 2.0f * c * xnorm_max;                    // the band of the re-rank's candidate set (below)
+    const int sq = kmax1 == 16 ? 64 : 32;                  // queries per launch: two query tiles where the lists hold 16 entries
+    for (int64_t q0 = 0; q0 < B; q0 += sq) {
+      KnnArgs b = a;
+      b.B = (int)(B - q0 < sq ? B - q0 : sq);
+      b.q = qb + q0 * D; b.qnorm = qnorm + q0; b.pB = (int)B; b.pq0 = (int)q0;
+      if (b.B > 32) rc = launch_knn_stream<16, 2, false, __bf16>(b, s, false);
+      else rc = kmax1 == 16 ? launch_knn_stream<16, 1, false, __bf16>(b, s, false) : launch_knn_stream<32, 1, false, __bf16>(b, s, false);
+      if (rc) return rc;
+    }
+    if (kmax1 == 16) launch_knn_merge<16>(a.pdist, a.pidx, (int)B, p.nchunks, k, adist, aidx, nullptr, k, 0, s);
+    else launch_knn_merge<32>(a.pdist, a.pidx, (int)B, p.nchunks, k, adist, aidx, nullptr, k, 0, s);
+    if ((rc = check_launch("knn_merge"))) return rc;
+  } else
   if ((rc = launch_knn_k<__bf16>(kmax1, a, s))) return rc;
   // pass 2: every row whose approximate score is within 2*eps of the k-th approximate score.
   // |s^ - s| <= eps = c * |q| * |x|: operand rounding (2^-8 + 2^-16) plus fp32 accumulation of both chains (4 d 2^-24),
   // 1e-4 relative slack for the fp32 norms.  A true top-k row has s >= s_(k), hence s^ >= s_(k) - eps >= s^_(k) - 2 eps.
-  const float c = (0.00390625f + 0.0000152587890625f + 4.0f * (float)D * 5.9604645e-8f) * 1.0001f;
   a.adist = adist; a.qnorm = qnorm; a.eps_scale = 2.0f * c * xnorm_max; a.cand = cand; a.cnt = cnt; a.cap = RR_CAP;
   if (p.nchunks > 1 && !g_knn_two_pass) {                  // the candidates are already in pass 1's per-chunk lists
     const dim3 cg((unsigned)((B + 3) / 4));

@@ -45,6 +45,9 @@
 #ifndef QA_ZERO_PAD
 #define QA_ZERO_PAD 0                                    // 1: rows past the image's last token are zero fragments instead of copies of the last token (same-box A/B: 1.1 % SLOWER, twice)
 #endif
+#ifndef QA_QKPAIR
+#define QA_QKPAIR 0                                      // 1: Q K^T walks the key tiles in pairs with alternating accumulators (see the attention loop)
+#endif
 #ifndef QA_KDEPTH
 #define QA_KDEPTH 1                                      // key tiles of lookahead of the K fragment reads in Q K^T
 #endif
@@ -389,6 +392,49 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);               // one query tile at a time (two score rows do not fit)
         const int tq = (2 * w + tt) * 32 + r31;
         f32x16 s[NTT];
+#if QA_QKPAIR
+        // Key tiles in PAIRS (round 4).  The four MFMAs of a key tile accumulate into one register tile, and a v_mfma_32x32x16 that reads the
+        // previous one's result as its C operand issues only every ~64 cycles instead of 32: the s_memtime timeline showed 1.9 k ticks for
+        // the 28 MFMAs of a query tile (0.9 k of matrix time), and reading the K fragments two or three tiles ahead did not move it
+        // (tools/qa_timeline.py, QA_KDEPTH) — it is the dependent chain, not the LDS.  Two tiles in lock step alternate their accumulators.
+        {
+          constexpr int NP = (NTT + 1) / 2;
+          V8 kp[2][2][4];                                // [buffer][tile of the pair][k step]
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j < NTT) {
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) kp[0][j][ks] = *reinterpret_cast<const V8*>(kb + (j * 4 + ks) * 1024);
+            }
+          qa_for<0, NP>([&](auto PP_) {
+            constexpr int pp = decltype(PP_)::value, cur = pp & 1, nxt = cur ^ 1, k0 = 2 * pp, k1 = 2 * pp + 1;
+            if constexpr (pp + 1 < NP) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                if (2 * (pp + 1) + j < NTT) {
+#pragma unroll
+                  for (int ks = 0; ks < 4; ++ks) kp[nxt][j][ks] = *reinterpret_cast<const V8*>(kb + ((2 * (pp + 1) + j) * 4 + ks) * 1024);
+                }
+            }
+            auto init = [&](auto K_) {
+              constexpr int kt = decltype(K_)::value;
+              if constexpr (INITMASK && kt == NTT - 1) s[kt] = sinit;
+              else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+              }
+            };
+            init(std::integral_constant<int, k0>{});
+            if constexpr (k1 < NTT) init(std::integral_constant<int, k1>{});
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              s[k0] = Op16<E>::mfma(kp[cur][0][ks], qf[tt][ks], s[k0]);
+              if constexpr (k1 < NTT) s[k1] = Op16<E>::mfma(kp[cur][1][ks], qf[tt][ks], s[k1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+#else
         // K fragments QA_KDEPTH key tiles ahead of their MFMAs (s_memtime timeline, tools/qa_timeline.py: with one tile of lookahead the
         // 28 MFMAs of a query tile's Q K^T took 1.9 k ticks for 0.9 k of matrix time — the four reads of a tile have 128 cycles of MFMAs
         // in front of them, less than an LDS round trip with four waves reading K / V and the weight DMA writing)
@@ -415,6 +461,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           for (int ks = 0; ks < 4; ++ks) s[kt] = Op16<E>::mfma(kf[cur][ks], qf[tt][ks], s[kt]);
           __builtin_amdgcn_sched_barrier(0);
         });
+#endif
         QA_STAMP_AT(5 + tt * 5)
         V8 vf[2][2];
 #pragma unroll

@@ -103,6 +103,10 @@ class IndexFlatIP:
         # Small indexes: the bf16 pass + re-rank pays only for large batches (10 k rows, 1024 queries: 0.135 vs 0.164 ms).
         if nq is None:
             return self.ntotal >= self.SCREEN_MIN_ROWS
+        # round 4: for 17..128 queries the screening pass streams the bf16 index once per 64 queries (dims that are multiples of 192):
+        # 1M x 384, 64 queries: see profiles/README.md — from 17 queries on it beats the exact fp32 stream, which is MFMA-bound there
+        if self.ntotal >= self.SCREEN_MIN_ROWS and self.d % 192 == 0 and self.d <= 768 and 16 < nq <= 128:
+            return True
         stream_cap = 64 if self.d <= 384 else 32
         # (k = 1 on a small index: the exact kernel keeps one-entry lists — 98 vs 111 us at 10 k rows x 1024 queries, tools/knn_c2_sweep.py)
         return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512 and k > 1)

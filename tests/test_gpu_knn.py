@@ -158,6 +158,40 @@ def test_screened_search_is_bit_identical(dev, N, D, B, k):
     assert torch.equal(I2, Is) and torch.equal(D2.view(torch.int32), Ds.view(torch.int32))
 
 
+@pytest.mark.parametrize("N,D,B,k", [(150_000, 384, 64, 10), (150_000, 384, 17, 1), (100_000, 768, 100, 10), (80_000, 384, 128, 20),
+                                     (80_000, 192, 33, 32)])
+def test_streaming_screen_is_bit_identical(dev, N, D, B, k):
+    """17..128 queries against a large index whose dim is a multiple of 192: the screening pass is the bf16 STREAMING kernel (64 queries per
+    launch; 32 where the lists hold 32 entries) instead of the 128-query tile kernel.  Same guarantee: ids and scores bit for bit those
+    of the exact search, no overflow flag on benign data; near-duplicate clusters and exact duplicates (tie rule) included."""
+    g = torch.Generator(device=dev).manual_seed(N + D + B)
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    X[7000:7003] = X[50]                                    # exact duplicates: ascending id
+    X[30000:30008] = torch.nn.functional.normalize(X[30000:30001] + 2e-3 * torch.randn(8, D, generator=g, device=dev), dim=1)   # a tight cluster (fits a chunk list)
+    pick = torch.randint(0, N, (B,), generator=g, device=dev)
+    pick[0], pick[1] = 50, 30000
+    Q = torch.nn.functional.normalize(X[pick] + 0.05 * torch.randn(B, D, generator=g, device=dev), dim=1)
+    Q[0] = X[50]
+    De, Ie, Ds, Is = _both(dev, X, Q, k)
+    assert torch.equal(Ie, Is)
+    assert torch.equal(De.view(torch.int32), Ds.view(torch.int32))
+    assert Is[0, 0].item() == 50 and (k < 2 or Is[0, 1].item() == 7000)
+    from effocr_amd.knn import IndexFlatIP
+    sc = IndexFlatIP(D, device=dev, screen=True)
+    sc.add(X)
+    sc.search_device(Q, k)
+    torch.cuda.synchronize()
+    assert _screen_flag(sc, B, k) == 0                      # the candidate lists did not overflow: no exact fallback ran
+    # the tile-kernel screen (A/B switch) agrees bit for bit
+    L = _lib.lib()
+    _lib.check(L.effocr_knn_set_option(b"force_tile", 1), "knn_set_option")
+    try:
+        _, _, D2, I2 = _both(dev, X, Q, k)
+    finally:
+        _lib.check(L.effocr_knn_set_option(b"force_tile", 0), "knn_set_option")
+    assert torch.equal(I2, Is) and torch.equal(D2.view(torch.int32), Ds.view(torch.int32))
+
+
 def test_screened_search_non_unit_rows_ties_and_overflow(dev):
     """Rows of very different norms (the bound uses the max norm), exact duplicates (tie rule: lower id first) and
     a cluster of > 512 near-identical rows around some queries (candidate overflow -> gated exact fallback)."""
