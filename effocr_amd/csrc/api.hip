@@ -80,7 +80,6 @@ struct effocr_encoder {
   int use_patchf = 1;               // fused im2col + patch-embed GEMM (patch.hip) on the blocked path (0: im2col kernel + gemm2, A/B switch)
   int use_mlp = 1;                  // fused LN2+fc1+GELU+fc2+residual kernel (mlp.hip) on the blocked panel path (0: A/B switch)
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
-  int mlp_tickets = 1;              // fused MLP: the last split part of a tail panel to arrive reduces the parts and writes the outputs itself (0: reduction + LayerNorm launch, A/B switch)
   int use_lnfold = 1;               // gemm3 path (ViT-B): LayerNorm folded into the residual producers' / qkv, fc1 consumers' epilogues (0: LayerNorm launches, A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
@@ -407,7 +406,7 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
   const size_t M = align_up((size_t)B * e->T, 128), D = e->vit.D, es = prec_esize(e->prec);
   Alloc a; VitWs w;
   w.rows = M;
-  w.status = a.take(2048);                   // int32 status word at workspace offset 0 (effocr_encoder_check_status); ints 64..319: ticket counters of the fused MLP's split panels
+  w.status = a.take(256);                    // int32 status word at workspace offset 0 (effocr_encoder_check_status)
   w.x = a.take(M * D * 4);
   w.xn = a.take(M * D * es);
   w.qkv = a.take(M * 3 * D * es);
@@ -497,7 +496,6 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
         m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
         m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split; m.stagger = e->mlp_stagger; m.stagger_min_rounds = e->mlp_stagger_min_rounds;   // the hidden buffer is free on this path
-        m.tickets = e->mlp_tickets ? reinterpret_cast<unsigned*>(ws + w.status) + 64 : nullptr;   // split tail panels finish inside the launch (zeroed by set_cls_rows, self-resetting)
         if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
           m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p);
           if (i + 1 == e->vit.depth && e->cls_only_last) {
@@ -789,7 +787,6 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_lnfold") { enc->use_lnfold = value; return EFFOCR_OK; }
-  if (n == "mlp_tickets") { enc->mlp_tickets = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }
   if (n == "use_qkvattn") { enc->use_qkvattn = value; return EFFOCR_OK; }
   if (n == "qa_min_batch") { enc->qa_min_batch = value; return EFFOCR_OK; }

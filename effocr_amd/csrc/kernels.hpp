@@ -64,10 +64,6 @@ struct MlpArgs {
   // optional second output: xn_out (16-bit, fragment-blocked) = LayerNorm(x_new; gamma_n, beta_n) — the NEXT block's
   // norm1, computed in the epilogue where a lane pair holds the whole new row (feeds qkvattn.hip)
   void* xn_out; const float* gamma_n; const float* beta_n;
-  // optional (round 4): one zeroed counter per split tail panel (>= 256 entries).  With it the split parts of a panel take a ticket
-  // behind their partial sums and the LAST one to arrive assembles the row (parts in index order + bias2), stores it and writes the
-  // second output itself — no reduction launch; the counters are left zero for the next launch.
-  unsigned* tickets;
 };
 bool mlp_fused_supported(int prec, int D, int H);
 int mlp_fused(int prec, const MlpArgs& a, hipStream_t s);

@@ -189,13 +189,12 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   float pb1[NB1], pdv[7][ND];
 #pragma unroll
   for (int i = 0; i < NB1; ++i) pb1[i] = a.b1[tid + 256 * i];
-  const bool second = a.xn_out != nullptr && (!PARTIAL || a.tickets != nullptr);   // (split parts: the last arriver writes it)
+  const bool second = !PARTIAL && a.xn_out != nullptr;
 #pragma unroll
   for (int j = 0; j < ND; ++j) {
     const int n = tid + 256 * j;
     if (n < D) {
-      pdv[0][j] = PARTIAL ? a.b2_logical[n] : a.b2[n];   // (split parts do not add bias2 themselves: the LOGICAL order for the last arriver's assembly)
-      pdv[1][j] = a.gamma[n]; pdv[2][j] = a.beta[n];
+      pdv[0][j] = a.b2[n]; pdv[1][j] = a.gamma[n]; pdv[2][j] = a.beta[n];
       if constexpr (PROJ) pdv[3][j] = a.bp[n];
       if (second) { pdv[4][j] = a.gamma_n[n]; pdv[5][j] = a.beta_n[n]; }
     }
@@ -654,62 +653,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   int hf = half;
   asm volatile("" : "+v"(hf));                           // opaque: else the LayerNorm's 48 chunk offsets are kept (spilled) across the main loop for this
   auto cq = [&](int t, int q) __attribute__((always_inline)) { return 8 * t + 4 * (q >> 1) + 2 * hf + (q & 1); };
-  // store the finished row (acc2 = x + bias2 + fc2) and, where asked for, the second output
-  auto finish = [&]() __attribute__((always_inline)) {
-    if (rb * 32 + r31 < a.M) {
-      char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
-      float sm = 0.f;
-      sfor<0, OT>([&](auto T_) {
-        constexpr int t = decltype(T_)::value;
-  #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
-          sm += (o[0] + o[1]) + (o[2] + o[3]);
-          st_act<4>(reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512), o);
-        }
-      });
-      MLP_STAMP_AT(9)
-      if (a.xn_out) {
-        // ---- second output.  The lane pair (r31, half 0 / 1) holds the whole new row: two-pass statistics (one cross-half
-        // exchange each) and the next block's norm1 applied on the way out, rounded to the operand type (same arithmetic as
-        // layernorm_blocked_kernel).  Registers 8p..8p+7 of tile t = 16-bit chunk 4t + 2p + half: one 16-byte store.
-        sm += __shfl_xor(sm, 32, 64);
-        const float mean = sm * (1.0f / D);
-        float ss = 0.f;
-        sfor<0, OT>([&](auto T_) {
-          constexpr int t = decltype(T_)::value;
-  #pragma unroll
-          for (int r = 0; r < 16; ++r) { const float d = acc2[t][r] - mean; ss += d * d; }
-        });
-        ss += __shfl_xor(ss, 32, 64);
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
-        char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
-        sfor<0, OT>([&](auto T_) {
-          constexpr int t = decltype(T_)::value;
-  #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            u32x2 pk[2];
-  #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int q = 2 * p + j, c = cq(t, q);       // fp32 chunk c = features 4c..4c+3 = half j of 16-bit chunk c >> 1
-              const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
-              const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
-              pk[j] = pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
-                               (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
-            }
-            const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
-            st_act<8>(reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512), o);
-          }
-        });
-      }
-    }
-  };
   if constexpr (PARTIAL) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
     const int64_t rbl = rb - (int64_t)a.panel0 * 4;
-    const int64_t part_stride = (int64_t)a.tail_rb * (D / 4) * 512;
-    char* pr0 = reinterpret_cast<char*>(a.partial) + (rbl * (D / 4)) * 512 + r31 * 16;
-    char* pr = pr0 + (int64_t)(bid % SPLIT) * part_stride;
+    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(bid % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + r31 * 16;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
@@ -718,40 +665,52 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
-    if (a.tickets) {
-      // ---- last arriver finishes the panel (round 4; was: a reduction + LayerNorm launch behind this one, ~20 us + its queue gap per
-      // transformer block — a quarter of a 64-crop forward).  Nobody waits: every part publishes its sums (device-scope release), takes a
-      // ticket, and only the part that draws the last one reads the others' sums back (acquire).  The row is assembled in PART order
-      // whoever arrives last — parts 0 .. SPLIT-1, then bias2 (then x without the projection): the arithmetic of the reduction kernel,
-      // bit for bit the same on every run.
-      __threadfence();
-      __syncthreads();
-      unsigned* sT = reinterpret_cast<unsigned*>(sB1);     // (bias1 is dead)
-      if (tid == 0) *sT = atomicAdd(a.tickets + (panel - a.panel0), 1u);
-      __syncthreads();
-      if (*sT == (unsigned)(SPLIT - 1)) {                  // workgroup-uniform
-        __threadfence();
-        if (tid == 0) a.tickets[panel - a.panel0] = 0u;    // ready for the next launch
-        sfor<0, OT>([&](auto T_) {
-          constexpr int t = decltype(T_)::value;
+  } else if (rb * 32 + r31 < a.M) {
+    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
+    float sm = 0.f;
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = cq(t, q);
-            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int p = 0; p < SPLIT; ++p) sum += *reinterpret_cast<const f32x4*>(pr0 + (int64_t)p * part_stride + (size_t)c * 512);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + c * 4);
-            f32x4 v = sum + bv;
-            if constexpr (!PROJ) v += *reinterpret_cast<const f32x4*>(xb + (size_t)c * 512);   // (with the projection part 0 carries the new row)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] = v[e];
-          }
-        });
-        finish();
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
+        sm += (o[0] + o[1]) + (o[2] + o[3]);
+        st_act<4>(reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512), o);
       }
+    });
+    MLP_STAMP_AT(9)
+    if (a.xn_out) {
+      // ---- second output.  The lane pair (r31, half 0 / 1) holds the whole new row: two-pass statistics (one cross-half
+      // exchange each) and the next block's norm1 applied on the way out, rounded to the operand type (same arithmetic as
+      // layernorm_blocked_kernel).  Registers 8p..8p+7 of tile t = 16-bit chunk 4t + 2p + half: one 16-byte store.
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm * (1.0f / D);
+      float ss = 0.f;
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc2[t][r] - mean; ss += d * d; }
+      });
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+      char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          u32x2 pk[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int q = 2 * p + j, c = cq(t, q);       // fp32 chunk c = features 4c..4c+3 = half j of 16-bit chunk c >> 1
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+            pk[j] = pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
+                             (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
+          }
+          const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+          st_act<8>(reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512), o);
+        }
+      });
     }
-  } else {
-    finish();
   }
   MLP_STAMP_AT(10)
 #ifdef MLP_STAMP
@@ -825,7 +784,7 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   else if (split == 2) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, PROJ>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 0, PROJ>), grid, dim3(256), 0, s, a);
   int rc = check_launch("mlp_fused");
-  if (rc || split == 1 || a.tickets) return rc;          // (tickets: the last part of every split panel has finished it inside the launch)
+  if (rc || split == 1) return rc;
   const int64_t rb0 = (int64_t)main_panels * 4;          // first row block of the split panels
   const int prec = std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16;
   if (a.xn_out && MLP_FUSED_REDUCE_LN) {

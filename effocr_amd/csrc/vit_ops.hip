@@ -213,10 +213,7 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict
 // token 0 of every image = cls_token + pos_embed[0] (pre-added on the host at weight upload)
 __global__ void set_cls_kernel(const float* __restrict__ cls_pos0, float* __restrict__ x, int B, int T, int D, int blocked, int* __restrict__ status_zero) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // first kernel of a forward: the status word (int 0) starts clean, and so do the 256 ticket counters of the fused MLP's split
-  // panels behind it (ints 64 .. 319; they return to zero by themselves, this only covers a forward that was cut short)
-  if (status_zero && id < 320 && (id == 0 || id >= 64)) status_zero[id] = 0;
-  if (status_zero && id == 0 && (int64_t)gridDim.x * 256 < 320) { for (int i = 64; i < 320; ++i) status_zero[i] = 0; }
+  if (id == 0 && status_zero) *status_zero = 0;          // first kernel of a forward: the status word starts clean
   if (id >= (int64_t)B * D) return;
   const int d = (int)(id % D);
   const int64_t img = id / D;
