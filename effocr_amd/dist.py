@@ -5,7 +5,8 @@ call site; the path shards embarrassingly over crops (every row of infer_effocr.
 independent), so each rank runs encoder + k-NN on its contiguous slice with the encoder weights and
 the glyph index REPLICATED per GPU, and a single ``all_gather`` (RCCL over xGMI when the backend is
 "nccl"; "gloo" in the CPU tests) assembles the per-rank top-k ids — ``B/P * k * 8`` bytes per rank,
-latency-bound.  No all-reduce exists on this path.
+latency-bound.  No all-reduce exists on this path.  ``ShardedIndexSearch`` is the optional variant that shards the index rows instead
+ and merges per-shard top-k lists exactly.
 """
 import torch
 import torch.distributed as dist
@@ -84,6 +85,50 @@ class ShardedRecognizer:
             local = crops[lo:hi]
         d, i = self.neighbors_fn(local)
         return all_gather_rows(d, n_total, self.group), all_gather_rows(i, n_total, self.group)
+
+
+def merge_topk(dists, ids, k):
+    """Exact merge of per-shard top-k lists: ``dists`` / ``ids`` [P, B, k'] (k' >= what each shard returned; padding = (-FLT_MAX, -1)) ->
+    the k best of every query's P * k' candidates in the product's order — score descending, equal scores by ascending GLOBAL id
+    (the tie rule of ``effocr_knn_ip_topk``), padding last.  Two stable sorts: by id, then by score."""
+    P, B, kk = dists.shape
+    d = dists.permute(1, 0, 2).reshape(B, P * kk)
+    i = ids.permute(1, 0, 2).reshape(B, P * kk)
+    big = torch.iinfo(torch.int64).max
+    order = torch.sort(torch.where(i < 0, torch.full_like(i, big), i), dim=1, stable=True)[1]      # ids ascending, padding last
+    d, i = torch.gather(d, 1, order), torch.gather(i, 1, order)
+    order = torch.sort(d, dim=1, descending=True, stable=True)[1]
+    d, i = torch.gather(d, 1, order)[:, :k], torch.gather(i, 1, order)[:, :k]
+    if d.shape[1] < k:                                   # fewer candidates than k in total: faiss pads (-FLT_MAX, -1)
+        padn = k - d.shape[1]
+        d = torch.cat([d, torch.full((B, padn), torch.finfo(torch.float32).min, dtype=d.dtype, device=d.device)], 1)
+        i = torch.cat([i, torch.full((B, padn), -1, dtype=i.dtype, device=i.device)], 1)
+    return d.contiguous(), i.contiguous()
+
+
+class ShardedIndexSearch:
+    """SURVEY 8(e)'s variant for indexes that outgrow one GPU: the glyph INDEX is sharded by rows instead of the crops.  Rank r
+    holds rows ``shard_bounds(ntotal, r, P)`` in its own ``IndexFlatIP``; every rank searches ALL queries against its shard
+    (``search_fn(q, k) -> (distances [B,k], LOCAL ids [B,k])``, e.g. ``index.search_device``), ONE all-gather of the
+    ``(score fp32, global id int64)[B,k]`` lists (12 k B bytes per rank: 120 KiB at 1024 queries, k = 10) and the exact merge above give
+    every rank the result of the single-index search — scores are the same fmaf chains, ties the same ascending-id rule, so ids and
+    scores are bit-identical to one big index (``tests/test_dist_gloo.py``).  Not needed at BASELINE configs[3]'s 3 GB."""
+
+    def __init__(self, search_fn, row_offset, group=None):
+        self.search_fn = search_fn
+        self.row_offset = int(row_offset)
+        self.group = group
+
+    def __call__(self, queries, k):
+        d, i = self.search_fn(queries, k)
+        i = torch.where(i >= 0, i + self.row_offset, i)      # local row -> global row; padding stays -1
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return d, i
+        world = dist.get_world_size(self.group)
+        B = d.shape[0]
+        dg = all_gather_rows(d, B * world, self.group).reshape(world, B, k)      # equal blocks of B rows per rank
+        ig = all_gather_rows(i, B * world, self.group).reshape(world, B, k)
+        return merge_topk(dg, ig, k)
 
 
 def all_gather_texts(local_pairs, group=None):

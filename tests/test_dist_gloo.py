@@ -57,6 +57,57 @@ def test_sharded_recognizer_world_size_2(tmp_path, n):
         assert np.array_equal(np.load(tmp_path / f"d{r}.npy"), d_ref)
 
 
+def _index_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from effocr_amd.dist import ShardedIndexSearch, shard_bounds
+        from oracle import knn_ref
+        rng = np.random.default_rng(1)
+        X = rng.standard_normal((301, 64)).astype(np.float32)
+        X[200] = X[7]; X[150] = X[7]                   # exact duplicates in BOTH shards: ties must rank by ascending global id
+        Q = np.concatenate([X[[7, 250]], rng.standard_normal((19, 64)).astype(np.float32)])
+        lo, hi = shard_bounds(301, rank, world)
+
+        def search(q, k):                              # stands in for this rank's IndexFlatIP.search_device over its rows
+            d, i = knn_ref.flat_ip_search(q.numpy(), X[lo:hi], k)
+            return torch.from_numpy(d), torch.from_numpy(i)
+
+        for k in (1, 10):
+            d, i = ShardedIndexSearch(search, lo)(torch.from_numpy(Q), k)
+            np.save(os.path.join(out_dir, f"si{rank}_{k}.npy"), i.numpy())
+            np.save(os.path.join(out_dir, f"sd{rank}_{k}.npy"), d.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_index_world_size_2(tmp_path):
+    """SURVEY 8(e) optional variant: index rows sharded over the ranks, per-shard top-k lists all-gathered and merged exactly — ids and
+    scores bit-identical to the single-index search, duplicates across the shard boundary ranked by ascending global id."""
+    from oracle import knn_ref
+    world, port = 2, _free_port()
+    mp.spawn(_index_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((301, 64)).astype(np.float32)
+    X[200] = X[7]; X[150] = X[7]
+    Q = np.concatenate([X[[7, 250]], rng.standard_normal((19, 64)).astype(np.float32)])
+    for k in (1, 10):
+        d_ref, i_ref = knn_ref.flat_ip_search(Q, X, k)
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / f"si{r}_{k}.npy"), i_ref)
+            assert np.array_equal(np.load(tmp_path / f"sd{r}_{k}.npy").view(np.uint32), d_ref.view(np.uint32))
+    assert list(knn_ref.flat_ip_search(Q, X, 10)[1][0][:3]) == [7, 150, 200]
+
+
+def test_merge_topk_padding_and_fewer_candidates_than_k():
+    from effocr_amd.dist import merge_topk
+    fmin = torch.finfo(torch.float32).min
+    d = torch.tensor([[[0.5, fmin]], [[0.5, 0.25]]])                 # shard 0 holds one row, shard 1 two; k' = 2
+    i = torch.tensor([[[3, -1]], [[1, 9]]])
+    dd, ii = merge_topk(d, i, 4)
+    assert ii.tolist() == [[1, 3, 9, -1]] and dd[0, 3].item() == fmin and dd[0, 0].item() == 0.5
+
+
 def test_single_process_passthrough():
     from effocr_amd.dist import ShardedRecognizer, all_gather_rows
     t = torch.arange(12).reshape(4, 3)

@@ -155,6 +155,52 @@ def test_sharded_recognizer_two_processes_on_gpu(dev, tmp_path):
     assert torch.equal(d.cpu(), d0)                     # same kernels, same rows: bit-identical however the batch is split
 
 
+def _index_shard_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # (both ranks may share the test box's one GPU)
+    try:
+        from effocr_amd.dist import ShardedIndexSearch, shard_bounds
+        from effocr_amd.knn import IndexFlatIP
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(rank % ndev)
+        dev = torch.device("cuda", rank % ndev)
+        X, Q = _index_shard_data()
+        lo, hi = shard_bounds(X.shape[0], rank, world)
+        idx = IndexFlatIP(X.shape[1], device=dev, screen=False)
+        idx.add(X[lo:hi])
+        for k in (1, 10):
+            d, i = ShardedIndexSearch(idx.search_device, lo)(Q.to(dev), k)
+            torch.save((d.cpu(), i.cpu()), os.path.join(out_dir, f"s{rank}_{k}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _index_shard_data():
+    g = torch.Generator().manual_seed(31)
+    X = torch.nn.functional.normalize(torch.randn(70_001, 128, generator=g), dim=1)
+    X[60_000] = X[5]; X[20_000] = X[5]                                  # duplicates on both sides of the shard boundary
+    Q = torch.nn.functional.normalize(torch.cat([X[[5, 69_000]], torch.randn(21, 128, generator=g)]), dim=1)
+    return X, Q
+
+
+def test_index_sharded_search_two_processes_on_gpu(dev, tmp_path):
+    """SURVEY 8(e)'s optional variant through the product API: the index rows split over two processes (HIP streaming search per shard),
+    (score, global id) lists all-gathered and merged — bit-identical to one process searching the whole index, duplicates ranked by id."""
+    import torch.multiprocessing as mp
+    from effocr_amd.knn import IndexFlatIP
+    mp.spawn(_index_shard_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    X, Q = _index_shard_data()
+    idx = IndexFlatIP(X.shape[1], device=dev, screen=False)
+    idx.add(X)
+    for k in (1, 10):
+        d, i = idx.search_device(Q.to(dev), k)
+        for r in range(2):
+            dr, ir = torch.load(tmp_path / f"s{r}_{k}.pt")
+            assert torch.equal(ir, i.cpu()) and torch.equal(dr.view(torch.int32), d.cpu().view(torch.int32))
+    assert idx.search_device(Q.to(dev), 10)[1][0, :3].tolist() == [5, 20_000, 60_000]
+
+
 def _nccl_rank_main(rank, world, port, out_dir):
     """One process per GPU over RCCL ("nccl"): the product's ShardedRecognizer + the id all-gather exactly as bench.py --gpus N runs it."""
     import torch.distributed as dist
