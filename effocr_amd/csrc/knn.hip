@@ -239,6 +239,16 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
       for (int j = 0; j < 2; ++j) {
         uint32_t hits = 0;
         const float thr = ls[j][KMAX - 1];
+        // quick reject (round 4): once the lists have warmed up almost no tile holds a candidate, and the per-score test below (row
+        // bound, threshold, bit merge: PMC counted 12 VALU instructions per MFMA in the screening pass of configs[3]) is what the
+        // kernel spent its time on.  The lane's 32 scores of this query column first go through a max tree (v_max3: half an
+        // instruction per score); only a wave in which some lane's maximum beats its threshold looks at the scores one by one.
+        float mxs = acc[0][j][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mxs = fmaxf(mxs, acc[i][j][r]);
+        if (__any(mxs > thr)) {
         float aS = 0.f; int aI = 0;
         if constexpr (AFTER) {                               // last result of the previous pass for this lane's query
           const int qg = q0 + wm * 64 + j * 32 + r31;
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void knn_partial_kernel(KnnArgs a) {
               if (mine) topk_insert<KMAX>(ls[j], li[j], sc, n);
             }
           }
+        }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
