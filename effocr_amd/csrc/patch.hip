@@ -18,6 +18,9 @@
 #include "kernels.hpp"
 #include <type_traits>
 
+#ifndef PE_SLABS
+#define PE_SLABS 2                                        // 64-k pixel slabs in flight per lane (32 registers each)
+#endif
 #ifndef PATCH_NT
 #define PATCH_NT 1                                        // non-temporal: 1 = pixel loads (read once), 2 = row stores
 #endif
@@ -69,9 +72,11 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
       sl.v[2 * c4 + 1] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4)) : *reinterpret_cast<const f32x4*>(q + 4);
     }
   };
-  Slab sl[2];
-  load_slab(sl[0], 0);
-  load_slab(sl[1], 1);
+  // PE_SLABS slabs in flight (static buffers, slab ks lives in buffer ks % PE_SLABS): 2 slabs = 64 KB per CU in flight, about the
+  // bandwidth-delay product of the chip's fair share — the kernel ran at 42 % of the HBM peak (round 3); 3 slabs = 96 KB
+  Slab sl[PE_SLABS];
+#pragma unroll
+  for (int i = 0; i < PE_SLABS; ++i) load_slab(sl[i], i);
   asm volatile("" ::: "memory");
 
   // ---- weight ring: stage s = (slab s / OG, group s % OG); wave w copies row block w of the group: 4 pieces of 1 KB
@@ -143,8 +148,8 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
     const char* st = smem + (S & (R - 1)) * PE_STAGE;
     const char* stn = smem + ((S + 1) & (R - 1)) * PE_STAGE;
     if constexpr (g == 0) {                              // a new slab: its pixels (requested two slabs ago) become fragments
-      to_frags(sl[ks & 1], xf);
-      if constexpr (ks + 2 < KS) load_slab(sl[ks & 1], ks + 2);
+      to_frags(sl[ks % PE_SLABS], xf);
+      if constexpr (ks + PE_SLABS < KS) load_slab(sl[ks % PE_SLABS], ks + PE_SLABS);
     }
     pfor<0, 4>([&](auto C4) {
       constexpr int c4 = decltype(C4)::value;
