@@ -160,7 +160,9 @@ int effocr_knn_ip_topk(const float* q_dev, int64_t nq, const float* xb_dev, int6
  * whose approximate score s^ lies within 2*eps of the k-th largest s^ (eps = c*|q|*xnorm_max bounds |s^ - s| rigorously:
  * operand rounding 2^-8 + 2^-16, fp32 accumulation 4*d*2^-24), the candidates are re-ranked with the exact ascending-k
  * fmaf chain, and — gated on the device — the exact search runs over everything if a query had more than 512
- * candidates.  dist / idx are BIT-IDENTICAL to effocr_knn_ip_topk for every input.
+ * candidates.  dist / idx are BIT-IDENTICAL to effocr_knn_ip_topk for every input.  For nq <= 128 against >= 65 536 rows with
+ * d % 192 == 0 (the ONNX driver's 64-crop batches, infer_effocr_onnx_multi.py:372) the screening pass STREAMS the bf16 copy once per
+ * 64 queries at the HBM rate (1M x 384, 64 queries: 0.33 ms); larger batches use the 128-query tile kernel.
  *   xb_bf16_dev  bf16 copy of xb_dev made with effocr_convert_bf16;  xnorm_max >= the L2 norm of every index row
  *   d % 64 == 0, k <= 32, ntotal >= k. */
 size_t effocr_knn_screen_workspace_bytes(int64_t nq, int64_t ntotal, int d, int k);
