@@ -18,9 +18,7 @@
 #include "kernels.hpp"
 #include <type_traits>
 
-#ifndef PE_SLABS
-#define PE_SLABS 2                                        // 64-k pixel slabs in flight per lane (32 registers each)
-#endif
+constexpr int PE_SLABS = 2;                              // 64-k pixel slabs in flight per lane (32 registers each; 3 and 4 measured +-0: not what binds)
 #ifndef PATCH_NT
 #define PATCH_NT 1                                        // non-temporal: 1 = pixel loads (read once), 2 = row stores
 #endif
@@ -72,8 +70,7 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
       sl.v[2 * c4 + 1] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4)) : *reinterpret_cast<const f32x4*>(q + 4);
     }
   };
-  // PE_SLABS slabs in flight (static buffers, slab ks lives in buffer ks % PE_SLABS): 2 slabs = 64 KB per CU in flight, about the
-  // bandwidth-delay product of the chip's fair share — the kernel ran at 42 % of the HBM peak (round 3); 3 slabs = 96 KB
+  // PE_SLABS slabs in flight (static buffers, slab ks lives in buffer ks % PE_SLABS), requested BEFORE the ring's prologue: they are needed first
   Slab sl[PE_SLABS];
 #pragma unroll
   for (int i = 0; i < PE_SLABS; ++i) load_slab(sl[i], i);

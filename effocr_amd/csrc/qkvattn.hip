@@ -42,18 +42,6 @@
 #ifndef QA_NT
 #define QA_NT 0                                          // non-temporal: 1 row loads, 2 output stores (both measured slower: the fused MLP reads the output next)
 #endif
-#ifndef QA_ZERO_PAD
-#define QA_ZERO_PAD 0                                    // 1: rows past the image's last token are zero fragments instead of copies of the last token (same-box A/B: 1.1 % SLOWER, twice)
-#endif
-#ifndef QA_QKPAIR
-#define QA_QKPAIR 0                                      // 1: Q K^T walks the key tiles in pairs with alternating accumulators (see the attention loop)
-#endif
-#ifndef QA_KDEPTH
-#define QA_KDEPTH 1                                      // key tiles of lookahead of the K fragment reads in Q K^T
-#endif
-#ifndef QA_TWOSET
-#define QA_TWOSET 0                                      // 1: two static W-fragment sets in the projection (reads a whole k-step ahead), see the k-step loop
-#endif
 #ifndef QA_BARRIER_DRAIN
 #define QA_BARRIER_DRAIN 0
 #endif
@@ -182,9 +170,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     V8 xf[NA][NXF];                                      // LayerNorm(x) operand fragments, resident for the whole kernel
 
     // lane = (row r31, half): operand fragment t of its row = 16-byte chunk 2t+half.  Rows past the image's last token (their keys
-    // are masked, their query rows never stored) re-read the last token.  (QA_ZERO_PAD = 1 makes them zero fragments — 59 of the 256
-    // row slots of a 197-token image would then feed the matrix pipe operands that do not toggle the multipliers, and the chip runs this
-    // kernel power-limited at 2.09 GHz — but the build measured 1.1 % slower end to end, twice, same box: not the default.)
+    // are masked, their query rows never stored) re-read the last token.  (Zero fragments instead — 59 of the 256 row slots of a
+    // 197-token image feeding the matrix pipe operands that do not toggle the multipliers, the chip runs this kernel power-limited —
+    // measured 1.1 % SLOWER end to end, twice, same box: DESIGN.md, round 4.)
     auto load_frags = [&](int img) __attribute__((always_inline)) {
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
@@ -196,12 +184,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         for (int i = 0; i < NXF; ++i) {
           xf[tt][i] = (QA_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const V8*>(xb + i * 1024)) : *reinterpret_cast<const V8*>(xb + i * 1024);
         }
-#if QA_ZERO_PAD
-        if (t0 >= T) {
-#pragma unroll
-          for (int i = 0; i < NXF; ++i) xf[tt][i] = V8{};
-        }
-#endif
       }
     };
     const int nimg = (a.B - slot0 + nslots - 1) / nslots;   // images of this workgroup (>= 1)
@@ -224,9 +206,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       QA_STAMP_AT(0)
       V8 qf[NA][4];                                      // Q^T operand fragments of the wave's tiles (k-step = 16 head dims)
       V8 f0, f1;                                         // the k-step's two W fragments (row blocks 0 / 1 of the stage)
-#if QA_TWOSET
-      V8 fw[2][2];                                       // two static fragment sets: step ks consumes set ks & 1 while set (ks + 1) & 1 loads
-#endif
       qa_for<0, 3>([&](auto SEC_) {
         constexpr int sec = decltype(SEC_)::value;       // 0 q, 1 k, 2 v
         f32x16 acc[NA][2];
@@ -244,57 +223,11 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           const int nslot = slot + 1 == R ? 0 : slot + 1;
           const char* stn = sW + nslot * QA_STAGE + half * 512 + r31 * 16;
           if constexpr (sl == 0) {                       // later stages: requested under the previous stage's last MFMAs
-#if QA_TWOSET
-            fw[0][0] = *reinterpret_cast<const V8*>(st);
-            fw[0][1] = *reinterpret_cast<const V8*>(st + 16 * 512);
-#else
             f0 = *reinterpret_cast<const V8*>(st);
             f1 = *reinterpret_cast<const V8*>(st + 16 * 512);
-#endif
           }
           qa_for<0, 8>([&](auto KS_) {
             constexpr int ks = decltype(KS_)::value;
-#if QA_TWOSET
-            // The rolling form below (f0 = n0) lets the register allocator give the next step's fragment the register the current one
-            // vacates: the read can then only issue behind the MFMAs that still read it, two MFMAs (64 cycles) in front of its own use —
-            // less than an LDS round trip with four waves and the weight DMA on the LDS (ISA of the round-3 kernel).  Two static sets
-            // keep the read a whole step (four MFMAs) ahead.
-            if constexpr (ks == 4) {
-              if constexpr (SMALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              else if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
-              else if constexpr (ft >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((ft < R - 2 ? ft : R - 2) - 1) * 4) : "memory");
-              __builtin_amdgcn_s_barrier();
-              asm volatile("" ::: "memory");
-            }
-            if constexpr (ks < 7) {
-              fw[(ks + 1) & 1][0] = *reinterpret_cast<const V8*>(st + (2 * (ks + 1)) * 512);
-              fw[(ks + 1) & 1][1] = *reinterpret_cast<const V8*>(st + (16 + 2 * (ks + 1)) * 512);
-            } else if constexpr (sl + 1 < NSH) {
-              fw[0][0] = *reinterpret_cast<const V8*>(stn);
-              fw[0][1] = *reinterpret_cast<const V8*>(stn + 16 * 512);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-              if constexpr (CLS && sec == 0) {
-                if (w == 0 && tt == 0) {
-                  acc[tt][0] = Op16<E>::mfma(fw[ks & 1][0], xf[tt][kt * 8 + ks], acc[tt][0]);
-                  acc[tt][1] = Op16<E>::mfma(fw[ks & 1][1], xf[tt][kt * 8 + ks], acc[tt][1]);
-                }
-              } else if constexpr (sec < 2) {
-                acc[tt][0] = Op16<E>::mfma(fw[ks & 1][0], xf[tt][kt * 8 + ks], acc[tt][0]);
-                acc[tt][1] = Op16<E>::mfma(fw[ks & 1][1], xf[tt][kt * 8 + ks], acc[tt][1]);
-              } else {
-                acc[tt][0] = Op16<E>::mfma(xf[tt][kt * 8 + ks], fw[ks & 1][0], acc[tt][0]);
-                acc[tt][1] = Op16<E>::mfma(xf[tt][kt * 8 + ks], fw[ks & 1][1], acc[tt][1]);
-              }
-            }
-            if constexpr (ks >= 4) {
-              if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_piece_asm(std::integral_constant<int, ks - 4>{}); }
-              else if constexpr (!LAST || ft >= R - 1) issue_piece_asm(std::integral_constant<int, ks - 4>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#else
             if constexpr (ks == 4) {
               // middle of stage g: stage g+1 has landed (own pieces; the younger stages may stay in flight) and,
               // past the barrier, everybody's; every wave is done with stage g-1, whose slot takes stage g+R-1
@@ -335,7 +268,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
               else if constexpr (!LAST || ft >= R - 1) issue_piece_asm(std::integral_constant<int, ks - 4>{});
             }
             if constexpr (ks < 7 || sl + 1 < NSH) { f0 = n0; f1 = n1; }
-#endif
           });
           if constexpr (SMALL) { if (g + R - 1 < gtotal) issue_advance(); }
           else if constexpr (!LAST || ft >= R - 1) issue_advance();
@@ -392,53 +324,9 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);               // one query tile at a time (two score rows do not fit)
         const int tq = (2 * w + tt) * 32 + r31;
         f32x16 s[NTT];
-#if QA_QKPAIR
-        // Key tiles in PAIRS (round 4).  The four MFMAs of a key tile accumulate into one register tile, and a v_mfma_32x32x16 that reads the
-        // previous one's result as its C operand issues only every ~64 cycles instead of 32: the s_memtime timeline showed 1.9 k ticks for
-        // the 28 MFMAs of a query tile (0.9 k of matrix time), and reading the K fragments two or three tiles ahead did not move it
-        // (tools/qa_timeline.py, QA_KDEPTH) — it is the dependent chain, not the LDS.  Two tiles in lock step alternate their accumulators.
-        {
-          constexpr int NP = (NTT + 1) / 2;
-          V8 kp[2][2][4];                                // [buffer][tile of the pair][k step]
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (j < NTT) {
-#pragma unroll
-              for (int ks = 0; ks < 4; ++ks) kp[0][j][ks] = *reinterpret_cast<const V8*>(kb + (j * 4 + ks) * 1024);
-            }
-          qa_for<0, NP>([&](auto PP_) {
-            constexpr int pp = decltype(PP_)::value, cur = pp & 1, nxt = cur ^ 1, k0 = 2 * pp, k1 = 2 * pp + 1;
-            if constexpr (pp + 1 < NP) {
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                if (2 * (pp + 1) + j < NTT) {
-#pragma unroll
-                  for (int ks = 0; ks < 4; ++ks) kp[nxt][j][ks] = *reinterpret_cast<const V8*>(kb + ((2 * (pp + 1) + j) * 4 + ks) * 1024);
-                }
-            }
-            auto init = [&](auto K_) {
-              constexpr int kt = decltype(K_)::value;
-              if constexpr (INITMASK && kt == NTT - 1) s[kt] = sinit;
-              else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-              }
-            };
-            init(std::integral_constant<int, k0>{});
-            if constexpr (k1 < NTT) init(std::integral_constant<int, k1>{});
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              s[k0] = Op16<E>::mfma(kp[cur][0][ks], qf[tt][ks], s[k0]);
-              if constexpr (k1 < NTT) s[k1] = Op16<E>::mfma(kp[cur][1][ks], qf[tt][ks], s[k1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
-#else
-        // K fragments QA_KDEPTH key tiles ahead of their MFMAs (s_memtime timeline, tools/qa_timeline.py: with one tile of lookahead the
-        // 28 MFMAs of a query tile's Q K^T took 1.9 k ticks for 0.9 k of matrix time — the four reads of a tile have 128 cycles of MFMAs
-        // in front of them, less than an LDS round trip with four waves reading K / V and the weight DMA writing)
-        constexpr int KD = QA_KDEPTH + 1;                // fragment sets in the ring
+        // K fragments one key tile ahead of their MFMAs (two and three tiles ahead, and key tiles in pairs with alternating accumulators,
+        // measured +-0 in round 4: the 1.9 k ticks the s_memtime timeline showed for a query tile's 28 Q K^T MFMAs were mostly the stamps)
+        constexpr int QA_KDEPTH = 1, KD = QA_KDEPTH + 1;   // lookahead in key tiles / fragment sets in the ring (2 and 3 tiles ahead: +-0)
         V8 kf[KD][4];
 #pragma unroll
         for (int d = 0; d < QA_KDEPTH; ++d)
@@ -461,7 +349,6 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
           for (int ks = 0; ks < 4; ++ks) s[kt] = Op16<E>::mfma(kf[cur][ks], qf[tt][ks], s[kt]);
           __builtin_amdgcn_sched_barrier(0);
         });
-#endif
         QA_STAMP_AT(5 + tt * 5)
         V8 vf[2][2];
 #pragma unroll
