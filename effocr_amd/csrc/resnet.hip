@@ -58,19 +58,68 @@ __device__ __forceinline__ void conv_stage_load16(u32x4 (&r)[4], const ConvArgs&
   }
 }
 
+// one K-stage of MFMAs for a wave's NI x NJ sub-tiles (32 channels x 32 pixels each): tile128::stage_mma with the wave's first weight / pixel
+// row explicit, so that the channel tile can be narrower than 128 (NW below)
+template <typename TA, int NI, int NJ>
+__device__ __forceinline__ void conv_stage_mma(f32x16 (&acc)[NI][NJ], const char* sW, const char* sX, int wrow0, int xrow0, int lane) {
+  const int r31 = lane & 31, half = lane >> 5;
+  const char* pw = sW + (wrow0 + r31) * ROWS;
+  const char* px = sX + (xrow0 + r31) * ROWS;
+  if constexpr (tile128::is_f32<TA>::value) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[NI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const f32x4*>(pw + i * 32 * ROWS + half * 64 + g * 16);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(px + j * 32 * ROWS + half * 64 + g * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+  } else {
+    typedef typename Op16<TA>::V8 V8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      V8 a[NI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const V8*>(pw + i * 32 * ROWS + (2 * ks + half) * 16);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const V8*>(px + j * 32 * ROWS + (2 * ks + half) * 16);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = Op16<TA>::mfma(a[i], b[j], acc[i][j]);
+    }
+  }
+}
+
 // E = float: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products).  E = __bf16: operands rounded to bf16 (activations in the
 // stage loader, weights once at upload: a.w16 [Cout][ceil(K/64)*64]) on v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogue.
-template <typename E>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+// NW = channel tile (round 4): 128 (2 x 2 waves of 64 channels x 64 pixels), 64 (2 x 2 waves of 32 x 64) or 32 (4 waves of 32 x 32, all
+// on the same 32 channels).  YOLOv5s spends 40 % of a forward in convolutions with <= 64 output channels (tools/loc_trace.py: C3 hidden
+// widths 32 / 64, the first down-sampling convolutions): on the 128-wide tile 1/2 .. 3/4 of their MFMAs multiplied clamped weight rows.
+template <typename E, int NW>
+__global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool B16 = !tile128::is_f32<E>::value;
-  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+  constexpr int NI = NW == 128 ? 2 : 1, NJ = NW == 32 ? 1 : 2;
+  // a stage = [NW weight rows | 128 pixel rows] of 144 bytes, double buffered: 73.7 / 55.3 / 46.1 KB -> 2 / 2 / 3 workgroups per CU (the
+  // narrow layers are the short-K, latency-bound ones: 1x1 convolutions of two to four stages)
+  constexpr int WTB = NW * ROWS, STB = WTB + TILEB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id(), wn = w >> 1, wm = w & 1;
   const int M = a.B * a.OH * a.OW;
   const int K = a.KH * a.KW * a.Cin;
-  const int ntn = (a.Cout + BN - 1) / BN;
+  const int ntn = (a.Cout + NW - 1) / NW;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * NW;
+  const int wrow0 = NW == 128 ? wn * 64 : (NW == 64 ? wn * 32 : 0);      // this wave's first channel / pixel row inside the tile
+  const int xrow0 = NW == 32 ? w * 32 : wm * 64;
   const int nks_all = B16 ? (K + 63) / 64 : K / 32;
   const int Kp = nks_all * 64;                           // (bf16) padded weight row length
   // split K: workgroup (x, y) runs the stages [y, y + 1) * nks_all / ksplit and writes its raw accumulators to the scratch
@@ -89,37 +138,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     rc[i].ix0 = ox * a.stride - a.pad;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  u32x4 rw[4], rx[4];
-  auto load_stage = [&](int ks) __attribute__((always_inline)) {
-    if constexpr (B16) {
-      stage_load<__bf16>(rw, static_cast<const __bf16*>(a.w16), Kp, n0, a.Cout, ks * ROWB, tid);
-      conv_stage_load16(rx, a, rc, ks, K, tid);
-    } else {
-      stage_load<float>(rw, a.w, K, n0, a.Cout, ks * ROWB, tid);
-      conv_stage_load(rx, a, rc, ks, tid);
+  // weight rows of the tile: 4 x 32 per stage on the 128-wide tile; the narrow tiles stage only their NW rows (threads of the first
+  // NW / 32 quarter passes: thread t copies row (t >> 3) + 32 i)
+  constexpr int WI = NW / 32;
+  u32x4 rw[WI], rx[4];
+  auto load_w = [&](int ks) __attribute__((always_inline)) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      int row = n0 + (tid >> 3) + 32 * i;
+      row = row < a.Cout ? row : a.Cout - 1;                 // clamp: channels past Cout are never stored
+      const char* p = B16 ? reinterpret_cast<const char*>(static_cast<const __bf16*>(a.w16) + (int64_t)row * Kp) : reinterpret_cast<const char*>(a.w + (int64_t)row * K);
+      rw[i] = *reinterpret_cast<const u32x4*>(p + ks * ROWB + c * 16);
     }
   };
+  auto store_w = [&](char* tile) __attribute__((always_inline)) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      char* rowp = tile + ((tid >> 3) + 32 * i) * ROWS;
+      if constexpr (!B16) {                                  // parity planes (tile128::stage_store): even k -> bytes [0,64), odd k -> [64,128)
+        *reinterpret_cast<u32x2*>(rowp + c * 8) = u32x2{rw[i][0], rw[i][2]};
+        *reinterpret_cast<u32x2*>(rowp + 64 + c * 8) = u32x2{rw[i][1], rw[i][3]};
+      } else {
+        *reinterpret_cast<u32x4*>(rowp + c * 16) = rw[i];
+      }
+    }
+  };
+  auto load_stage = [&](int ks) __attribute__((always_inline)) {
+    load_w(ks);
+    if constexpr (B16) conv_stage_load16(rx, a, rc, ks, K, tid);
+    else conv_stage_load(rx, a, rc, ks, tid);
+  };
   load_stage(ks_lo);
-  stage_store<E>(rw, smem, tid);
-  stage_store<E>(rx, smem + TILEB, tid);
+  store_w(smem);
+  stage_store<E>(rx, smem + WTB, tid);
   __syncthreads();
   for (int ks = ks_lo; ks < ks_hi; ++ks) {
-    char* cur = smem + ((ks - ks_lo) & 1) * STAGEB;
-    char* nxt = smem + (((ks - ks_lo) & 1) ^ 1) * STAGEB;
+    char* cur = smem + ((ks - ks_lo) & 1) * STB;
+    char* nxt = smem + (((ks - ks_lo) & 1) ^ 1) * STB;
     const bool more = (ks + 1) < ks_hi;
     if (more) load_stage(ks + 1);
-    stage_mma<E>(acc, cur, cur + TILEB, wn, wm, lane);
+    conv_stage_mma<E, NI, NJ>(acc, cur, cur + WTB, wrow0, xrow0, lane);
     if (more) {
-      stage_store<E>(rw, nxt, tid);
-      stage_store<E>(rx, nxt + TILEB, tid);
+      store_w(nxt);
+      stage_store<E>(rx, nxt + WTB, tid);
     }
     __syncthreads();
   }
@@ -127,14 +198,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int half = lane >> 5;
   if (ksp > 1) {                                         // raw partial sums [split][M][Cout]; conv_reduce_kernel finishes
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+      const int m = m0 + xrow0 + j * 32 + (lane & 31);
       if (m >= M) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+          const int n = n0 + wrow0 + i * 32 + 8 * q + 4 * half;
           if (n >= a.Cout) continue;
           const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
           *reinterpret_cast<f32x4*>(a.partial + ((int64_t)sp * M + m) * a.Cout + n) = v;
@@ -143,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < NJ; ++j) {
+    const int m = m0 + xrow0 + j * 32 + (lane & 31);
     if (m >= M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+        const int n = n0 + wrow0 + i * 32 + 8 * q + 4 * half;
         if (n >= a.Cout) continue;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
         f32x4 v = {acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1], acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]};
@@ -284,7 +355,8 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
   if ((a.in_ld | a.in_off | a.out_ld | a.out_off | a.res_ld | a.res_off) & 3) return fail(EFFOCR_EUNSUPPORTED, "conv2d: channel strides / offsets must be multiples of 4");
   if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
   if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
-  const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  const int nw = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);       // channel tile: narrow layers do not multiply clamped weight rows
+  const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + nw - 1) / nw);
   // few tiles and a long K (the deep layers at small inputs: 4 workgroups looping over 144 stages): split K over up to a round of CUs
   const int nks = a.w16 ? (a.KH * a.KW * a.Cin + 63) / 64 : a.KH * a.KW * a.Cin / 32;
   a.ksplit = 1;
@@ -297,8 +369,15 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
     a.ksplit = (int)sp;
   }
   const dim3 g((unsigned)grid, (unsigned)a.ksplit);
-  if (a.w16) hipLaunchKernelGGL(conv_igemm_kernel<__bf16>, g, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv_igemm_kernel<float>, g, dim3(256), 0, s, a);
+  if (a.w16) {
+    if (nw == 32) hipLaunchKernelGGL((conv_igemm_kernel<__bf16, 32>), g, dim3(256), 0, s, a);
+    else if (nw == 64) hipLaunchKernelGGL((conv_igemm_kernel<__bf16, 64>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<__bf16, 128>), g, dim3(256), 0, s, a);
+  } else {
+    if (nw == 32) hipLaunchKernelGGL((conv_igemm_kernel<float, 32>), g, dim3(256), 0, s, a);
+    else if (nw == 64) hipLaunchKernelGGL((conv_igemm_kernel<float, 64>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<float, 128>), g, dim3(256), 0, s, a);
+  }
   int rc = check_launch("conv2d_nhwc");
   if (rc || a.ksplit == 1) return rc;
   const int64_t items = M * (a.Cout / 4);
