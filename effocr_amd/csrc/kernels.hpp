@@ -182,8 +182,9 @@ int global_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, int l
 // generic im2col for a stem conv with few input channels: x NCHW [B,Cin,H,W] -> col [B*OH*OW][kpad], k = (ky*KW + kx)*Cin + c, zero padded
 int im2col_nchw(const float* x, float* col, int B, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW, int kpad, hipStream_t s);
 // YOLOv5 stem Conv(3, 32, 6, 2, 2) + bias + SiLU straight from NCHW (w: [32][w_ld] rows of (ky*6 + kx)*3 + c taps) -> NHWC channel slice
-int stem6x6s2_nchw(const float* x, const float* w, int w_ld, const float* bias, float* out, int B, int H, int W, int OH, int OW, int out_ld, int out_off,
-                   int silu, hipStream_t s);
+// wt (optional): the same weights transposed to [108 taps][32 channels] — with it, an even W and an 8-byte aligned x the scalar-weight kernel runs
+int stem6x6s2_nchw(const float* x, const float* w, int w_ld, const float* wt, const float* bias, float* out, int B, int H, int W, int OH, int OW, int out_ld,
+                   int out_off, int silu, hipStream_t s);
 int upsample2x_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s);
 int maxpool5_nhwc(const float* in, int in_ld, int in_off, float* out, int out_ld, int out_off, int B, int H, int W, int C, hipStream_t s);
 // Detect head decode of one level: raw [B,ny,nx,raw_ld] (channel a*no + o) -> pred [B,total,no] rows row0 + (a*ny + y)*nx + x

@@ -33,7 +33,7 @@ struct Op {
   int conv;                                              // index into convs
   int level;                                             // OP_DETECT
 };
-struct LConv { std::string w, bn, bias; int cin, cout, cout_pad, k, stride, pad, act; size_t w_off, b_off; int kpad; size_t w16_off; };   // w16: the bf16 copy, rows padded to 64 k
+struct LConv { std::string w, bn, bias; int cin, cout, cout_pad, k, stride, pad, act; size_t w_off, b_off; int kpad; size_t w16_off; size_t wt_off; };   // w16: the bf16 copy, rows padded to 64 k
 
 }  // namespace
 }  // namespace effocr
@@ -167,6 +167,8 @@ void build_yolov5s(effocr_localizer* e) {
     c.w_off = off; off = align_up(off + (size_t)c.cout_pad * K * 4, 256);
     c.b_off = off; off = align_up(off + (size_t)c.cout_pad * 4, 256);
     c.w16_off = off; off = align_up(off + (size_t)c.cout_pad * ((K + 63) / 64 * 64) * 2, 256);
+    c.wt_off = 0;
+    if (c.kpad) { c.wt_off = off; off = align_up(off + (size_t)c.k * c.k * c.cin * c.cout_pad * 4, 256); }   // stem: [tap][channel] transpose (scalar-weight kernel)
   }
   e->wbytes = off;
 }
@@ -196,6 +198,11 @@ void pack_localizer(effocr_localizer* e, std::vector<char>& blob) {
         for (int kx = 0; kx < c.k; ++kx)
           for (int ci = 0; ci < c.cin; ++ci)
             wd[(size_t)co * Kp + (ky * c.k + kx) * c.cin + ci] = (float)((double)w[(((size_t)co * c.cin + ci) * c.k + ky) * c.k + kx] * sc);
+    }
+    if (c.kpad) {
+      float* wt = reinterpret_cast<float*>(blob.data() + c.wt_off);
+      for (int kk = 0; kk < K; ++kk)
+        for (int co = 0; co < c.cout_pad; ++co) wt[(size_t)kk * c.cout_pad + co] = wd[(size_t)co * Kp + kk];
     }
     // bf16 copy of the folded weights (round to nearest even), rows zero-padded to a multiple of 64 k
     const int Kp64 = (Kp + 63) / 64 * 64;
@@ -318,7 +325,8 @@ int effocr_localizer_forward(effocr_localizer_t* loc, const float* x_dev, int ba
         const Buf o = loc->bufs[op.out.buf];
         if (loc->direct_stem && c.k == 6 && c.stride == 2 && c.pad == 2 && c.cin == 3 && c.cout_pad == 32 && c.kpad >= 108) {
           // (fp32 in both precision modes: 108 taps per pixel are VALU work, the operand rounding of the bf16 mode starts at layer 1)
-          if ((rc = stem6x6s2_nchw(x_dev, reinterpret_cast<const float*>(loc->wdev + c.w_off), c.kpad, reinterpret_cast<const float*>(loc->wdev + c.b_off),
+          if ((rc = stem6x6s2_nchw(x_dev, reinterpret_cast<const float*>(loc->wdev + c.w_off), c.kpad, reinterpret_cast<const float*>(loc->wdev + c.wt_off),
+                                   reinterpret_cast<const float*>(loc->wdev + c.b_off),
                                    P(op.out.buf), batch, loc->in_h, loc->in_w, o.H, o.W, o.C, op.out.off, c.act, s))) return rc;
           break;
         }

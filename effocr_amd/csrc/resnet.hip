@@ -18,23 +18,43 @@ namespace {
 
 using namespace tile128;
 
-struct RowCoord { int b, iy0, ix0; };
+// a tile row's output pixel: top-left input coordinate of its window and the element index of (b, iy0, ix0, in_off + 4 c) — the index may
+// lie outside the image (padding); it is only dereferenced for taps inside
+struct RowCoord { int b, iy0, ix0, base; };
+// the K-stage's tap (uniform over the workgroup): stage ks covers input channels ci0 .. ci0 + 32 of tap (ky, kx); advanced incrementally
+// (round 4: the two integer divisions per stage, the 64-bit index arithmetic and the per-row bounds BRANCHES were 1 360 of a stage's 6 500
+// cycles in front of its first MFMA — tools/conv_timeline.py)
+struct TapState { int ky, kx, ci0; };
+__device__ __forceinline__ TapState tap_of_stage(const ConvArgs& a, int ks) {
+  const int kk = ks * 32, tap = kk / a.Cin;
+  TapState t;
+  t.ci0 = kk - tap * a.Cin; t.ky = tap / a.KW; t.kx = tap - t.ky * a.KW;
+  return t;
+}
+__device__ __forceinline__ void tap_advance(TapState& t, const ConvArgs& a) {
+  t.ci0 += 32;
+  const bool wc = t.ci0 >= a.Cin;
+  t.ci0 = wc ? 0 : t.ci0;
+  t.kx += wc ? 1 : 0;
+  const bool wx = t.kx >= a.KW;
+  t.kx = wx ? 0 : t.kx;
+  t.ky += wx ? 1 : 0;
+}
 
-__device__ __forceinline__ void conv_stage_load(u32x4 (&r)[4], const ConvArgs& a, const RowCoord (&rc)[4], int ks, int tid) {
-  const int c = tid & 7;
-  const int kk = ks * 32;
-  const int tap = kk / a.Cin, ci0 = kk - tap * a.Cin;
-  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+// branch-free: a tap outside the image loads the tensor's first 16 bytes and is zeroed (conv_stage_zero, called behind the stage's MFMAs
+// when the data is stored to LDS), so that the whole loop body is ONE basic block and the address arithmetic sits between the MFMAs
+__device__ __forceinline__ void conv_stage_load(u32x4 (&r)[4], int (&ok)[4], const ConvArgs& a, const RowCoord (&rc)[4], const TapState& t) {
+  const int off = (t.ky * a.W + t.kx) * a.in_ld + t.ci0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int iy = rc[i].iy0 + ky, ix = rc[i].ix0 + kx;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-      const float* p = a.in + (((int64_t)rc[i].b * a.H + iy) * a.W + ix) * a.in_ld + a.in_off + ci0 + c * 4;
-      v = *reinterpret_cast<const u32x4*>(p);
-    }
-    r[i] = v;
+    ok[i] = (int)((unsigned)(rc[i].iy0 + t.ky) < (unsigned)a.H) & (int)((unsigned)(rc[i].ix0 + t.kx) < (unsigned)a.W);   // & not &&: no control flow
+    const int idx = ok[i] ? rc[i].base + off : 0;
+    r[i] = *reinterpret_cast<const u32x4*>(a.in + idx);
   }
+}
+__device__ __forceinline__ void conv_stage_zero(u32x4 (&r)[4], const int (&ok)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = ok[i] ? r[i] : u32x4{0u, 0u, 0u, 0u};
 }
 
 // bf16-operand variant of the stage loader: a 128-byte stage row = 64 k values; chunk c (8 values = 16 bytes) is 8 consecutive
@@ -80,6 +100,9 @@ __device__ __forceinline__ void conv_stage_mma(f32x16 (&acc)[NI][NJ], const char
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      // the global loads the caller issued in front of this stage stay inside the first quarter of the MFMA stream (left alone, the
+      // scheduler sinks them towards their use at the end of the stage and exposes their latency); LDS reads may cross the fence
+      if (g == 0) __builtin_amdgcn_sched_barrier(0x100);
     }
   } else {
     typedef typename Op16<TA>::V8 V8;
@@ -98,6 +121,15 @@ __device__ __forceinline__ void conv_stage_mma(f32x16 (&acc)[NI][NJ], const char
   }
 }
 
+// -DCONV_STAMP (tools/ab_build.sh variant, never shipped): the waves of the first 256 workgroups of the 3x3 128 -> 128 layers record
+// s_memtime at their per-stage milestones; tools/conv_timeline.py reads the last such launch's table through effocr_debug_conv_stamps.
+#ifdef CONV_STAMP
+constexpr int CONV_STAMP_WGS = 256, CONV_STAMP_N = 160;
+__device__ unsigned long long conv_stamps[CONV_STAMP_WGS * 4 * CONV_STAMP_N];
+#define CONV_STAMP_AT(k) if (stamp_on && lane == 0 && (k) < CONV_STAMP_N) conv_stamps[((int)blockIdx.x * 4 + w) * CONV_STAMP_N + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONV_STAMP_AT(k)
+#endif
 // E = float: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products).  E = __bf16: operands rounded to bf16 (activations in the
 // stage loader, weights once at upload: a.w16 [Cout][ceil(K/64)*64]) on v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogue.
 // NW = channel tile (round 4): 128 (2 x 2 waves of 64 channels x 64 pixels), 64 (2 x 2 waves of 32 x 64) or 32 (4 waves of 32 x 32, all
@@ -114,6 +146,10 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id(), wn = w >> 1, wm = w & 1;
   const int M = a.B * a.OH * a.OW;
+#ifdef CONV_STAMP
+  const bool stamp_on = NW == 128 && a.KH == 3 && a.Cin == 128 && a.Cout == 128 && a.ksplit <= 1 && blockIdx.x < CONV_STAMP_WGS;
+  CONV_STAMP_AT(0)
+#endif
   const int K = a.KH * a.KW * a.Cin;
   const int ntn = (a.Cout + NW - 1) / NW;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -136,6 +172,7 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
     rc[i].b = t / a.OH;
     rc[i].iy0 = oy * a.stride - a.pad;
     rc[i].ix0 = ox * a.stride - a.pad;
+    rc[i].base = ((rc[i].b * a.H + rc[i].iy0) * a.W + rc[i].ix0) * a.in_ld + a.in_off + (tid & 7) * 4;   // < 2^31 elements: conv2d_nhwc checks
   }
 
   f32x16 acc[NI][NJ];
@@ -150,17 +187,20 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
   // NW / 32 quarter passes: thread t copies row (t >> 3) + 32 i)
   constexpr int WI = NW / 32;
   u32x4 rw[WI], rx[4];
-  auto load_w = [&](int ks) __attribute__((always_inline)) {
-    const int c = tid & 7;
+  unsigned woff[WI];                                         // byte offset of (this thread's weight row i, chunk c) in the weight matrix (< 4 GB)
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      int row = n0 + (tid >> 3) + 32 * i;
-      row = row < a.Cout ? row : a.Cout - 1;                 // clamp: channels past Cout are never stored
-      const char* p = B16 ? reinterpret_cast<const char*>(static_cast<const __bf16*>(a.w16) + (int64_t)row * Kp) : reinterpret_cast<const char*>(a.w + (int64_t)row * K);
-      rw[i] = *reinterpret_cast<const u32x4*>(p + ks * ROWB + c * 16);
-    }
+  for (int i = 0; i < WI; ++i) {
+    int row = n0 + (tid >> 3) + 32 * i;
+    row = row < a.Cout ? row : a.Cout - 1;                   // clamp: channels past Cout are never stored
+    woff[i] = (unsigned)row * (unsigned)(B16 ? Kp * 2 : K * 4) + (tid & 7) * 16;
+  }
+  const char* wbase = B16 ? reinterpret_cast<const char*>(a.w16) : reinterpret_cast<const char*>(a.w);
+  auto load_w = [&](int ks, u32x4 (&rw)[WI]) __attribute__((always_inline)) {
+    const char* wb = wbase + (int64_t)ks * ROWB;             // uniform base + per-thread 32-bit offset
+#pragma unroll
+    for (int i = 0; i < WI; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wb + woff[i]);
   };
-  auto store_w = [&](char* tile) __attribute__((always_inline)) {
+  auto store_w = [&](char* tile, const u32x4 (&rw)[WI]) __attribute__((always_inline)) {
     const int c = tid & 7;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
@@ -173,26 +213,52 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
       }
     }
   };
-  auto load_stage = [&](int ks) __attribute__((always_inline)) {
-    load_w(ks);
+  TapState tap = tap_of_stage(a, ks_lo);
+  int okx[4] = {1, 1, 1, 1};
+  auto load_stage = [&](int ks, u32x4 (&rw)[WI], u32x4 (&rx)[4]) __attribute__((always_inline)) {
+    load_w(ks, rw);
     if constexpr (B16) conv_stage_load16(rx, a, rc, ks, K, tid);
-    else conv_stage_load(rx, a, rc, ks, tid);
+    else conv_stage_load(rx, okx, a, rc, tap);
   };
-  load_stage(ks_lo);
-  store_w(smem);
+  load_stage(ks_lo, rw, rx);
+  if constexpr (!B16) conv_stage_zero(rx, okx);
+  store_w(smem, rw);
   stage_store<E>(rx, smem + WTB, tid);
   __syncthreads();
-  for (int ks = ks_lo; ks < ks_hi; ++ks) {
-    char* cur = smem + ((ks - ks_lo) & 1) * STB;
-    char* nxt = smem + (((ks - ks_lo) & 1) ^ 1) * STB;
-    const bool more = (ks + 1) < ks_hi;
-    if (more) load_stage(ks + 1);
-    conv_stage_mma<E, NI, NJ>(acc, cur, cur + WTB, wrow0, xrow0, lane);
-    if (more) {
-      store_w(nxt);
-      stage_store<E>(rx, nxt + WTB, tid);
+  CONV_STAMP_AT(1)
+  if constexpr (B16) {
+    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+      char* cur = smem + ((ks - ks_lo) & 1) * STB;
+      char* nxt = smem + (((ks - ks_lo) & 1) ^ 1) * STB;
+      const bool more = (ks + 1) < ks_hi;
+      if (more) load_stage(ks + 1, rw, rx);
+      conv_stage_mma<E, NI, NJ>(acc, cur, cur + WTB, wrow0, xrow0, lane);
+      if (more) {
+        store_w(nxt, rw);
+        stage_store<E>(rx, nxt + WTB, tid);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    // One basic block per stage: the next stage's loads are requested inside the first quarter of this stage's MFMAs (fence in
+    // conv_stage_mma), zeroed / stored to the idle buffer behind the last MFMA; the last stage re-loads itself (stored, never read).
+    // (Loads TWO stages ahead with the LDS stores inside the MFMA stream: +32..88 registers, 3.98 vs 3.95 ms per 16-image forward.)
+    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+      char* cur = smem + ((ks - ks_lo) & 1) * STB;
+      char* nxt = smem + (((ks - ks_lo) & 1) ^ 1) * STB;
+      if (ks + 1 < ks_hi) tap_advance(tap, a);
+      load_stage(ks + 1 < ks_hi ? ks + 1 : ks, rw, rx);
+      CONV_STAMP_AT(4 + 4 * (ks - ks_lo))
+      conv_stage_mma<E, NI, NJ>(acc, cur, cur + WTB, wrow0, xrow0, lane);
+      CONV_STAMP_AT(5 + 4 * (ks - ks_lo))
+      __builtin_amdgcn_sched_barrier(0);                  // nothing that consumes the loads moves up into the MFMA stream
+      conv_stage_zero(rx, okx);
+      store_w(nxt, rw);
+      stage_store<E>(rx, nxt + WTB, tid);
+      CONV_STAMP_AT(6 + 4 * (ks - ks_lo))
+      __syncthreads();
+      CONV_STAMP_AT(7 + 4 * (ks - ks_lo))
+    }
   }
 
   const int half = lane >> 5;
@@ -227,7 +293,7 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
         f32x4 v = {acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1], acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]};
         if (a.silu) {                                    // x * sigmoid(x), before the residual (Bottleneck: x + cv2(cv1(x)))
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = silu_fast(v[e]);
         }
         if (a.resid) {
           const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)m * a.res_ld + a.res_off + n);
@@ -241,6 +307,7 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
       }
     }
   }
+  CONV_STAMP_AT(2)
 }
 
 // split-K epilogue: out = act(sum over splits (fixed order) + bias) (+ residual) — one thread per (output pixel, 4 channels)
@@ -255,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int64_t M)
   v += *reinterpret_cast<const f32x4*>(a.bias + n);
   if (a.silu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+    for (int e = 0; e < 4; ++e) v[e] = silu_fast(v[e]);
   }
   if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + m * a.res_ld + a.res_off + n);
   if (a.relu) {
@@ -355,8 +422,11 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
   if ((a.in_ld | a.in_off | a.out_ld | a.out_off | a.res_ld | a.res_off) & 3) return fail(EFFOCR_EUNSUPPORTED, "conv2d: channel strides / offsets must be multiples of 4");
   if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
   if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
-  const int nw = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);       // channel tile: narrow layers do not multiply clamped weight rows
-  const int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + nw - 1) / nw);
+  int nw = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);             // channel tile: narrow layers do not multiply clamped weight rows
+  int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + nw - 1) / nw);
+  // between half a round and one round of 128-channel tiles (16 images: the 40 x 40 maps, 200 tiles on 256 CUs, ONE workgroup per CU with
+  // nothing to run under its barriers): 64-channel tiles instead, two co-resident workgroups on most CUs (3.78 -> 3.72 ms per forward)
+  if (nw == 128 && grid * 2 > device_cus() && grid <= device_cus()) { nw = 64; grid = ((M + BM - 1) / BM) * ((a.Cout + nw - 1) / nw); }
   // few tiles and a long K (the deep layers at small inputs: 4 workgroups looping over 144 stages): split K over up to a round of CUs
   const int nks = a.w16 ? (a.KH * a.KW * a.Cin + 63) / 64 : a.KH * a.KW * a.Cin / 32;
   a.ksplit = 1;
@@ -407,3 +477,11 @@ int global_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, int l
 }
 
 }  // namespace effocr
+
+#ifdef CONV_STAMP
+extern "C" int effocr_debug_conv_stamps(unsigned long long* out, int n) {
+  const int m = effocr::CONV_STAMP_WGS * 4 * effocr::CONV_STAMP_N;
+  if (n < m) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(effocr::conv_stamps), (size_t)m * 8) == hipSuccess ? 0 : -2;
+}
+#endif

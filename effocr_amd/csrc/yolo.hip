@@ -92,7 +92,76 @@ __global__ __launch_bounds__(256) void stem6x6s2_kernel(const float* __restrict_
       f32x4 r = {acc[p][4 * q] + bv[0], acc[p][4 * q + 1] + bv[1], acc[p][4 * q + 2] + bv[2], acc[p][4 * q + 3] + bv[3]};
       if (silu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = r[e] / (1.0f + expf(-r[e]));
+        for (int e = 0; e < 4; ++e) r[e] = silu_fast(r[e]);
+      }
+      *reinterpret_cast<f32x4*>(o + 4 * q) = r;
+    }
+  }
+}
+
+// Round 4: the kernel above is bound by its LDS weight reads (one broadcast ds_read_b128 per 8 FMAs: 272 us per 16 images for 82 us of
+// packed FMAs).  Here a thread owns FOUR horizontally adjacent pixels x 32 channels (128 accumulators; their windows share 8 of 12
+// columns) and the weights never touch LDS: `wt` is the [tap][co] transpose in global memory, its addresses are uniform, so the compiler
+// fetches them with s_load_dwordx16 through the scalar cache (13.8 KB, resident) and feeds them to v_pk_fma_f32 as SGPR pairs.  Inputs
+// as 8-byte pairs (W even: a pair is inside or outside the row as a whole), branch-free.  Same tap order (ky, kx, c) and fmaf chain per
+// output as above: bit-identical.
+__global__ __launch_bounds__(256) void stem6x6s2_sw_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int B, int H, int W, int OH, int OW, int out_ld, int out_off, int silu) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int OW4 = (OW + 3) >> 2;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)B * OH * OW4) return;
+  const int ox = (int)(id % OW4) * 4, oy = (int)((id / OW4) % OH);
+  const int64_t b = id / ((int64_t)OW4 * OH);
+  float acc[4][32];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[p][co] = 0.f;
+  const int ix0 = ox * 2 - 2;
+#pragma unroll 1
+  for (int ky = 0; ky < 6; ++ky) {
+    const int iy = oy * 2 - 2 + ky;
+    const int rowok = (int)(iy >= 0) & (int)(iy < H);
+    float v[3][12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* xr = x + ((b * 3 + c) * H + (rowok ? iy : 0)) * (int64_t)W;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int ix = ix0 + 2 * j;
+        const int ok = rowok & (int)(ix >= 0) & (int)(ix < W);
+        const f32x2 t = *reinterpret_cast<const f32x2*>(xr + (ok ? ix : 0));
+        v[c][2 * j] = ok ? t[0] : 0.f;
+        v[c][2 * j + 1] = ok ? t[1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 6; ++kx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* wr = wt + ((ky * 6 + kx) * 3 + c) * 32;     // uniform address: scalar loads
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[p][4 * q + e] = fmaf(v[c][kx + 2 * p], wv[e], acc[p][4 * q + e]);
+        }
+      }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (ox + p >= OW) break;
+    float* o = out + ((b * OH + oy) * (int64_t)OW + ox + p) * out_ld + out_off;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+      f32x4 r = {acc[p][4 * q] + bv[0], acc[p][4 * q + 1] + bv[1], acc[p][4 * q + 2] + bv[2], acc[p][4 * q + 3] + bv[3]};
+      if (silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = silu_fast(r[e]);
       }
       *reinterpret_cast<f32x4*>(o + 4 * q) = r;
     }
@@ -480,11 +549,16 @@ int im2col_nchw(const float* x, float* col, int B, int Cin, int H, int W, int KH
   return check_launch("im2col_nchw");
 }
 
-int stem6x6s2_nchw(const float* x, const float* w, int w_ld, const float* bias, float* out, int B, int H, int W, int OH, int OW, int out_ld, int out_off,
-                   int silu, hipStream_t s) {
+int stem6x6s2_nchw(const float* x, const float* w, int w_ld, const float* wt, const float* bias, float* out, int B, int H, int W, int OH, int OW, int out_ld,
+                   int out_off, int silu, hipStream_t s) {
   const int64_t total = (int64_t)B * OH * ((OW + 1) / 2);
   if (total <= 0) return EFFOCR_OK;
   if (w_ld < 108 || ((out_ld | out_off) & 3)) return fail(EFFOCR_EINVAL, "stem conv: weight rows of >= 108 taps, channel stride / offset multiples of 4");
+  if (wt && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0) {      // transposed weights + 8-byte input pairs: the scalar-weight kernel
+    const int64_t t4 = (int64_t)B * OH * ((OW + 3) / 4);
+    hipLaunchKernelGGL(stem6x6s2_sw_kernel, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, s, x, wt, bias, out, B, H, W, OH, OW, out_ld, out_off, silu);
+    return check_launch("stem6x6s2_sw");
+  }
   hipLaunchKernelGGL(stem6x6s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, w_ld, bias, out, B, H, W, OH, OW, out_ld, out_off, silu);
   return check_launch("stem6x6s2");
 }
