@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void stem6x6s2_kernel(const float* __restrict_
 // fetches them with s_load_dwordx16 through the scalar cache (13.8 KB, resident) and feeds them to v_pk_fma_f32 as SGPR pairs.  Inputs
 // as 8-byte pairs (W even: a pair is inside or outside the row as a whole), branch-free.  Same tap order (ky, kx, c) and fmaf chain per
 // output as above: bit-identical.
-__global__ __launch_bounds__(256) void stem6x6s2_sw_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void stem6x6s2_sw_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
                                                            float* __restrict__ out, int B, int H, int W, int OH, int OW, int out_ld, int out_off, int silu) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int OW4 = (OW + 3) >> 2;
@@ -119,23 +119,35 @@ __global__ __launch_bounds__(256) void stem6x6s2_sw_kernel(const float* __restri
 #pragma unroll
     for (int co = 0; co < 32; ++co) acc[p][co] = 0.f;
   const int ix0 = ox * 2 - 2;
-#pragma unroll 1
-  for (int ky = 0; ky < 6; ++ky) {
+  // the 18 input pairs of row ky + 1 are requested in front of row ky's 1 152 packed FMAs (requested inside the loop body they were
+  // waited for where they were issued: five exposed round trips per row with two waves per SIMD to cover them)
+  f32x2 raw[3][6];
+  int okm[6], rowok_n;
+  auto request = [&](int ky) __attribute__((always_inline)) {
     const int iy = oy * 2 - 2 + ky;
-    const int rowok = (int)(iy >= 0) & (int)(iy < H);
-    float v[3][12];
+    rowok_n = (int)(iy >= 0) & (int)(iy < H);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = ix0 + 2 * j;
+      okm[j] = rowok_n & (int)(ix >= 0) & (int)(ix < W);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float* xr = x + ((b * 3 + c) * H + (rowok ? iy : 0)) * (int64_t)W;
+      const float* xr = x + ((b * 3 + c) * H + (rowok_n ? iy : 0)) * (int64_t)W;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int ix = ix0 + 2 * j;
-        const int ok = rowok & (int)(ix >= 0) & (int)(ix < W);
-        const f32x2 t = *reinterpret_cast<const f32x2*>(xr + (ok ? ix : 0));
-        v[c][2 * j] = ok ? t[0] : 0.f;
-        v[c][2 * j + 1] = ok ? t[1] : 0.f;
-      }
+      for (int j = 0; j < 6; ++j) raw[c][j] = *reinterpret_cast<const f32x2*>(xr + (okm[j] ? ix0 + 2 * j : 0));
     }
+  };
+  request(0);
+#pragma unroll 1
+  for (int ky = 0; ky < 6; ++ky) {
+    float v[3][12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { v[c][2 * j] = okm[j] ? raw[c][j][0] : 0.f; v[c][2 * j + 1] = okm[j] ? raw[c][j][1] : 0.f; }
+    request(ky < 5 ? ky + 1 : 5);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kx = 0; kx < 6; ++kx)
 #pragma unroll
