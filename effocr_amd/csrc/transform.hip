@@ -148,114 +148,6 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
   }
 }
 
-
-// Round 4: antialiased path, separable INSIDE a workgroup.  The direct kernel above evaluates the width filter of a source row again for every
-// output row that uses it (4x up-scaling: 8 times) with byte loads from global memory — 0.82 ms for the 1 139 crops of a configs[4] call, ten
-// times its 686 MB of stores.  Here a workgroup owns a band of SEP_R output rows of one crop: pass 1 filters the source rows the band needs
-// along x into LDS (hp[row][ox][c] fp32: thread = output column), pass 2 filters along y out of LDS (thread = 4 output pixels of a row).
-// The fmaf chains per output are the direct kernel's (width first, taps ascending; then height), so the results are bit-identical to it.  A band
-// that needs more than SEP_MAXROWS source rows (down-scaling by more than ~1.4) takes the direct evaluation.
-constexpr int SEP_R = 32, SEP_MAXROWS = 24, SEP_S = 224;
-__global__ __launch_bounds__(256) void crop_transform_sep_kernel(CropArgs a) {
-  __shared__ float hp[SEP_MAXROWS * SEP_S * 3];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int S = a.S, S4 = S >> 2;
-  const int r0 = blockIdx.x * SEP_R, r1 = r0 + SEP_R < S ? r0 + SEP_R : S;
-  const int* bx = a.boxes + (size_t)a.box_ld * b;
-  int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
-  const int im = a.box_ld > 4 ? bx[4] : 0;
-  x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
-  x1 = x1 > a.W ? a.W : x1; y1 = y1 > a.H ? a.H : y1;
-  const bool im_ok = im >= 0 && im < a.n_img;
-  const int w = im_ok ? x1 - x0 : 0, h = y1 - y0;
-  float* obase = a.out + (size_t)b * 3 * S * S;
-  if (w <= 0 || h <= 0) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int it = tid; it < (r1 - r0) * S4; it += 256) {
-      const int oy = r0 + it / S4, ox = (it % S4) * 4;
-      for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(obase + (size_t)c * S * S + (size_t)oy * S + ox) = z;
-    }
-    return;
-  }
-  const int L = w > h ? w : h;
-  const float scale = (float)L / (float)S;
-  const uint8_t* base = a.img + (size_t)im * a.img_stride + (size_t)y0 * a.stride + (size_t)x0 * 3;
-  auto px = [&](int y, int x, float (&v)[3]) {
-    if (y < h && x < w) {
-      const uint8_t* sp = base + (size_t)y * a.stride + x * 3;
-      v[0] = (float)sp[0]; v[1] = (float)sp[1]; v[2] = (float)sp[2];
-    } else { v[0] = a.fill[0]; v[1] = a.fill[1]; v[2] = a.fill[2]; }
-  };
-  const Taps tfirst = aa_taps(r0, scale, L), tlast = aa_taps(r1 - 1, scale, L);
-  const int ylo = tfirst.start, yhi = tlast.start + tlast.count;          // window starts / ends ascend with the output row
-  const int nrows = yhi - ylo;
-  const bool sep = nrows <= SEP_MAXROWS;                                 // uniform over the workgroup
-  if (sep) {
-    if (tid < S) {
-      const Taps tx = aa_taps(tid, scale, L);
-      for (int r = 0; r < nrows; ++r) {
-        float row[3] = {0.f, 0.f, 0.f};
-        for (int jx = 0; jx < tx.count; ++jx) {
-          float v[3];
-          px(ylo + r, tx.start + jx, v);
-          const float wx = aa_weight(tx, jx);
-          row[0] = fmaf(wx, v[0], row[0]); row[1] = fmaf(wx, v[1], row[1]); row[2] = fmaf(wx, v[2], row[2]);
-        }
-        float* d = hp + ((size_t)r * S + tid) * 3;
-        d[0] = row[0]; d[1] = row[1]; d[2] = row[2];
-      }
-    }
-    __syncthreads();
-  }
-  for (int it = tid; it < (r1 - r0) * S4; it += 256) {
-    const int oy = r0 + it / S4, ox = (it % S4) * 4;
-    const Taps ty = aa_taps(oy, scale, L);
-    float acc[4][3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc[q][c] = 0.f;
-    if (sep) {
-      for (int jy = 0; jy < ty.count; ++jy) {
-        const float wy = aa_weight(ty, jy);
-        const f32x4* src = reinterpret_cast<const f32x4*>(hp + ((size_t)(ty.start + jy - ylo) * S + ox) * 3);   // 12 floats: 4 pixels x 3 channels
-        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
-        const float rv[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) acc[q][c] = fmaf(wy, rv[q * 3 + c], acc[q][c]);
-      }
-    } else {
-      Taps tx[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) tx[q] = aa_taps(ox + q, scale, L);
-      for (int jy = 0; jy < ty.count; ++jy) {
-        const int y = ty.start + jy;
-        const float wy = aa_weight(ty, jy);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float row[3] = {0.f, 0.f, 0.f};
-          for (int jx = 0; jx < tx[q].count; ++jx) {
-            float v[3];
-            px(y, tx[q].start + jx, v);
-            const float wx = aa_weight(tx[q], jx);
-            row[0] = fmaf(wx, v[0], row[0]); row[1] = fmaf(wx, v[1], row[1]); row[2] = fmaf(wx, v[2], row[2]);
-          }
-          acc[q][0] = fmaf(wy, row[0], acc[q][0]); acc[q][1] = fmaf(wy, row[1], acc[q][1]); acc[q][2] = fmaf(wy, row[2], acc[q][2]);
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      f32x4 r;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r[q] = (acc[q][c] / 255.f - a.mean[c]) / a.std[c];
-      *reinterpret_cast<f32x4*>(obase + (size_t)c * S * S + (size_t)oy * S + ox) = r;
-    }
-  }
-}
-
 }  // namespace
 
 // n_img images of one geometry, img_stride bytes apart; boxes [n, box_ld] int32 (box_ld 4: every box cuts image 0; 5: column 4 =
@@ -272,8 +164,7 @@ int crop_transform(const uint8_t* img, int n_img, int64_t img_stride, int H, int
     a.boxes = boxes + lo * box_ld; a.n = m; a.S = S; a.out = out + lo * 3 * S * S;
     for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = stdv[c]; a.fill[c] = fill[c]; }
     const dim3 grid((unsigned)((S * (S / 4) + 255) / 256), (unsigned)m);
-    if (antialias && S == SEP_S) hipLaunchKernelGGL(crop_transform_sep_kernel, dim3((unsigned)((S + SEP_R - 1) / SEP_R), (unsigned)m), dim3(256), 0, s, a);
-    else if (antialias) hipLaunchKernelGGL(crop_transform_kernel<true>, grid, dim3(256), 0, s, a);
+    if (antialias) hipLaunchKernelGGL(crop_transform_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(crop_transform_kernel<false>, grid, dim3(256), 0, s, a);
     const int rc = check_launch("crop_transform");
     if (rc) return rc;
