@@ -422,6 +422,18 @@ int conv2d_nhwc(const ConvArgs& a_in, hipStream_t s) {
   if ((a.in_ld | a.in_off | a.out_ld | a.out_off | a.res_ld | a.res_off) & 3) return fail(EFFOCR_EUNSUPPORTED, "conv2d: channel strides / offsets must be multiples of 4");
   if (a.Cin % 32 != 0 || a.Cout % 4 != 0) return fail(EFFOCR_EUNSUPPORTED, "conv2d: Cin must be a multiple of 32 and Cout of 4");
   if (M >= ((int64_t)1 << 31) - 256) return fail(EFFOCR_EUNSUPPORTED, "conv2d: too many output pixels");
+  // the stage loader indexes the input with 32-bit element offsets and the weights with 32-bit byte offsets
+  if ((int64_t)a.Cout * (((int64_t)a.KH * a.KW * a.Cin + 63) / 64 * 64) * 4 >= ((int64_t)1 << 32)) return fail(EFFOCR_EUNSUPPORTED, "conv2d: weights of 4 GB or more");
+  if ((int64_t)a.B * a.H * a.W * a.in_ld >= ((int64_t)1 << 31)) {      // halve the batch until a launch's input fits
+    if (a.B < 2) return fail(EFFOCR_EUNSUPPORTED, "conv2d: one image of 2^31 or more input elements");
+    ConvArgs lo = a, hi = a;
+    lo.B = a.B / 2; hi.B = a.B - lo.B;
+    hi.in = a.in + (int64_t)lo.B * a.H * a.W * a.in_ld;
+    hi.out = a.out + (int64_t)lo.B * a.OH * a.OW * a.out_ld;
+    if (a.resid) hi.resid = a.resid + (int64_t)lo.B * a.OH * a.OW * a.res_ld;
+    const int rc = conv2d_nhwc(lo, s);
+    return rc ? rc : conv2d_nhwc(hi, s);
+  }
   int nw = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);             // channel tile: narrow layers do not multiply clamped weight rows
   int64_t grid = ((M + BM - 1) / BM) * ((a.Cout + nw - 1) / nw);
   // between half a round and one round of 128-channel tiles (16 images: the 40 x 40 maps, 200 tiles on 256 CUs, ONE workgroup per CU with

@@ -43,6 +43,24 @@ def test_network_matches_oracle(dev, shape, B):
     assert (alt - got).abs().max().item() < 1e-2 * max(shape)             # two summation orders of the same layer
 
 
+def test_stem_kernels_agree_bit_for_bit(dev):
+    """The stem has two direct kernels: scalar-loaded weights + 8-byte input pairs (4 pixels per thread; taken when the input pointer is
+    8-byte aligned) and the LDS-weight kernel (2 pixels per thread; the fallback).  Same taps in the same fmaf order per output, so an input
+    that starts 4 bytes off an 8-byte boundary — a view into a larger buffer — must give the same bits as the aligned copy."""
+    sd = _busy_state_dict(2, seed=4)
+    shape, B = (96, 160), 2
+    eng = HipLocalizer(sd, input_shape=shape, device=dev)
+    x = torch.rand(B, 3, *shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    buf = torch.empty(x.numel() + 1, dtype=torch.float32, device=dev)
+    off = 1 if buf.data_ptr() % 8 == 0 else 0                            # first element of the view at 4 (mod 8)
+    view = buf[off:off + x.numel()].view_as(x)
+    view.copy_(x)
+    assert view.data_ptr() % 8 == 4 and x.data_ptr() % 8 == 0 and view.is_contiguous()
+    a = eng.forward(x).cpu()
+    b = eng.forward(view).cpu()
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape,B", [((640, 640), 1), ((64, 96), 3)])
 def test_network_bf16_operands(dev, shape, B):
     """precision="bf16": the convolutions with an activation run on bf16-rounded operands (fp32 accumulation, fp32 Detect heads).
