@@ -33,7 +33,8 @@ struct Op {
   int conv;                                              // index into convs
   int level;                                             // OP_DETECT
 };
-struct LConv { std::string w, bn, bias; int cin, cout, cout_pad, k, stride, pad, act; size_t w_off, b_off; int kpad; size_t w16_off; size_t wt_off; };   // w16: the bf16 copy, rows padded to 64 k
+struct LConv { std::string w, bn, bias; int cin, cout, cout_pad, k, stride, pad, act; size_t w_off, b_off; int kpad; size_t w16_off; size_t wt_off;
+               std::string w2, bn2; int cout1 = 0; };   // w2 / bn2: a second Conv block stacked behind the first cout1 output channels (C3's cv1 | cv2 in one launch)   // w16: the bf16 copy, rows padded to 64 k
 
 }  // namespace
 }  // namespace effocr
@@ -80,13 +81,28 @@ struct Builder {
     e->convs.push_back(c);
     e->ops.push_back({OP_CONV, in, out, res, (int)e->convs.size() - 1, 0});
   }
-  // C3(c1 -> c2, n bottlenecks, shortcut): returns nothing, writes `out`
+  // two Conv blocks of the same geometry on the same input in ONE launch: output channels [0, c1) = block `n1`, [c1, out.C) = block `n2`
+  void conv_pair(const std::string& n1, const std::string& n2, View in, View out, int c1, int k, int s) {
+    LConv c; c.w = n1 + ".conv.weight"; c.bn = n1 + ".bn"; c.bias = ""; c.w2 = n2 + ".conv.weight"; c.bn2 = n2 + ".bn"; c.cout1 = c1;
+    c.cin = in.C; c.cout = out.C; c.cout_pad = out.C; c.k = k; c.stride = s; c.pad = k / 2; c.act = 1; c.kpad = 0;
+    for (int h = 0; h < 2; ++h) {
+      const std::string& n = h ? n2 : n1;
+      const int co = h ? out.C - c1 : c1;
+      ladd(e, n + ".conv.weight", {co, in.C, k, k});
+      ladd(e, n + ".bn.weight", {co}); ladd(e, n + ".bn.bias", {co}); ladd(e, n + ".bn.running_mean", {co}); ladd(e, n + ".bn.running_var", {co});
+    }
+    e->convs.push_back(c);
+    e->ops.push_back({OP_CONV, in, out, {-1, 0, 0}, (int)e->convs.size() - 1, 0});
+  }
+  // C3(c1 -> c2, n bottlenecks, shortcut): returns nothing, writes `out`.  cv1 and cv2 (two 1x1 Conv blocks on the same input) run as ONE
+  // convolution of 2 c_ output channels straight into the concat buffer [m(cv1(x)) | cv2(x)] (round 4: the input is read once, half the
+  // launches / prologues, a wider channel tile); the bottleneck chain starts from slice 0 and its last block writes slice 0 back — in
+  // place when n = 1: its 3x3 convolution reads the temporary t, and the residual element is read by the lane that overwrites it.
   void c3(const std::string& name, View in, View out, int n, bool shortcut) {
     const int c_ = out.C / 2, H = e->bufs[in.buf].H, W = e->bufs[in.buf].W;
     const int cat = new_buf(H, W, 2 * c_);
-    View cur = {new_buf(H, W, c_), 0, c_};
-    conv(name + ".cv1", in, cur, 1, 1);
-    conv(name + ".cv2", in, {cat, c_, c_}, 1, 1);
+    conv_pair(name + ".cv1", name + ".cv2", in, whole(cat), c_, 1, 1);
+    View cur = {cat, 0, c_};
     for (int i = 0; i < n; ++i) {
       const std::string m = name + ".m." + std::to_string(i);
       View t = {new_buf(H, W, c_), 0, c_};
@@ -177,7 +193,6 @@ const std::vector<float>& LP(const effocr_localizer* e, const std::string& n) { 
 
 void pack_localizer(effocr_localizer* e, std::vector<char>& blob) {
   for (const LConv& c : e->convs) {
-    const auto& w = LP(e, c.w);
     const int K = c.k * c.k * c.cin, Kp = c.kpad ? c.kpad : K;
     float* wd = reinterpret_cast<float*>(blob.data() + c.w_off);
     float* bd = reinterpret_cast<float*>(blob.data() + c.b_off);
@@ -185,19 +200,23 @@ void pack_localizer(effocr_localizer* e, std::vector<char>& blob) {
       for (int kk = 0; kk < Kp; ++kk) wd[(size_t)co * Kp + kk] = 0.f;
       bd[co] = 0.f;
       if (co >= c.cout) continue;
+      const bool second = !c.w2.empty() && co >= c.cout1;   // stacked pair: rows [cout1, cout) come from the second block
+      const auto& w = LP(e, second ? c.w2 : c.w);
+      const std::string& bn = second ? c.bn2 : c.bn;
+      const int cs = second ? co - c.cout1 : co;            // the row inside its own block
       double sc = 1.0;
-      if (!c.bn.empty()) {                               // BatchNorm2d(eps = 1e-3: ultralytics initialize_weights) folded in
-        const double g = LP(e, c.bn + ".weight")[co], bt = LP(e, c.bn + ".bias")[co], mu = LP(e, c.bn + ".running_mean")[co],
-                     var = LP(e, c.bn + ".running_var")[co];
+      if (!bn.empty()) {                                 // BatchNorm2d(eps = 1e-3: ultralytics initialize_weights) folded in
+        const double g = LP(e, bn + ".weight")[cs], bt = LP(e, bn + ".bias")[cs], mu = LP(e, bn + ".running_mean")[cs],
+                     var = LP(e, bn + ".running_var")[cs];
         sc = g / sqrt(var + 1e-3);
         bd[co] = (float)(bt - mu * sc);
       } else {
-        bd[co] = LP(e, c.bias)[co];
+        bd[co] = LP(e, c.bias)[cs];
       }
       for (int ky = 0; ky < c.k; ++ky)
         for (int kx = 0; kx < c.k; ++kx)
           for (int ci = 0; ci < c.cin; ++ci)
-            wd[(size_t)co * Kp + (ky * c.k + kx) * c.cin + ci] = (float)((double)w[(((size_t)co * c.cin + ci) * c.k + ky) * c.k + kx] * sc);
+            wd[(size_t)co * Kp + (ky * c.k + kx) * c.cin + ci] = (float)((double)w[(((size_t)cs * c.cin + ci) * c.k + ky) * c.k + kx] * sc);
     }
     if (c.kpad) {
       float* wt = reinterpret_cast<float*>(blob.data() + c.wt_off);
