@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
   const int w = wave_id(), wn = w >> 1, wm = w & 1;
   const int M = a.B * a.OH * a.OW;
 #ifdef CONV_STAMP
+#ifdef CONV_STAMP_K1                                        // the 1x1 128 -> 128 layers instead (four K-stages)
+  const bool stamp_on = NW == 128 && a.KH == 1 && a.Cin == 128 && a.Cout == 128 && a.ksplit <= 1 && blockIdx.x < CONV_STAMP_WGS;
+#else
   const bool stamp_on = NW == 128 && a.KH == 3 && a.Cin == 128 && a.Cout == 128 && a.ksplit <= 1 && blockIdx.x < CONV_STAMP_WGS;
+#endif
   CONV_STAMP_AT(0)
 #endif
   const int K = a.KH * a.KW * a.Cin;
