@@ -77,6 +77,7 @@ struct QkvAttnArgs {
   int64_t rows_alloc;               // rows addressable in xn / out (multiple of 32, >= B * T)
   int cls_only;                     // 1: only the attention rows of token tile 0 of every image are needed (last block); a hint — shapes
                                     // without the specialised kernel compute every row
+  int img0;                         // first image of this launch (images img0 .. B - 1; set by the launcher: 0, or the tail images of a batch)
   int hsplit;                       // workgroups per image (each runs heads / hsplit heads): 0 = chosen by the launcher (small batches
                                     // spread over the CUs), 1 = never split, n = at most n
 };

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   // images slot, slot + nslots, ... — every workgroup still holds the image's whole rows (k and v need every token), so a
   // batch of 64 images occupies 192 CUs with 2 heads each instead of 64 CUs with 6.
   const int HS = a.hsplit > 1 ? a.hsplit : 1, NH = HEADS / HS;
-  const int grp = (int)blockIdx.x % HS, slot0 = (int)blockIdx.x / HS, nslots = (int)gridDim.x / HS;
+  const int grp = (int)blockIdx.x % HS, slot0 = a.img0 + (int)blockIdx.x / HS, nslots = (int)gridDim.x / HS;
   const int hb = grp * NH;                               // first head of this workgroup
   const int h0 = ((int)blockIdx.x >> 3) % NH;            // blocks b, b+8, ... share an XCD (and its L2)
   const char* Wb = static_cast<const char*>(a.Wb);
@@ -490,16 +490,31 @@ int launch_qkvattn(const QkvAttnArgs& a, hipStream_t s) {
   // one persistent workgroup per CU (160 KB of LDS each); batches of less than half a round of CUs split every image's heads
   // over hs workgroups (hs = the largest divisor of the head count with B * hs <= CUs; D = 384 only: a head must be at least
   // as long as the ring's prefetch distance)
-  int hs = 1;
-  if (a.hsplit != 1 && a.D == 384) {
-    const int heads = a.D / 64;
+  const int heads = a.D / 64;
+  auto split_for = [&](int64_t images) {                   // largest divisor of the head count with images * hs <= CUs
+    if (a.hsplit == 1 || a.D != 384) return 1;
     for (int c = heads; c >= 2; --c)
-      if (heads % c == 0 && (int64_t)a.B * c <= cus && (a.hsplit <= 0 || c <= a.hsplit)) { hs = c; break; }
+      if (heads % c == 0 && images * c <= cus && (a.hsplit <= 0 || c <= a.hsplit)) return c;
+    return 1;
+  };
+  const int64_t nimg_launch = (int64_t)a.B - a.img0;
+  int hs = split_for(nimg_launch);
+  // A batch of several rounds whose last round fills at most half of the CUs (1 139 crops of a configs[4] call: 4 x 256 + 115) runs that tail
+  // as a SECOND launch with the heads of every tail image split over hs workgroups — 4.55 instead of 5 image times on the critical path.
+  if (a.img0 == 0 && hs == 1 && a.B > cus && a.hsplit != 1) {
+    const int tail = a.B % cus, ths = tail ? split_for(tail) : 1;
+    if (ths > 1) {
+      QkvAttnArgs m = a, t = a;
+      m.B = a.B - tail; m.hsplit = 1;                        // images 0 .. B - tail - 1, whole rounds
+      t.img0 = a.B - tail;                                   // the rest, split
+      const int rc = launch_qkvattn<E>(m, s);
+      return rc ? rc : launch_qkvattn<E>(t, s);
+    }
   }
   QkvAttnArgs ah = a;
   ah.hsplit = hs;
   const QkvAttnArgs& a2 = ah;
-  const dim3 grid((unsigned)(hs > 1 ? a.B * hs : (a.B < cus ? a.B : cus))), blk(256);
+  const dim3 grid((unsigned)(hs > 1 ? nimg_launch * hs : (nimg_launch < cus ? nimg_launch : cus))), blk(256);
   const bool short_tail = a.T <= 32 * ntt - 16;          // the last 16 keys are all padding
   if (a.D == 384 && ntt == 7 && a.cls_only && short_tail) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true, 13>), grid, blk, 0, s, a2);
   else if (a.D == 384 && ntt == 7 && a.cls_only) hipLaunchKernelGGL((qkvattn_kernel<E, 384, 7, true>), grid, blk, 0, s, a2);
