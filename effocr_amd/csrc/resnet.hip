@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
   }
 
   const int half = lane >> 5;
-  if (ksp > 1) {                                         // raw partial sums [split][M][Cout]; conv_reduce_kernel finishes
-#pragma unroll
+  if (ksp > 1) {                                         // raw partial sums [split][M][Cout]; conv_reduce_kernel finishes (direct stores: through
+#pragma unroll                                           // the LDS tile like the epilogue below measured 0.4 % slower — the deep layers' tiles are few)
     for (int j = 0; j < NJ; ++j) {
       const int m = m0 + xrow0 + j * 32 + (lane & 31);
       if (m >= M) continue;
@@ -283,33 +283,50 @@ __global__ __launch_bounds__(256, (NW == 32 ? 3 : 2)) void conv_igemm_kernel(Con
     }
     return;
   }
+  // Epilogue through LDS (round 4).  In the MFMA result layout a lane holds 4 channels of ONE pixel: a `global_store_dwordx4` of the wave is 32
+  // separate 32-byte pieces (230 cycles per instruction on the stamps, 16 of them per lane) and the residual read has the same shape.  The
+  // stage buffers are free behind the last barrier: bias + SiLU in the result layout, tile to LDS as [pixel][NW + 4 channels], then every wave
+  // instruction moves whole pixel rows (NW = 128: two rows of 512 bytes) — residual read, ReLU and the store in that layout.
+  constexpr int TS = NW + 4;                               // floats per pixel row of the transposed tile (odd multiple of 4: conflict-free)
+  static_assert(128 * TS * 4 <= 2 * STB, "conv epilogue: the output tile must fit the stage buffers");
+  float* tile = reinterpret_cast<float*>(smem);
+  const int cmax = a.Cout - 4;                            // Cout % 4 == 0
+  f32x4 bv[NI][4];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int m = m0 + xrow0 + j * 32 + (lane & 31);
-    if (m >= M) continue;
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wrow0 + i * 32 + 8 * q + 4 * half;
+      bv[i][q] = *reinterpret_cast<const f32x4*>(a.bias + (n < cmax ? n : cmax));
+    }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wrow0 + i * 32 + 8 * q + 4 * half;
-        if (n >= a.Cout) continue;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-        f32x4 v = {acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1], acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]};
-        if (a.silu) {                                    // x * sigmoid(x), before the residual (Bottleneck: x + cv2(cv1(x)))
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        v += bv[i][q];
+        if (a.silu) {                           // x * sigmoid(x), before the residual (Bottleneck: x + cv2(cv1(x)))
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = silu_fast(v[e]);
         }
-        if (a.resid) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)m * a.res_ld + a.res_off + n);
-          v += rv;
-        }
-        if (a.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(a.out + (int64_t)m * a.out_ld + a.out_off + n) = v;
+        *reinterpret_cast<f32x4*>(tile + (xrow0 + j * 32 + (lane & 31)) * TS + wrow0 + i * 32 + 8 * q + 4 * half) = v;
       }
+  __syncthreads();
+  constexpr int C4 = NW / 4;                               // 16-byte pieces per pixel row
+#pragma unroll
+  for (int it = 0; it < 128 * C4 / 256; ++it) {
+    const int idx = it * 256 + tid, p = idx / C4, c4 = idx - p * C4;
+    const int m = m0 + p, n = n0 + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(tile + p * TS + c4 * 4);
+    const bool ok = m < M && n < a.Cout;
+    if (a.resid && ok) v += *reinterpret_cast<const f32x4*>(a.resid + (int64_t)m * a.res_ld + a.res_off + n);
+    if (a.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
+    if (ok) *reinterpret_cast<f32x4*>(a.out + (int64_t)m * a.out_ld + a.out_off + n) = v;
   }
   CONV_STAMP_AT(2)
 }
