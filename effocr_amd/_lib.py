@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip
 # Never loaded by the engines on their own; tests that compare those paths switch to it with use_library().
 SO_PATH_AB = os.path.join(_HERE, "libeffocr_hip_ab.so")
 
-ABI_VERSION = 5          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
+ABI_VERSION = 6          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
@@ -35,7 +35,7 @@ def build(force=False, verbose=False, ab=True):
     so = os.path.join(_HERE, "libeffocr_hip.so")
     for extra, target in (([], so),) + (((["AB=1"], SO_PATH_AB),) if ab else ()):
         cmd = ["make", "-C", _CSRC, "-j", str(min(16, os.cpu_count() or 1))] + extra
-        if force:
+        if force and not extra:                                # the AB link reuses the objects the first pass just rebuilt
             cmd.append("-B")
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if verbose or res.returncode != 0:
@@ -54,6 +54,8 @@ def use_library(path=None):
         SO_PATH = path or os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip.so")
         if SO_PATH != prev:
             _lib = _loaded.get(SO_PATH)
+            if _lib is not None:
+                EXPORTS = sorted(_declare(_lib).keys())
     return prev
 
 
@@ -74,7 +76,9 @@ def _declare(lib):
         "effocr_encoder_upload": (i32, [vp, vp, sz]),
         "effocr_encoder_workspace_bytes": (sz, [vp, i32]),
         "effocr_encoder_forward": (i32, [vp, f32p, i32, f32p, i32, vp, sz, vp]),
+        "effocr_encoder_forward_ex": (i32, [vp, vp, i32, i32, f32p, i32, vp, sz, vp]),
         "effocr_encoder_check_status": (i32, [vp, vp, vp]),
+        "effocr_encoder_reset_status": (i32, [vp, vp, vp]),
         "effocr_clock_sample": (i32, [vp, vp]),
         "effocr_encoder_set_chunk": (i32, [vp, i32]),
         "effocr_encoder_set_option": (i32, [vp, c.c_char_p, i32]),
@@ -96,6 +100,8 @@ def _declare(lib):
                                         c.POINTER(c.c_float), f32p, vp]),
         "effocr_crop_transform_batch": (i32, [vp, i32, i64, i32, i32, i64, vp, i64, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),
                                               c.POINTER(c.c_float), f32p, vp]),
+        "effocr_crop_transform_batch_ex": (i32, [vp, i32, i64, i32, i32, i64, vp, i64, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),
+                                                 c.POINTER(c.c_float), i32, vp, vp]),
         "effocr_localizer_create": (i32, [c.c_char_p, i32, i32, i32, c.POINTER(vp)]),
         "effocr_localizer_destroy": (None, [vp]),
         "effocr_localizer_num_params": (i32, [vp]),
@@ -162,9 +168,11 @@ def lib():
     return _lib
 
 
-def check(rc, what=""):
+def check(rc, what="", handle=None):
+    """``handle``: the library the failing call was made through (engines pass the one they were created with — last_error is
+    per shared object, and use_library() may have switched the process default since)."""
     if rc != 0:
-        msg = lib().effocr_last_error()
+        msg = (handle or lib()).effocr_last_error()
         raise EffOCRHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 

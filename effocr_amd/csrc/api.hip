@@ -419,7 +419,7 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
   return w;
 }
 
-int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, char* ws, bool first_chunk, hipStream_t s) {
+int vit_forward(effocr_encoder* e, const void* x, int x16, int B, float* emb, int l2, char* ws, hipStream_t s) {
   const VitWs w = vit_ws(e, B);
   const int D = e->vit.D, T = e->T, Pn = e->P, M = B * T, prec = e->prec;
   const char* wb = e->wdev;
@@ -443,13 +443,15 @@ int vit_forward(effocr_encoder* e, const float* x, int B, float* emb, int l2, ch
   const bool qaf = blk && panel && mlpf && qkv_attn_supported(prec, D, T) && (e->use_qkvattn == 2 || (e->use_qkvattn == 1 && B >= e->qa_min_batch));
   const bool g3 = blk && e->use_gemm3 && gemm3_supported(prec, D, e->vit.mlp);
   const bool patchf = blk && e->use_patchf && patch_embed_fused_supported(prec, D);
-  if (!patchf && (rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, B, e->img, e->img, hb, s); }))) return rc;
+  if (!patchf && (rc = timed(e, "im2col_patch16", 0.0, s, [&] { return im2col_patch16(prec, x, x16, B, e->img, e->img, hb, s); }))) return rc;
+  // the status word is STICKY: forwards only ever OR into it (final_cls_norm), effocr_encoder_check_status reads and clears it — so one
+  // check covers every forward issued with this workspace since the previous check (sub-batches, slices of a large call, async callers)
   int* status = reinterpret_cast<int*>(ws + w.status);
-  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, first_chunk ? status : nullptr, s))) return rc;
+  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, nullptr, s))) return rc;
   GemmArgs g{};
   if (patchf) {                                          // pixels -> tokens in one kernel: the patch rows never exist in HBM
     PatchArgs pa{};
-    pa.x = x; pa.B = B; pa.H = e->img; pa.W = e->img; pa.Wb = wb + e->off_patchw_b; pa.bias = F(e->off_patchb); pa.pos = F(e->off_pos);
+    pa.x = x; pa.x16 = x16; pa.B = B; pa.H = e->img; pa.W = e->img; pa.Wb = wb + e->off_patchw_b; pa.bias = F(e->off_patchb); pa.pos = F(e->off_pos);
     pa.out = xs; pa.D = D; pa.P = Pn;
     if ((rc = timed(e, "patch_embed_fused", 2.0 * B * Pn * Dd * 768.0, s, [&] { return patch_embed_fused(prec, pa, s); }))) return rc;
   } else {
@@ -809,7 +811,16 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk) {
 
 int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev, int l2_normalize,
                            void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return effocr_encoder_forward_ex(enc, x_dev, EFFOCR_PREC_FP32, batch, emb_dev, l2_normalize, workspace_dev, workspace_bytes, stream);
+}
+
+int effocr_encoder_forward_ex(effocr_encoder_t* enc, const void* x_dev, int x_dtype, int batch, float* emb_dev, int l2_normalize,
+                              void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (!enc) return fail(EFFOCR_EINVAL, "forward: NULL encoder");
+  if (x_dtype != PREC_FP32 && !(enc->is_vit && enc->prec != PREC_FP32 && x_dtype == enc->prec))
+    return fail(x_dtype < 0 || x_dtype > 2 ? EFFOCR_EINVAL : EFFOCR_EUNSUPPORTED,
+                "forward: crops must be fp32, or (ViT, 16-bit precision modes) already in the encoder's own operand type");
+  const int x16 = x_dtype != PREC_FP32;
   if (batch < 0) return fail(EFFOCR_EINVAL, "forward: negative batch");
   if (batch == 0) return EFFOCR_OK;
   if (!x_dev || !emb_dev || !workspace_dev) return fail(EFFOCR_EINVAL, "forward: NULL device pointer");
@@ -818,14 +829,14 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
   if ((int64_t)batch * (enc->is_vit ? enc->T : enc->img * enc->img) >= (int64_t)1 << 30)
     return fail(EFFOCR_EUNSUPPORTED, "forward: batch too large for 32-bit row indices");
   char* ws = static_cast<char*>(workspace_dev);
-  if (!enc->is_vit) return resnet_forward(enc, x_dev, batch, emb_dev, l2_normalize, ws, S(stream));
+  if (!enc->is_vit) return resnet_forward(enc, static_cast<const float*>(x_dev), batch, emb_dev, l2_normalize, ws, S(stream));
   // sub-batches: all activations of `chunk` crops (~1.6 MB per ViT-S crop) stay resident in the
   // 256 MiB Infinity Cache between consecutive kernels instead of round-tripping through HBM
   const int chunk = enc->chunk > 0 ? enc->chunk : batch;
-  const size_t img_elems = (size_t)3 * enc->img * enc->img;
+  const size_t img_bytes = (size_t)3 * enc->img * enc->img * (x16 ? 2 : 4);
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int cb = (batch - b0 < chunk) ? batch - b0 : chunk;
-    const int rc = vit_forward(enc, x_dev + (size_t)b0 * img_elems, cb, emb_dev + (size_t)b0 * enc->D, l2_normalize, ws, b0 == 0, S(stream));
+    const int rc = vit_forward(enc, static_cast<const char*>(x_dev) + (size_t)b0 * img_bytes, x16, cb, emb_dev + (size_t)b0 * enc->D, l2_normalize, ws, S(stream));
     if (rc) return rc;
   }
   return EFFOCR_OK;
@@ -840,13 +851,22 @@ int effocr_encoder_check_status(const effocr_encoder_t* enc, const void* workspa
   if (!enc || !workspace_dev) return fail(EFFOCR_EINVAL, "check_status: NULL argument");
   if (!enc->is_vit) return EFFOCR_OK;                     // the CNN path computes in fp32 throughout
   int st = 0;
-  hipError_t er = hipStreamSynchronize(S(stream));
-  if (er == hipSuccess) er = hipMemcpy(&st, workspace_dev, sizeof(int), hipMemcpyDeviceToHost);   // VitWs::status = offset 0
+  // on the caller's stream (not the null stream, which would synchronise with every blocking stream of the process)
+  hipError_t er = hipMemcpyAsync(&st, workspace_dev, sizeof(int), hipMemcpyDeviceToHost, S(stream));   // VitWs::status = offset 0
+  if (er == hipSuccess) er = hipStreamSynchronize(S(stream));
+  if (er == hipSuccess && st != 0) er = hipMemsetAsync(const_cast<void*>(workspace_dev), 0, sizeof(int), S(stream));   // read-and-clear
   if (er != hipSuccess) return fail(EFFOCR_EHIP, std::string("check_status: ") + hipGetErrorString(er));
   if (st != 0)
     return fail(EFFOCR_EOVERFLOW, enc->prec == PREC_FP16
                     ? "forward: non-finite embedding — an f16 operand overflowed (|q|, |k|, |v| or an fc1 pre-activation beyond 65504) or the input was not finite; use precision bf16 or fp32 for this checkpoint"
                     : "forward: non-finite embedding — the input crops or the weights hold inf / nan");
+  return EFFOCR_OK;
+}
+
+int effocr_encoder_reset_status(const effocr_encoder_t* enc, void* workspace_dev, void* stream) {
+  if (!enc || !workspace_dev) return fail(EFFOCR_EINVAL, "reset_status: NULL argument");
+  const hipError_t er = hipMemsetAsync(workspace_dev, 0, 256, S(stream));
+  if (er != hipSuccess) return fail(EFFOCR_EHIP, std::string("reset_status: ") + hipGetErrorString(er));
   return EFFOCR_OK;
 }
 
@@ -933,18 +953,26 @@ int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64
   if (n > 0 && (!image_dev || !boxes_dev || !out_dev || !mean || !stdv || !fill)) return fail(EFFOCR_EINVAL, "crop_transform: NULL pointer");
   for (int c = 0; c < 3 && n > 0; ++c)
     if (!(stdv[c] != 0.f)) return fail(EFFOCR_EINVAL, "crop_transform: std must be non-zero");
-  return crop_transform(image_dev, 1, 0, height, width, row_stride, boxes_dev, 4, n, size, antialias, mean, stdv, fill, out_dev, S(stream));
+  return crop_transform(image_dev, 1, 0, height, width, row_stride, boxes_dev, 4, n, size, antialias, mean, stdv, fill, out_dev, PREC_FP32, S(stream));
 }
 
 int effocr_crop_transform_batch(const uint8_t* images_dev, int n_images, int64_t image_stride, int height, int width, int64_t row_stride,
                                 const int32_t* boxes_dev, int64_t n, int size, int antialias, const float* mean, const float* stdv,
                                 const float* fill, float* out_dev, void* stream) {
+  return effocr_crop_transform_batch_ex(images_dev, n_images, image_stride, height, width, row_stride, boxes_dev, n, size, antialias, mean, stdv,
+                                        fill, EFFOCR_PREC_FP32, out_dev, stream);
+}
+
+int effocr_crop_transform_batch_ex(const uint8_t* images_dev, int n_images, int64_t image_stride, int height, int width, int64_t row_stride,
+                                   const int32_t* boxes_dev, int64_t n, int size, int antialias, const float* mean, const float* stdv,
+                                   const float* fill, int out_dtype, void* out_dev, void* stream) {
+  if (out_dtype < 0 || out_dtype > 2) return fail(EFFOCR_EINVAL, "crop_transform_batch: unknown output type");
   if (n < 0 || n_images <= 0 || height <= 0 || width <= 0 || row_stride < (int64_t)3 * width || image_stride < row_stride * height)
     return fail(EFFOCR_EINVAL, "crop_transform_batch: bad image geometry");
   if (n > 0 && (!images_dev || !boxes_dev || !out_dev || !mean || !stdv || !fill)) return fail(EFFOCR_EINVAL, "crop_transform_batch: NULL pointer");
   for (int c = 0; c < 3 && n > 0; ++c)
     if (!(stdv[c] != 0.f)) return fail(EFFOCR_EINVAL, "crop_transform_batch: std must be non-zero");
-  return crop_transform(images_dev, n_images, image_stride, height, width, row_stride, boxes_dev, 5, n, size, antialias, mean, stdv, fill, out_dev, S(stream));
+  return crop_transform(images_dev, n_images, image_stride, height, width, row_stride, boxes_dev, 5, n, size, antialias, mean, stdv, fill, out_dev, out_dtype, S(stream));
 }
 
 int effocr_gather_rows(const float* src_dev, const int64_t* keep_rows_dev, int64_t n_keep, int d, float* dst_dev, void* stream) {

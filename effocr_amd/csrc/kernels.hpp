@@ -86,7 +86,8 @@ int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s);
 
 // patch.hip — fused im2col + patch-embedding GEMM (+ bias + pos_embed) straight from the NCHW fp32 crops into the blocked residual stream
 struct PatchArgs {
-  const float* x; int B, H, W;      // crops [B,3,H,W] fp32 (H, W multiples of 16)
+  const void* x; int B, H, W;       // crops [B,3,H,W] fp32 — or, with x16, already in the operand type (H, W multiples of 16)
+  int x16;                          // 1: x holds 16-bit values of the kernel's operand type (the crop transform's 16-bit hand-off)
   const void* Wb;                   // patch_embed.proj.weight [D, 768] fragment-blocked (16-bit), k = (c, py, px)
   const float* bias; const float* pos;   // [D]; pos_embed rows [1 + P, D] fp32
   float* out;                       // fp32 residual stream, fragment-blocked: row img * (P + 1) + 1 + p
@@ -124,7 +125,7 @@ int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, co
                            float eps, void* out, hipStream_t s);
 int layernorm_rows(int prec_out, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                    float eps, void* out, hipStream_t s);
-int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s);
+int im2col_patch16(int prec_out, const void* x, int x16, int B, int H, int W, void* out, hipStream_t s);   // x16: x is already 16-bit (prec_out's type)
 int clock_sample(unsigned long long* out, hipStream_t s);
 int set_cls_rows(const float* cls_pos0, float* x, int B, int T, int D, int blocked, int* status_zero, hipStream_t s);
 // rows img*T of x (fp32 blocked) and att (16-bit blocked) -> compact blocked buffers of B rows (last block: class tokens only)
@@ -152,8 +153,9 @@ int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s)
 int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);
 
 // transform.hip — create_paired_transform over a box list (crop, pad to square, /255, bilinear resize, normalise)
+// out_prec: PREC_FP32 (float out) or PREC_BF16 / PREC_FP16 — the fp32 result rounded once (round-to-nearest-even) to that type
 int crop_transform(const uint8_t* img, int n_img, int64_t img_stride, int H, int W, int64_t stride, const int* boxes, int box_ld, int64_t n, int S,
-                   int antialias, const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s);
+                   int antialias, const float* mean, const float* stdv, const float* fill, void* out, int out_prec, hipStream_t s);
 
 // resnet.hip
 struct ConvArgs {

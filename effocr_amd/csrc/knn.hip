@@ -47,10 +47,13 @@ __device__ __forceinline__ bool before(float s1, int i1, float s2, int i2) {
 // (the ds_bpermute form — two LDS-crossbar round trips per step, six steps, once per output — was most of the merge kernels' time).
 // Scores map to order-preserving unsigned keys (-0 folded onto +0 so that key equality is float equality); the winner is the lane with
 // the largest key and, among equal keys, the smallest id: one max-reduction and one min-reduction, 6 DPP steps each, result in lane 63.
+// A NaN score (a non-finite query: e.g. an f16 operand overflow in the encoder) maps to key 0, below every real score AND below the
+// (-FLT_MAX, ID_NONE) sentinel: it can never win a merge, so such a query comes back as (-FLT_MAX, -1) padding, never as a plausible id.
 __device__ __forceinline__ unsigned f32_key(float f) {
   unsigned u = __float_as_uint(f);
   u = (u == 0x80000000u) ? 0u : u;
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  const unsigned key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return (f != f) ? 0u : key;
 }
 __device__ __forceinline__ float key_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 template <bool MAX> __device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
@@ -75,8 +78,12 @@ __device__ __forceinline__ bool wave_best(float s, int i, float& ws, int& wi) {
   const unsigned key = f32_key(s);
   const unsigned kmax = wave_reduce_u32<true>(key);
   const unsigned imin = wave_reduce_u32<false>(key == kmax ? (unsigned)i : 0xffffffffu);
-  ws = key_f32(kmax); wi = (int)imin;
-  return key == kmax && i == wi && wi != ID_NONE;
+  wi = (int)imin;
+  const bool won = key == kmax && i == wi && wi != ID_NONE;
+  // the winner's ORIGINAL score bits (the key folds -0 onto +0: a -0.0 inner product must come out as -0.0, like oracle/flat_ip.c)
+  const unsigned long long m = __ballot(won);
+  ws = m ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(s), (int)__builtin_ctzll(m))) : key_f32(kmax);
+  return won;
 }
 
 // One wave merges `nl` sorted lists resident in LDS (entry t of list l at s[l * stride + t], `len` entries each, (score desc, id asc))
@@ -376,6 +383,7 @@ template <int KMAX>
 void launch_knn_merge(const float* pdist, const int* pidx, int B, int nchunks, int k, float* dist, int64_t* idx, const int* run_flag,
                       int ldo, int ocol, hipStream_t s) {
   const int kk = k < KMAX ? k : KMAX;
+  static_assert((size_t)MAX_CHUNKS * 32 * 8 <= 64 * 1024, "knn_merge: the staged lists must fit the default 64 KB dynamic LDS limit");
   hipLaunchKernelGGL((knn_merge_kernel<KMAX>), dim3((unsigned)B), dim3(64), (size_t)nchunks * kk * 8, s,
                      pdist, pidx, B, nchunks, k, dist, idx, run_flag, ldo, ocol);
 }

@@ -12,13 +12,19 @@
 //   * the weight [D, 768] (fragment-blocked copy) streams through an 8-slot ring of 16 KB LDS stages (4 row blocks x 64 k) by
 //     LDS-DMA, stage order (k slab, output group): a slab's four fragments feed all D / 32 output tiles (12 MFMAs per fragment);
 //   * swapped MFMAs (A = weight rows, B = patches): a lane ends with 4 consecutive features of its patch per register quad ->
-//     bias + pos_embed + 16-byte stores into the blocked residual stream.  D / 2 accumulator registers per lane (192 at D = 384).
+//     bias + pos_embed + 16-byte stores into the blocked residual stream.  DW / 2 accumulator registers per lane (192 at DW = 384).
+// Round 5: (1) embed dims wider than 384 (ViT-B: 768) are cut into DW = 384-wide output slices, one workgroup per (panel, slice), the
+// slices of a panel adjacent in dispatch order so that the second reader of a pixel finds it in the memory-side cache; (2) the crops may
+// arrive ALREADY in the operand type (X = E: effocr_crop_transform_batch_ex's 16-bit hand-off, SURVEY f-2): a lane's 8-k fragment is then
+// ONE 16-byte load and nothing is converted — the values are the ones pack4 would have produced from the fp32 crop, so both input
+// types give bit-identical tokens.
 // Steady-state DMA is issued from inline asm (see mlp_kernel.hpp: the builtin makes hipcc drain the LDS queue after every piece).
 #include "common.hpp"
 #include "kernels.hpp"
 #include <type_traits>
 
-constexpr int PE_SLABS = 2;                              // 64-k pixel slabs in flight per lane (32 registers each; 3 and 4 measured +-0: not what binds)
+constexpr int PE_SLABS = 2;                              // 64-k pixel slabs in flight per lane (32 registers each for fp32 pixels; 3 and 4 measured +-0: not what binds)
+constexpr int PE_SLABS16 = 4;                            // ... for 16-bit pixels (16 registers each)
 #ifndef PATCH_NT
 #define PATCH_NT 1                                        // non-temporal: 1 = pixel loads (read once), 2 = row stores
 #endif
@@ -36,44 +42,52 @@ constexpr int PE_STAGE = 16384;                          // bytes per ring stage
 constexpr int PE_RING = 8;
 constexpr int PE_K = 768;                                // 3 x 16 x 16
 
-template <typename E, int D>
+template <typename E, typename X, int D>                 // D = output width of ONE workgroup (a.D = the embed dim = D x slices)
 __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
   typedef typename Op16<E>::V8 V8;
+  constexpr bool X16 = sizeof(X) == 2;                   // crops already in the operand type
+  constexpr int NSL = X16 ? PE_SLABS16 : PE_SLABS;
   constexpr int KC = PE_K / 8;                           // 16-byte k chunks per weight row
   constexpr int OT = D / 32, OG = OT / 4;                // output tiles / groups of 4 tiles (one ring stage = one group x 64 k)
   constexpr int KS = PE_K / 64;                          // 64-k slabs
   constexpr int NS = KS * OG;                            // ring stages per panel, order (slab, group)
   constexpr int R = PE_RING;
-  static_assert(D % 128 == 0 && D <= 384, "patch_embed: embed dim must be 128, 256 or 384");
+  static_assert(D % 128 == 0 && D <= 384, "patch_embed: a workgroup's output slice must be 128, 256 or 384 wide");
   static_assert(NS >= R - 1, "patch_embed: the panel's stream must be at least as long as the prefetch distance");
   __shared__ __attribute__((aligned(16))) char smem[R * PE_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
   const int64_t total = (int64_t)a.B * a.P;
-  const int64_t m = (int64_t)blockIdx.x * 128 + w * 32 + r31;         // this lane's patch (both half-waves: same patch, other k half)
+  const int nsl = a.D / D;                               // output slices per panel (1, or 2 at D = 768)
+  const int panel = (int)blockIdx.x / nsl, n0 = ((int)blockIdx.x - panel * nsl) * D;   // this workgroup's features n0 .. n0 + D - 1
+  const int64_t m = (int64_t)panel * 128 + w * 32 + r31;              // this lane's patch (both half-waves: same patch, other k half)
   const int64_t mc = m < total ? m : total - 1;                       // patches past the end re-read the last one, never stored
   const int img = (int)(mc / a.P), p = (int)(mc - (int64_t)img * a.P);
   const int PW = a.W / 16, ty = p / PW, tx = p - ty * PW;
   // k16 step kk = (c = kk / 16, py = kk % 16): the lane's 8 pixels at  xp + (c * H + py) * W
-  const float* xp = a.x + ((int64_t)img * 3 * a.H + ty * 16) * a.W + tx * 16 + 8 * half;
+  const X* xp = static_cast<const X*>(a.x) + ((int64_t)img * 3 * a.H + ty * 16) * a.W + tx * 16 + 8 * half;
   const int64_t plane = (int64_t)a.H * a.W;
 
   // ---- pixels of a slab: 4 k16 steps x 2 x 16 bytes per lane, converted to 4 operand fragments when the slab is consumed.
   // Two slabs in flight (static even / odd buffers); requested BEFORE the ring's prologue: they are needed first.
-  struct Slab { f32x4 v[8]; };
+  struct Slab { u32x4 v[X16 ? 4 : 8]; };
   auto load_slab = [&](Slab& sl, int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
       const int kk = ks * 4 + c4;
-      const float* q = xp + (int64_t)(kk >> 4) * plane + (int64_t)(kk & 15) * a.W;
-      sl.v[2 * c4] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q);
-      sl.v[2 * c4 + 1] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4)) : *reinterpret_cast<const f32x4*>(q + 4);
+      const X* q = xp + (int64_t)(kk >> 4) * plane + (int64_t)(kk & 15) * a.W;
+      if constexpr (X16) {
+        sl.v[c4] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q)) : *reinterpret_cast<const u32x4*>(q);
+      } else {
+        sl.v[2 * c4] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q)) : *reinterpret_cast<const u32x4*>(q);
+        sl.v[2 * c4 + 1] = (PATCH_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q + 4)) : *reinterpret_cast<const u32x4*>(q + 4);
+      }
     }
   };
-  // PE_SLABS slabs in flight (static buffers, slab ks lives in buffer ks % PE_SLABS), requested BEFORE the ring's prologue: they are needed first
-  Slab sl[PE_SLABS];
+  // NSL slabs in flight (static buffers, slab ks lives in buffer ks % NSL), requested BEFORE the ring's prologue: they are needed first
+  Slab sl[NSL];
 #pragma unroll
-  for (int i = 0; i < PE_SLABS; ++i) load_slab(sl[i], i);
+  for (int i = 0; i < NSL; ++i) load_slab(sl[i], i);
   asm volatile("" ::: "memory");
 
   // ---- weight ring: stage s = (slab s / OG, group s % OG); wave w copies row block w of the group: 4 pieces of 1 KB
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
   const unsigned lane16 = (unsigned)lane * 16u;
   auto stage_src = [&](int s) __attribute__((always_inline)) -> const char* {
     const int ks = s / OG, g = s - ks * OG;
-    return Wb + ((size_t)(4 * g + w) * KC + 8 * ks) * 512 + lane16;
+    return Wb + ((size_t)(4 * g + w + (n0 >> 5)) * KC + 8 * ks) * 512 + lane16;
   };
   const unsigned sW_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
@@ -111,11 +125,14 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
   auto to_frags = [&](const Slab& sl, V8 (&xf)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
-      const f32x4 lo = sl.v[2 * c4], hi = sl.v[2 * c4 + 1];
-      const u32x2 p0 = pack4<E>(lo[0], lo[1], lo[2], lo[3]);
-      const u32x2 p1 = pack4<E>(hi[0], hi[1], hi[2], hi[3]);
-      const u32x4 q = {p0[0], p0[1], p1[0], p1[1]};
-      xf[c4] = __builtin_bit_cast(V8, q);
+      if constexpr (X16) xf[c4] = __builtin_bit_cast(V8, sl.v[c4]);
+      else {
+        const f32x4 lo = __builtin_bit_cast(f32x4, sl.v[2 * c4]), hi = __builtin_bit_cast(f32x4, sl.v[2 * c4 + 1]);
+        const u32x2 p0 = pack4<E>(lo[0], lo[1], lo[2], lo[3]);
+        const u32x2 p1 = pack4<E>(hi[0], hi[1], hi[2], hi[3]);
+        const u32x4 q = {p0[0], p0[1], p1[0], p1[1]};
+        xf[c4] = __builtin_bit_cast(V8, q);
+      }
     }
   };
 
@@ -145,8 +162,8 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
     const char* st = smem + (S & (R - 1)) * PE_STAGE;
     const char* stn = smem + ((S + 1) & (R - 1)) * PE_STAGE;
     if constexpr (g == 0) {                              // a new slab: its pixels (requested two slabs ago) become fragments
-      to_frags(sl[ks % PE_SLABS], xf);
-      if constexpr (ks + PE_SLABS < KS) load_slab(sl[ks % PE_SLABS], ks + PE_SLABS);
+      to_frags(sl[ks % NSL], xf);
+      if constexpr (ks + NSL < KS) load_slab(sl[ks % NSL], ks + NSL);
     }
     pfor<0, 4>([&](auto C4) {
       constexpr int c4 = decltype(C4)::value;
@@ -172,45 +189,48 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
   // ---- epilogue: registers 4q..4q+3 of tile t = features 32t + 8q + 4half .. +3 of the lane's patch
   if (m < total) {
     const int64_t orow = (int64_t)img * (a.P + 1) + 1 + p;
-    const float* posr = a.pos + (int64_t)(1 + p) * D;
-    char* ob = reinterpret_cast<char*>(a.out);
+    const float* posr = a.pos + (int64_t)(1 + p) * a.D + n0;
+    const float* biasr = a.bias + n0;
+    char* ob = reinterpret_cast<char*>(a.out) + ((orow >> 5) * (a.D >> 2) + (n0 >> 2)) * 512 + (orow & 31) * 16;   // blk_off(orow, n0 / 4 + chunk, a.D / 4) = ob + chunk * 512
     pfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f0 = 32 * t + 8 * q + 4 * half;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + f0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(biasr + f0);
         const f32x4 pv = *reinterpret_cast<const f32x4*>(posr + f0);
         const f32x4 o = {acc[t][4 * q] + bv[0] + pv[0], acc[t][4 * q + 1] + bv[1] + pv[1], acc[t][4 * q + 2] + bv[2] + pv[2],
                          acc[t][4 * q + 3] + bv[3] + pv[3]};
-        if (PATCH_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(ob + blk_off(orow, f0 >> 2, D / 4))); else *reinterpret_cast<f32x4*>(ob + blk_off(orow, f0 >> 2, D / 4)) = o;
+        if (PATCH_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(ob + (f0 >> 2) * 512)); else *reinterpret_cast<f32x4*>(ob + (f0 >> 2) * 512) = o;
       }
     });
   }
 }
 
-template <typename E>
+template <typename E, typename X>
 int launch_patch(const PatchArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.B * a.P;
-  const dim3 grid((unsigned)((total + 127) / 128)), blk(256);
+  const int nsl = a.D > 384 ? a.D / 384 : 1;              // 384-wide output slices of a panel (ViT-B: 2)
+  const dim3 grid((unsigned)((total + 127) / 128 * nsl)), blk(256);
   switch (a.D) {
-    case 128: hipLaunchKernelGGL((patch_embed_kernel<E, 128>), grid, blk, 0, s, a); break;
-    case 256: hipLaunchKernelGGL((patch_embed_kernel<E, 256>), grid, blk, 0, s, a); break;
-    case 384: hipLaunchKernelGGL((patch_embed_kernel<E, 384>), grid, blk, 0, s, a); break;
-    default: return fail(EFFOCR_EUNSUPPORTED, "patch_embed_fused: embed dim must be 128, 256 or 384");
+    case 128: hipLaunchKernelGGL((patch_embed_kernel<E, X, 128>), grid, blk, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((patch_embed_kernel<E, X, 256>), grid, blk, 0, s, a); break;
+    case 384: case 768: hipLaunchKernelGGL((patch_embed_kernel<E, X, 384>), grid, blk, 0, s, a); break;
+    default: return fail(EFFOCR_EUNSUPPORTED, "patch_embed_fused: embed dim must be 128, 256, 384 or 768");
   }
   return check_launch("patch_embed_fused");
 }
 
 }  // namespace
 
-bool patch_embed_fused_supported(int prec, int D) { return (prec == PREC_BF16 || prec == PREC_FP16) && (D == 128 || D == 256 || D == 384); }
+bool patch_embed_fused_supported(int prec, int D) { return (prec == PREC_BF16 || prec == PREC_FP16) && (D == 128 || D == 256 || D == 384 || D == 768); }
 
 int patch_embed_fused(int prec, const PatchArgs& a, hipStream_t s) {
   if (a.B <= 0) return EFFOCR_OK;
-  if (!patch_embed_fused_supported(prec, a.D)) return fail(EFFOCR_EUNSUPPORTED, "patch_embed_fused: needs bf16/fp16 and an embed dim of 128, 256 or 384");
+  if (!patch_embed_fused_supported(prec, a.D)) return fail(EFFOCR_EUNSUPPORTED, "patch_embed_fused: needs bf16/fp16 and an embed dim of 128, 256, 384 or 768");
   if (a.H % 16 || a.W % 16 || a.P != (a.H / 16) * (a.W / 16)) return fail(EFFOCR_EINVAL, "patch_embed_fused: image size must be a multiple of 16");
-  return prec == PREC_BF16 ? launch_patch<__bf16>(a, s) : launch_patch<_Float16>(a, s);
+  if (a.x16) return prec == PREC_BF16 ? launch_patch<__bf16, __bf16>(a, s) : launch_patch<_Float16, _Float16>(a, s);
+  return prec == PREC_BF16 ? launch_patch<__bf16, float>(a, s) : launch_patch<_Float16, float>(a, s);
 }
 
 }  // namespace effocr

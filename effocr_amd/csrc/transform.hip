@@ -9,7 +9,9 @@
 // and evaluates the separable filter straight from the uint8 image (the crop is a few KB: L1/L2 hits),
 // width first, then height, as ATen does (fp32 row intermediate).  The /255 is applied to the filtered
 // value instead of every tap (weights sum to 1; <= 2 ulp from ATen's order).  HBM-write bound:
-// 602 112 B per crop at S = 224.
+// 602 112 B per crop at S = 224 — 301 056 B with the 16-bit hand-off (SURVEY f-2: "-> [B,3,224,224] bf16"): the fp32 value rounded
+// ONCE to the encoder's operand type, which is exactly what the patch embedding does with an fp32 crop before its MFMAs, so the
+// tokens are bit-identical either way and half the bytes cross HBM twice.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -60,11 +62,11 @@ struct CropArgs {
   const uint8_t* img; int H, W; int64_t stride;
   int64_t img_stride; int n_img, box_ld;                 // batch form: box_ld = 5, column 4 = image index, images img_stride bytes apart
   const int* boxes; int n; int S;
-  float* out;
+  void* out;
   float mean[3], std[3], fill[3];
 };
 
-template <bool AA>
+template <bool AA, typename TO>
 __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
   const int b = blockIdx.y;
   const int S = a.S, S4 = S >> 2;
@@ -78,10 +80,14 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
   x1 = x1 > a.W ? a.W : x1; y1 = y1 > a.H ? a.H : y1;
   const bool im_ok = im >= 0 && im < a.n_img;
   const int w = im_ok ? x1 - x0 : 0, h = y1 - y0;
-  float* o = a.out + (size_t)b * 3 * S * S + (size_t)oy * S + ox;
+  TO* o = static_cast<TO*>(a.out) + (size_t)b * 3 * S * S + (size_t)oy * S + ox;
+  auto put4 = [&](int c, const f32x4& r) {                // 4 consecutive pixels of plane c: 16 bytes fp32 / 8 bytes 16-bit (one rounding)
+    if constexpr (sizeof(TO) == 4) *reinterpret_cast<f32x4*>(o + (size_t)c * S * S) = r;
+    else *reinterpret_cast<u32x2*>(o + (size_t)c * S * S) = pack4<TO>(r[0], r[1], r[2], r[3]);
+  };
   if (w <= 0 || h <= 0) {                                 // host rejects empty boxes; never read out of bounds
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(o + (size_t)c * S * S) = z;
+    for (int c = 0; c < 3; ++c) put4(c, z);
     return;
   }
   const int L = w > h ? w : h;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
     f32x4 r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = (acc[q][c] / 255.f - a.mean[c]) / a.std[c];
-    *reinterpret_cast<f32x4*>(o + (size_t)c * S * S) = r;
+    put4(c, r);
   }
 }
 
@@ -153,19 +159,29 @@ __global__ __launch_bounds__(256) void crop_transform_kernel(CropArgs a) {
 // n_img images of one geometry, img_stride bytes apart; boxes [n, box_ld] int32 (box_ld 4: every box cuts image 0; 5: column 4 =
 // image index; a box that names no image yields a zero crop).  Any n: launched in slices of 65535 boxes.
 int crop_transform(const uint8_t* img, int n_img, int64_t img_stride, int H, int W, int64_t stride, const int* boxes, int box_ld, int64_t n, int S,
-                   int antialias, const float* mean, const float* stdv, const float* fill, float* out, hipStream_t s) {
+                   int antialias, const float* mean, const float* stdv, const float* fill, void* out, int out_prec, hipStream_t s) {
   if (n <= 0) return EFFOCR_OK;
+  if (out_prec != PREC_FP32 && out_prec != PREC_BF16 && out_prec != PREC_FP16) return fail(EFFOCR_EINVAL, "crop_transform: unknown output type");
+  const size_t osz = out_prec == PREC_FP32 ? 4 : 2;
   if (S <= 0 || (S & 3)) return fail(EFFOCR_EUNSUPPORTED, "crop_transform: output size must be a positive multiple of 4");
   if (box_ld != 4 && box_ld != 5) return fail(EFFOCR_EINVAL, "crop_transform: boxes must have 4 or 5 columns");
   for (int64_t lo = 0; lo < n; lo += 65535) {
     const int m = (int)(n - lo < 65535 ? n - lo : 65535);
     CropArgs a;
     a.img = img; a.H = H; a.W = W; a.stride = stride; a.img_stride = img_stride; a.n_img = n_img; a.box_ld = box_ld;
-    a.boxes = boxes + lo * box_ld; a.n = m; a.S = S; a.out = out + lo * 3 * S * S;
+    a.boxes = boxes + lo * box_ld; a.n = m; a.S = S; a.out = static_cast<char*>(out) + (size_t)lo * 3 * S * S * osz;
     for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = stdv[c]; a.fill[c] = fill[c]; }
     const dim3 grid((unsigned)((S * (S / 4) + 255) / 256), (unsigned)m);
-    if (antialias) hipLaunchKernelGGL(crop_transform_kernel<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(crop_transform_kernel<false>, grid, dim3(256), 0, s, a);
+    if (out_prec == PREC_FP32) {
+      if (antialias) hipLaunchKernelGGL((crop_transform_kernel<true, float>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((crop_transform_kernel<false, float>), grid, dim3(256), 0, s, a);
+    } else if (out_prec == PREC_BF16) {
+      if (antialias) hipLaunchKernelGGL((crop_transform_kernel<true, __bf16>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((crop_transform_kernel<false, __bf16>), grid, dim3(256), 0, s, a);
+    } else {
+      if (antialias) hipLaunchKernelGGL((crop_transform_kernel<true, _Float16>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((crop_transform_kernel<false, _Float16>), grid, dim3(256), 0, s, a);
+    }
     const int rc = check_launch("crop_transform");
     if (rc) return rc;
   }

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void cls_norm_kernel(const float* __restrict__
 // rows [(img,py,px)][k = c*256 + ky*16 + kx] in the GEMM operand type (k order = the conv weight's
 // own [D,3,16,16] flattening, so the weight needs no permutation).
 // ------------------------------------------------------------------------------------------
-template <typename TO>
-__global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__ x, int B, int H, int W,
+template <typename TO, typename TI = float>               // TI = TO (16-bit): the crops arrive in the operand type already — a plain gather
+__global__ __launch_bounds__(256) void im2col16_kernel(const TI* __restrict__ x, int B, int H, int W,
                                                        TO* __restrict__ out) {
   const int PH = H / 16, PW = W / 16;
   const int64_t total = (int64_t)B * PH * PW * 96;
@@ -181,10 +181,15 @@ __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__
   const int px = (int)(m % PW), py = (int)((m / PW) % PH);
   const int64_t img = m / ((int64_t)PW * PH);
   const int c = k8 >> 5, ky = (k8 & 31) >> 1, kx0 = (k8 & 1) * 8;
-  const float* src = x + ((img * 3 + c) * H + (py * 16 + ky)) * (int64_t)W + px * 16 + kx0;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(src);
-  const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+  const TI* src = x + ((img * 3 + c) * H + (py * 16 + ky)) * (int64_t)W + px * 16 + kx0;
   TO* dst = out + m * 768 + k8 * 8;
+  if constexpr (sizeof(TI) == 2) {
+    static_assert(sizeof(TO) == 2, "im2col16: 16-bit crops feed 16-bit patch rows");
+    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    return;
+  }
+  const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src));
+  const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + 4);
   if constexpr (sizeof(TO) == 4) {
     *reinterpret_cast<f32x4*>(dst) = a;
     *reinterpret_cast<f32x4*>(dst + 4) = b;
@@ -486,11 +491,11 @@ int launch_ln_blocked(const float* x, int64_t rows, int D, const float* gamma, c
   return check_launch("layernorm_blocked");
 }
 
-template <typename TO>
-int launch_im2col(const float* x, int B, int H, int W, TO* out, hipStream_t s) {
+template <typename TO, typename TI = float>
+int launch_im2col(const void* x, int B, int H, int W, TO* out, hipStream_t s) {
   const int64_t total = (int64_t)B * (H / 16) * (W / 16) * 96;
   if (total <= 0) return EFFOCR_OK;
-  hipLaunchKernelGGL((im2col16_kernel<TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, B, H, W, out);
+  hipLaunchKernelGGL((im2col16_kernel<TO, TI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const TI*>(x), B, H, W, out);
   return check_launch("im2col16");
 }
 
@@ -559,8 +564,13 @@ int layernorm_rows_blocked(int prec_out, const float* x, int64_t rows, int D, co
   return fail(EFFOCR_EUNSUPPORTED, "layernorm(blocked): 16-bit output only");
 }
 
-int im2col_patch16(int prec_out, const float* x, int B, int H, int W, void* out, hipStream_t s) {
+int im2col_patch16(int prec_out, const void* x, int x16, int B, int H, int W, void* out, hipStream_t s) {
   if (H % 16 || W % 16) return fail(EFFOCR_EINVAL, "im2col: image size must be a multiple of 16");
+  if (x16) {
+    if (prec_out == PREC_BF16) return launch_im2col<__bf16, __bf16>(x, B, H, W, static_cast<__bf16*>(out), s);
+    if (prec_out == PREC_FP16) return launch_im2col<_Float16, _Float16>(x, B, H, W, static_cast<_Float16*>(out), s);
+    return fail(EFFOCR_EUNSUPPORTED, "im2col: 16-bit crops need a 16-bit precision mode");
+  }
   switch (prec_out) {
     case PREC_BF16: return launch_im2col<__bf16>(x, B, H, W, static_cast<__bf16*>(out), s);
     case PREC_FP16: return launch_im2col<_Float16>(x, B, H, W, static_cast<_Float16*>(out), s);

@@ -62,11 +62,22 @@ def _all_gather_list(out, pad, world, mx, group):
 class ShardedRecognizer:
     """Wraps a per-rank ``neighbors(crops) -> (distances, indices)`` callable (e.g.
     ``effocr_amd.pipeline.Recognizer.neighbors``): every rank passes the SAME full batch (or only
-    its own slice with ``presharded=True``) and gets the full ``[B,k]`` results back."""
+    its own slice with ``presharded=True``) and gets the full ``[B,k]`` results back.
 
-    def __init__(self, neighbors_fn, group=None):
+    ``status_fn`` (optional; derived from a bound ``Recognizer.neighbors``): called on every rank AFTER the gathers — the call's
+    synchronisation point — and raises if this rank's encoder produced a non-finite embedding (f16 operand overflow,
+    EFFOCR_EOVERFLOW); the collectives have completed on every rank by then, so a raising rank leaves no peer waiting."""
+
+    def __init__(self, neighbors_fn, group=None, status_fn=None):
         self.neighbors_fn = neighbors_fn
         self.group = group
+        if status_fn is None:
+            owner = getattr(neighbors_fn, "__self__", None)
+            enc = getattr(owner, "recongizer_encoder", None)
+            if enc is not None:
+                from .pipeline import check_encoder_status
+                status_fn = lambda: check_encoder_status(enc)      # noqa: E731
+        self.status_fn = status_fn
 
     def _rank_world(self):
         if dist.is_available() and dist.is_initialized():
@@ -84,7 +95,10 @@ class ShardedRecognizer:
             lo, hi = shard_bounds(n_total, rank, world)
             local = crops[lo:hi]
         d, i = self.neighbors_fn(local)
-        return all_gather_rows(d, n_total, self.group), all_gather_rows(i, n_total, self.group)
+        out = all_gather_rows(d, n_total, self.group), all_gather_rows(i, n_total, self.group)
+        if self.status_fn is not None:
+            self.status_fn()
+        return out
 
 
 def merge_topk(dists, ids, k):

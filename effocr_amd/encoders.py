@@ -27,6 +27,7 @@ from . import weights as W
 # wherever two glyphs are more than 1e-4 apart in cosine) and stays one keyword away for users who want its 4 % higher rate and
 # fp32's exponent range; "fp32" is the exact parity mode.  bench.py's headline keeps bf16 because BASELINE.json names it.
 DEFAULT_PRECISION = "fp16"
+_CROP_DTYPE = {"fp16": torch.float16, "bf16": torch.bfloat16}
 
 
 class HipEncoder:
@@ -77,14 +78,24 @@ class HipEncoder:
     def workspace_bytes(self, batch):
         return int(self._L.effocr_encoder_workspace_bytes(self._h, int(batch)))
 
+    @property
+    def crop_dtype(self):
+        """Element type a crop producer on the device should hand over (PairedTransform.boxes_batch(dtype=...), SURVEY f-2): the
+        ViT encoders' own 16-bit operand type — the patch embedding rounds fp32 crops to it anyway, so the embeddings are
+        bit-identical and half the bytes move — float32 for the fp32 mode and the CNN."""
+        if self.arch.startswith("vit") and self.precision in _CROP_DTYPE:
+            return _CROP_DTYPE[self.precision]
+        return torch.float32
+
     def forward(self, x, normalize=False):
-        """x: [B,3,H,W] float32 CUDA tensor -> [B,D] float32 CUDA tensor (async on the current stream)."""
+        """x: [B,3,H,W] CUDA tensor, float32 (the reference's type) or ``crop_dtype`` -> [B,D] float32 CUDA tensor (async on the
+        current stream)."""
         if not isinstance(x, torch.Tensor):
             raise TypeError("HipEncoder.forward expects a torch.Tensor")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
             raise ValueError(f"expected input [B,3,{self.img_size},{self.img_size}], got {tuple(x.shape)}")
-        if x.dtype != torch.float32:
-            raise ValueError(f"expected float32 input, got {x.dtype}")
+        if x.dtype != torch.float32 and x.dtype != self.crop_dtype:
+            raise ValueError(f"expected float32 input{'' if self.crop_dtype == torch.float32 else f' (or {self.crop_dtype})'}, got {x.dtype}")
         if x.device != self.device:
             raise ValueError(f"input is on {x.device}, encoder on {self.device}")
         x = x.contiguous()
@@ -99,22 +110,27 @@ class HipEncoder:
             if ws is None or ws.numel() < need:
                 self._ws.pop(key, None)
                 ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws[:256].zero_()                                # the sticky status word starts clean (effocr_encoder_check_status)
                 self._ws[key] = ws
-            _lib.check(self._L.effocr_encoder_forward(self._h, _lib.ptr(x), B, _lib.ptr(emb), 1 if normalize else 0,
-                                                      _lib.ptr(ws), ws.numel(),
-                                                      _lib.current_stream(self.device)), "effocr_encoder_forward")
+            x_dtype = _lib.PREC["fp32"] if x.dtype == torch.float32 else _lib.PREC[self.precision]
+            _lib.check(self._L.effocr_encoder_forward_ex(self._h, _lib.ptr(x), x_dtype, B, _lib.ptr(emb), 1 if normalize else 0,
+                                                         _lib.ptr(ws), ws.numel(),
+                                                         _lib.current_stream(self.device)), "effocr_encoder_forward", self._L)
         return emb
 
     def check_status(self):
-        """Synchronise the current stream and raise EffOCRHipError (EFFOCR_EOVERFLOW) if the last forward issued on it produced a
-        non-finite embedding — how an f16 operand overflow surfaces (include/effocr_hip.h).  Callers that synchronise anyway
-        (EffRecognizer.run, Recognizer.__call__, run_effocr) call it there; a purely asynchronous user calls it when it wants to know."""
+        """Synchronise the current stream and raise EffOCRHipError (EFFOCR_EOVERFLOW) if ANY forward issued on it since the previous
+        check produced a non-finite embedding — how an f16 operand overflow surfaces (include/effocr_hip.h; the status word is
+        sticky and this call clears it).  Callers that synchronise anyway (EffRecognizer.run, Recognizer.__call__, run_effocr,
+        ShardedRecognizer) call it there; a purely asynchronous user (HipEncoder.forward, the AutoEncoder twin, Recognizer.neighbors)
+        calls it when it wants to know, and a non-finite query can never come back from the k-NN with a plausible id in the meantime
+        (knn.hip ranks a NaN score below every real one: ids -1)."""
         with self._lock, torch.cuda.device(self.device):
             ws = self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
             if ws is None:
                 return
             _lib.check(self._L.effocr_encoder_check_status(self._h, _lib.ptr(ws), _lib.current_stream(self.device)),
-                       "effocr_encoder_check_status")
+                       "effocr_encoder_check_status", self._L)
 
     __call__ = forward
 
@@ -209,6 +225,11 @@ def AutoEncoderFactory(backend, modelpath, precision=DEFAULT_PRECISION, img_size
 
         def forward(self, x):
             return self.engine.forward(x, normalize=False)
+
+        def check_status(self):
+            """Raise if any forward since the last check produced a non-finite embedding (HipEncoder.check_status)."""
+            if self._engine is not None:
+                self._engine.check_status()
 
         __call__ = forward
 

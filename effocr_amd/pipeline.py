@@ -195,6 +195,7 @@ def run_recognizer_batches(char_crops, recognizer_engine, knn_func, candidate_ch
         while not output_queue.empty():
             i, result = output_queue.get()
             embeddings[i] = result
+    check_encoder_status(recognizer_engine)                 # EffRecognizer.run already refuses non-finite embeddings; other engines: here
     dev = knn_func.index.device
     embs = [l2_normalize(torch.from_numpy(e[0][0]).to(dev)) for e in embeddings]
     indices = [knn_func(e, k=1)[1] for e in embs]
@@ -373,7 +374,8 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
             y0, y1 = torch.zeros_like(x0), torch.full_like(x0, H)
         boxes5 = torch.stack((x0, y0, x1, y1, line_idx), dim=-1)[sel].to(torch.int32)      # [total,5]; boolean indexing = sync 1
         if boxes5.shape[0]:
-            crops = char_transform.boxes_batch(stack, boxes5)
+            # 16-bit hand-off (SURVEY f-2): the crops are written in the encoder's operand type — same embeddings bit for bit
+            crops = char_transform.boxes_batch(stack, boxes5, dtype=getattr(recognizer_engine, "crop_dtype", torch.float32))
             emb = recognizer_engine.encode_device(crops, normalize=True)
             ids = knn_func(emb, k=1)[1][:, 0]
         else:

@@ -74,10 +74,21 @@ class EffRecognizer:
     def img_size(self):
         return self._eng_net.img_size
 
+    @property
+    def crop_dtype(self):
+        """What a device-side crop producer should hand to ``encode_device`` (HipEncoder.crop_dtype): the encoder's 16-bit operand
+        type for the ViTs in fp16 / bf16 mode, float32 otherwise."""
+        return self._eng_net.crop_dtype
+
+    def check_status(self):
+        self._eng_net.check_status()
+
     def encode_device(self, x, normalize=False, chunk=2048):
         """Device-resident twin of ``run`` for callers whose crops are already in HBM (effocr_amd.pipeline.run_effocr):
-        x [B,3,S,S] float32 on the engine's device -> [B,D] float32 on the device, asynchronous on the current stream.
-        Calls of more than ``chunk`` crops are encoded in slices (bounds the activation workspace: ~1.6 MB per ViT-S crop)."""
+        x [B,3,S,S] float32 (or ``crop_dtype``) on the engine's device -> [B,D] float32 on the device, asynchronous on the current
+        stream.  Calls of more than ``chunk`` crops are encoded in slices (bounds the activation workspace: ~1.6 MB per ViT-S
+        crop); the slices share one workspace and its STICKY status word, so the caller's one check_status() sees an overflow in
+        any of them."""
         if x.shape[0] <= chunk:
             return self._eng_net.forward(x, normalize=normalize)
         return torch.cat([self._eng_net.forward(x[i:i + chunk], normalize=normalize) for i in range(0, x.shape[0], chunk)])

@@ -46,6 +46,9 @@ def slice_boxes(boxes, height, width):
     return np.ascontiguousarray(out.astype(np.int32))
 
 
+_OUT_PREC = {torch.float32: _lib.PREC["fp32"], torch.float16: _lib.PREC["fp16"], torch.bfloat16: _lib.PREC["bf16"]}
+
+
 def _f3(v):
     return (ctypes.c_float * 3)(*[float(x) for x in v])
 
@@ -109,12 +112,17 @@ class PairedTransform:
             # bx is freed by the caching allocator in stream order: safe without a sync
         return out
 
-    def boxes_batch(self, images, boxes5, out=None):
+    def boxes_batch(self, images, boxes5, out=None, dtype=torch.float32):
         """The crops of SEVERAL images of one geometry in one launch (effocr_crop_transform_batch): ``images`` = uint8 device tensor
         [L,H,W,3] (contiguous), ``boxes5`` = int32 device tensor [n,5] = x0,y0,x1,y1,image index, coordinates already resolved the
         way numpy slicing does (``slice_boxes`` semantics).  An EMPTY box gives a zero crop — what the reference's
         ``create_batches`` substitutes for a crop whose transform raised (infer_effocr_onnx_multi.py:145-147,196-200).
-        -> Tensor[n,3,S,S] fp32 on the device, nothing synchronised."""
+        ``dtype``: torch.float32 (the reference's crop type) or torch.float16 / torch.bfloat16 — SURVEY f-2's 16-bit hand-off: the
+        fp32 result rounded once to the encoder's operand type (``HipEncoder.crop_dtype``), which the patch embedding would do
+        itself; same embeddings bit for bit, half the bytes written here and read there.
+        -> Tensor[n,3,S,S] on the device, nothing synchronised."""
+        if dtype not in _OUT_PREC:
+            raise ValueError("dtype must be torch.float32, torch.float16 or torch.bfloat16")
         if images.dim() != 4 or images.shape[3] != 3 or images.dtype != torch.uint8 or not images.is_cuda:
             raise ValueError("images must be a uint8 device tensor [L,H,W,3]")
         if boxes5.dim() != 2 or boxes5.shape[1] != 5 or boxes5.dtype != torch.int32 or boxes5.device != images.device:
@@ -123,15 +131,16 @@ class PairedTransform:
         Lc, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
         n, S, dev = int(boxes5.shape[0]), self.size, images.device
         if out is None:
-            out = torch.empty((n, 3, S, S), dtype=torch.float32, device=dev)
-        elif tuple(out.shape) != (n, 3, S, S) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
-            raise ValueError("out must be a contiguous float32 [n,3,size,size] tensor on the images' device")
+            out = torch.empty((n, 3, S, S), dtype=dtype, device=dev)
+        elif tuple(out.shape) != (n, 3, S, S) or out.dtype != dtype or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"out must be a contiguous {dtype} [n,3,size,size] tensor on the images' device")
         if n == 0:
             return out
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().effocr_crop_transform_batch(_lib.ptr(images), Lc, H * W * 3, H, W, W * 3, _lib.ptr(boxes5), n, S, int(self.antialias),
-                                                              _f3(self.mean), _f3(self.std), _f3(self.fill), _lib.ptr(out),
-                                                              _lib.current_stream(dev)), "crop_transform_batch")
+            _lib.check(_lib.lib().effocr_crop_transform_batch_ex(_lib.ptr(images), Lc, H * W * 3, H, W, W * 3, _lib.ptr(boxes5), n, S,
+                                                                 int(self.antialias), _f3(self.mean), _f3(self.std), _f3(self.fill),
+                                                                 _OUT_PREC[dtype], _lib.ptr(out), _lib.current_stream(dev)),
+                       "crop_transform_batch")
         return out
 
     def __call__(self, crop):

@@ -29,7 +29,7 @@ extern "C" {
 /* bumped whenever an exported signature or the meaning of an argument changes (round 1: 1; round 2 added
  * arguments to effocr_op_mlp_blocked without a bump — callers must treat 1 as "unknown layout"); a caller built
  * against another value must refuse to call into the library (effocr_amd/_lib.py does) */
-#define EFFOCR_ABI_VERSION 5
+#define EFFOCR_ABI_VERSION 6
 
 enum effocr_status {
   EFFOCR_OK = 0,
@@ -85,6 +85,13 @@ size_t effocr_encoder_workspace_bytes(const effocr_encoder_t* enc, int batch);
  * emb_dev: [B,D] fp32.  l2_normalize != 0 fuses F.normalize(p=2,dim=1) (infer_effocr.py:316). */
 int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch, float* emb_dev,
                            int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same with the crops' element type stated (ABI 6; SURVEY §8 f-2's hand-off "uint8 line image + box list -> [B,3,224,224] bf16"):
+ * x_dtype = EFFOCR_PREC_FP32 (x_dev as above) or — ViT encoders in a 16-bit precision mode only — the encoder's OWN operand type
+ * (EFFOCR_PREC_BF16 / EFFOCR_PREC_FP16: x_dev holds [B,3,img,img] 16-bit values, what effocr_crop_transform_batch_ex writes).  The patch
+ * embedding rounds an fp32 crop to that type before its MFMAs anyway, so a crop that was rounded once by the producer yields
+ * BIT-IDENTICAL embeddings at half the input bytes.  Any other combination: EFFOCR_EUNSUPPORTED. */
+int effocr_encoder_forward_ex(effocr_encoder_t* enc, const void* x_dev, int x_dtype, int batch, float* emb_dev,
+                              int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Measurement aid (bench.py): one tiny kernel on `stream` that stores { s_memtime (shader-clock ticks), s_memrealtime (100 MHz) } into
  * out_dev[0..1] (uint64).  Two samples bracket an interval: d(memtime) / d(memrealtime) x 100 MHz = the average shader clock under
@@ -92,14 +99,19 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
  * under saturated MFMA load with random operands. */
 int effocr_clock_sample(void* out_dev, void* stream);
 
-/* Status of the LAST forward issued with this workspace on `stream` (ViT; the CNN path is fp32 throughout and always reports OK):
- * synchronises the stream, reads the int32 status word the forward keeps at workspace offset 0 (zeroed by its first kernel, OR-ed by
- * its last) and returns EFFOCR_EOVERFLOW if an embedding came out non-finite.  In f16 mode that is how operand overflow surfaces:
+/* Status of EVERY forward issued with this workspace since the previous check (ViT; the CNN path is fp32 throughout and always
+ * reports OK): the forward keeps an int32 status word at workspace offset 0 and only ever ORs into it (its last kernel); this call
+ * copies it on `stream`, synchronises the stream, CLEARS it if it was set and returns EFFOCR_EOVERFLOW if an embedding came out
+ * non-finite — one check covers the slices of a large call, internal sub-batches and any number of asynchronous forwards (ABI 6;
+ * up to ABI 5 the first kernel of each forward zeroed the word, so only the last forward was visible).  The caller zeroes the first
+ * 256 bytes of a freshly allocated workspace once (effocr_encoder_reset_status, or a memset).  In f16 mode that is how operand overflow surfaces:
  * q / k / v and the fc1 pre-activations are rounded to f16 (max 65504), an overflow becomes inf, and an inf anywhere in a block turns
  * the LayerNorm / softmax of every row it feeds into nan — it cannot stay hidden in a finite embedding.  (The reference computes in
  * fp32, infer_effocr.py:314-316; precision "bf16" / "fp32" have fp32's exponent range.)  Not on the hot path: call it where the
  * caller synchronises anyway. */
 int effocr_encoder_check_status(const effocr_encoder_t* enc, const void* workspace_dev, void* stream);
+/* zero the status word of a (freshly allocated) workspace, asynchronously on `stream` */
+int effocr_encoder_reset_status(const effocr_encoder_t* enc, void* workspace_dev, void* stream);
 
 /* ViT only: run the forward in internal sub-batches of `crops_per_chunk` crops (0 = whole batch) so
  * that the activations between consecutive kernels stay in the 256 MiB Infinity Cache.  Results
@@ -123,7 +135,7 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *                 that the CUs do not request / store their rows all at the same moment (0 = off)
  *   "mlp_stagger_min_rounds" [2] ... for launches of at least this many rounds of CUs (512-crop calls: +7.7 %; no effect below two)
  *   "use_projf"   [1] attn.proj + residual fused in front of the fused MLP kernel (0: its own row-panel launch)
- *   "use_patchf"  [1] fused im2col + patch-embedding GEMM (ViT-S / 128-wide); 0: im2col kernel + DMA-ring GEMM
+ *   "use_patchf"  [1] fused im2col + patch-embedding GEMM (embed dims 128 / 256 / 384 / 768); 0: im2col kernel + DMA-ring GEMM
  *   "qa_min_batch" [1] fused qkv + attention kernel from this many crops per call on (below: row-panel qkv + attention kernels)
  *   "qa_hsplit"   [0] fused qkv + attention: workgroups per image (heads split over them); 0 = launcher's choice (calls of less
  *                 than a round of CUs split), 1 = never, n = at most n
@@ -214,6 +226,12 @@ int effocr_crop_transform(const uint8_t* image_dev, int height, int width, int64
 int effocr_crop_transform_batch(const uint8_t* images_dev, int n_images, int64_t image_stride, int height, int width,
                                 int64_t row_stride, const int32_t* boxes_dev, int64_t n, int size, int antialias,
                                 const float* mean, const float* std, const float* fill, float* out_dev, void* stream);
+/* ... with the output element type stated (ABI 6): out_dtype = EFFOCR_PREC_FP32 (as above) or EFFOCR_PREC_BF16 / EFFOCR_PREC_FP16 —
+ * out_dev [n,3,size,size] 16-bit, each value the fp32 result rounded ONCE (round to nearest even) to that type: the encoder's input
+ * for effocr_encoder_forward_ex (half the bytes written here and read there; same embeddings bit for bit). */
+int effocr_crop_transform_batch_ex(const uint8_t* images_dev, int n_images, int64_t image_stride, int height, int width,
+                                   int64_t row_stride, const int32_t* boxes_dev, int64_t n, int size, int antialias,
+                                   const float* mean, const float* std, const float* fill, int out_dtype, void* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Localizer engine: the YOLOv5 character / word detector the reference runs through ONNXRuntime

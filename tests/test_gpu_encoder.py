@@ -16,7 +16,8 @@ from oracle.encoders_ref import encoder_forward, l2_normalize
 
 pytestmark = pytest.mark.gpu
 
-REL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 1e-2}   # measured: 1e-6 / 5e-4 / 4.7e-3
+REL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 8e-3}   # the DEFAULT dispatch against oracle A; measured: 1e-6 / 5e-4 ... 8.5e-4 / 4.7 ... 7.6e-3 (max norm over a few crops: sample dependent)
+REL_AB = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 1e-2}   # non-default A/B paths and path-vs-path differences (ViT-B with LayerNorm launches: 8.8e-3)
 
 
 def rel_err(got, ref):
@@ -97,13 +98,13 @@ def test_vit_base_folded_layernorm(dev, prec):
     plain = enc.forward(x.to(dev), normalize=True).cpu()
     e1, e0 = rel_err(fold, ref), rel_err(plain, ref)
     print(f"vit_base {prec}: folded LayerNorm {e1:.3e}, LayerNorm launches {e0:.3e}")
-    assert e1 <= REL[prec] and e0 <= REL[prec]
+    assert e1 <= REL[prec] and e0 <= REL_AB[prec]
     assert not torch.equal(fold, plain)                  # the switch really selects another path
     xb = torch.randn(300, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(9), device=dev)
     big0 = enc.forward(xb, normalize=True)
     enc.set_option("use_lnfold", 1)
     big1 = enc.forward(xb, normalize=True)
-    assert torch.isfinite(big1).all() and rel_err(big1.cpu(), big0.cpu()) <= REL[prec]
+    assert torch.isfinite(big1).all() and rel_err(big1.cpu(), big0.cpu()) <= REL_AB[prec]
     assert rel_err(big1[:9].cpu(), enc.forward(xb[:9].contiguous(), normalize=True).cpu()) <= REL[prec]
     enc.set_option("cls_only_last", 0)                   # every token through the last block: the same embedding
     assert rel_err(enc.forward(xb[:9].contiguous(), normalize=True).cpu(), big1[:9].cpu()) <= REL[prec]
@@ -148,14 +149,14 @@ def test_panel_and_streaming_paths_agree(dev, ab_lib):
     a = enc.forward(x.to(dev)).cpu()
     enc.set_option("use_blocked", 0)             # row-major activations instead of fragment-blocked cells
     r = enc.forward(x.to(dev)).cpu()
-    assert rel_err(a, r) <= REL["bf16"]          # same arithmetic, but the fused LayerNorm sums in a different lane order -> bf16 roundings flip
+    assert rel_err(a, r) <= REL_AB["bf16"]          # same arithmetic, but the fused LayerNorm sums in a different lane order -> bf16 roundings flip
     enc.set_option("use_blocked", 1)
     enc.set_option("panel_rows", 64)             # 64-row panels, two workgroups per CU
     c = enc.forward(x.to(dev)).cpu()
     enc.set_option("use_panel", 0)
     b = enc.forward(x.to(dev)).cpu()
-    assert rel_err(a, ref) <= REL["bf16"] and rel_err(b, ref) <= REL["bf16"] and rel_err(c, ref) <= REL["bf16"]
-    assert rel_err(a, b) <= REL["bf16"]
+    assert rel_err(a, ref) <= REL_AB["bf16"] and rel_err(b, ref) <= REL_AB["bf16"] and rel_err(c, ref) <= REL_AB["bf16"]
+    assert rel_err(a, b) <= REL_AB["bf16"]
     assert torch.equal(a, c)                     # same arithmetic, same summation order -> bit-identical
 
 
@@ -204,7 +205,7 @@ def test_every_switchable_path_matches_the_oracle(dev, ab_lib, B):
                                    "use_patchf": 1, "qa_hsplit": 0, "qa_min_batch": 1}[k])
         assert torch.equal(outs["default"], enc.forward(x.to(dev)).cpu())          # switches restored, run-to-run bitwise
         for name, o in outs.items():
-            assert rel_err(o, ref) <= REL[prec], (name, prec, B, rel_err(o, ref))
+            assert rel_err(o, ref) <= REL_AB[prec], (name, prec, B, rel_err(o, ref))
 
 
 def test_fused_attention_default_dispatch_and_full_batch(dev, ab_lib):
@@ -222,7 +223,7 @@ def test_fused_attention_default_dispatch_and_full_batch(dev, ab_lib):
         enc.set_option("use_qkvattn", 0)
         e0 = enc.forward(x)
         assert not torch.equal(e0, e1)                       # really two different kernel sequences
-        assert rel_err(e1.cpu(), e0.cpu()) <= REL[prec]
+        assert rel_err(e1.cpu(), e0.cpu()) <= REL_AB[prec]
         sel = [0, 150, 299]
         ref = encoder_forward(arch, sd, x[sel].cpu())
         assert rel_err(e1[sel].cpu(), ref) <= REL[prec] and rel_err(e0[sel].cpu(), ref) <= REL[prec]
@@ -283,6 +284,14 @@ def test_embedding_does_not_depend_on_the_call_size(dev, prec):
     same = (idx.search_device(big[:64], 1)[1] == idx.search_device(mid, 1)[1]).float().mean().item()
     print(f"  top-1 against 2000 random rows identical for {100 * same:.1f} % of the crops")
     assert same == 1.0 if prec == "fp32" else same >= 0.9           # random rows: margins of ~1e-2; real glyph margins are wider
+    # ... and with a PLANTED neighbour per crop (the glyph index of a trained recognizer holds a render of every character: the
+    # right row scores ~1, everything else ~0.1) the transcription cannot depend on the call size: every crop finds its own row
+    planted = IndexFlatIP(384, device=dev)
+    planted.add(torch.cat([torch.nn.functional.normalize(torch.randn(2000, 384, generator=torch.Generator().manual_seed(1)), dim=1),
+                           small.cpu(), big[6:64].cpu()]))
+    want = torch.arange(2000, 2064, device=dev)
+    for emb in (big[:64], mid):
+        assert torch.equal(planted.search_device(emb, 1)[1][:, 0], want)
 
 
 def test_resnet_and_localizer_do_not_depend_on_the_call_size(dev):
@@ -367,7 +376,83 @@ def test_f16_overflow_is_reported_not_hidden(dev):
     ok = HipEncoder(arch, sd, img_size=img, precision="bf16", device=dev)
     assert torch.isfinite(ok.forward(x.to(dev), normalize=True)).all()
     ok.check_status()
-    # the flag is per forward: a clean call on the same engine clears it
     good = HipEncoder(arch, init_state_dict(arch, seed=5, img_size=img), img_size=img, precision="fp16", device=dev)
     good.forward(x.to(dev))
     good.check_status()
+
+
+def test_status_word_is_sticky_until_checked(dev):
+    """ABI 6: the status word is only ever OR-ed by a forward and cleared by check_status — an overflow in an EARLIER forward on the
+    same workspace (a slice of EffRecognizer.encode_device, an asynchronous HipEncoder.forward, a sub-batch) is still reported after
+    later clean forwards, exactly once; and a non-finite query comes back from the k-NN as (-FLT_MAX, -1) padding, never as a real id."""
+    from effocr_amd import _lib
+    from effocr_amd.encoders import HipEncoder
+    from effocr_amd.knn import IndexFlatIP
+    from effocr_amd.recognizer_engine import EffRecognizer
+    arch, img = "vit_tiny_test", 64
+    sd = init_state_dict(arch, seed=5, img_size=img)
+    g = torch.Generator().manual_seed(6)
+    clean = torch.randn(9, 3, img, img, generator=g).to(dev)
+    bad = clean.clone()
+    bad[4, 1, 7, 9] = float("inf")                           # the status word reports ANY non-finite embedding: here a non-finite crop
+    enc = HipEncoder(arch, sd, img_size=img, precision="fp16", device=dev)
+    e_bad = enc.forward(bad, normalize=True)
+    e_ok = enc.forward(clean, normalize=True)                # a later, clean forward on the same workspace
+    assert torch.isfinite(e_ok).all() and not torch.isfinite(e_bad).all()
+    with pytest.raises(_lib.EffOCRHipError, match="code -6"):
+        enc.check_status()
+    enc.check_status()                                       # read-and-clear: reported once
+    enc.forward(clean)
+    enc.check_status()
+    # encode_device in slices: the overflow sits in the FIRST slice, the last slice is clean
+    rec = EffRecognizer(sd, arch=arch, precision="fp16", img_size=img, device=dev)
+    rec.encode_device(torch.cat([bad, clean]), normalize=True, chunk=9)
+    with pytest.raises(_lib.EffOCRHipError, match="overflow"):
+        rec.check_status()
+    # a NaN query never yields a plausible neighbour
+    index = IndexFlatIP(128)
+    index.add(torch.nn.functional.normalize(torch.randn(300, 128, generator=g), dim=1))
+    q = torch.nn.functional.normalize(torch.randn(4, 128, generator=g), dim=1).to(dev)
+    q[1] = float("nan")
+    d, i = index.search_device(q, 5)
+    assert (i[1] == -1).all() and (i[[0, 2, 3]] >= 0).all()
+
+
+@pytest.mark.parametrize("arch,img,B", [("vit_small_patch16_224", 224, 70), ("vit_base_patch16_224", 224, 5), ("vit_tiny_test", 64, 37)])
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_16bit_crops_give_bit_identical_embeddings(dev, arch, img, B, prec):
+    """SURVEY f-2's hand-off: crops already in the encoder's operand type (effocr_encoder_forward_ex) — the patch embedding rounds an
+    fp32 crop to that type before its MFMAs, so a crop rounded once by its producer gives the SAME embedding bit for bit, on the fused
+    patch-embedding kernel (default; D = 768 in two 384-wide output slices) and on the im2col + GEMM path."""
+    from effocr_amd.encoders import HipEncoder
+    sd = init_state_dict(arch, seed=11, img_size=img)
+    x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(12)).to(dev)
+    enc = HipEncoder(arch, sd, img_size=img, precision=prec, device=dev)
+    assert enc.crop_dtype == (torch.float16 if prec == "fp16" else torch.bfloat16)
+    for patchf in (1, 0):
+        enc.set_option("use_patchf", patchf)
+        a = enc.forward(x, normalize=True)
+        b = enc.forward(x.to(enc.crop_dtype), normalize=True)
+        assert torch.equal(a, b), f"use_patchf={patchf}"
+    with pytest.raises(ValueError):
+        enc.forward(x.to(torch.bfloat16 if prec == "fp16" else torch.float16))
+    with pytest.raises(ValueError):
+        HipEncoder(arch, sd, img_size=img, precision="fp32", device=dev).forward(x.half())
+
+
+def test_vit_base_fused_patch_embedding_matches_the_unfused_pair(dev):
+    """ViT-B's patch embedding on patch.hip (two 384-wide output slices per 128-patch panel) against the im2col + gemm2 pair it
+    replaces and against oracle A: same operands, same fp32 accumulation up to summation order."""
+    from effocr_amd.encoders import HipEncoder
+    arch, img, B = "vit_base_patch16_224", 224, 3
+    sd = init_state_dict(arch, seed=2, img_size=img)
+    x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(3))
+    ref = encoder_forward(arch, sd, x)
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    for prec in ("fp16", "bf16"):
+        enc = HipEncoder(arch, sd, img_size=img, precision=prec, device=dev)
+        fused = enc.forward(x.to(dev), normalize=True).cpu()
+        enc.set_option("use_patchf", 0)
+        pair = enc.forward(x.to(dev), normalize=True).cpu()
+        assert rel_err(fused, ref) <= REL[prec] and rel_err(pair, ref) <= REL_AB[prec]
+        assert rel_err(fused, pair) <= 2e-3 * (8 if prec == "bf16" else 1)

@@ -13,7 +13,7 @@ from oracle.encoders_ref import encoder_forward, l2_normalize
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
-REL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 1e-2}
+REL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 8e-3}   # default dispatch, measured 4.7 ... 7.6e-3 (bf16)
 
 
 def load(name):

@@ -189,3 +189,31 @@ def test_device_transform_matches_committed_golden(dev):
         got = PairedTransform(size=size, device=dev, antialias=aa).boxes(img, boxes, already_int=True).cpu().numpy()
         assert got.shape == g[key].shape
         np.testing.assert_allclose(got, g[key], atol=3e-5 if aa else 2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_16bit_hand_off_is_the_rounded_fp32_result(dev, dtype):
+    """SURVEY f-2 ("uint8 line image + box list -> [B,3,224,224] bf16"): effocr_crop_transform_batch_ex with a 16-bit output type writes
+    exactly the fp32 result rounded once (round to nearest even) — bit for bit torch's own cast of the fp32 kernel's output — for
+    both resize flavours, including the zero crop of an empty box; and against the committed golden vectors within the rounding."""
+    import os
+    from effocr_amd.transforms import PairedTransform, slice_boxes
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crop_transform.npz"))
+    img, size = g["image"], int(g["size"])
+    H, W = img.shape[:2]
+    ib = slice_boxes([tuple(int(v) for v in b) for b in g["boxes"]], H, W)
+    boxes5 = np.concatenate([ib, np.zeros((len(ib), 1), np.int32)], 1)
+    boxes5 = np.concatenate([boxes5, np.array([[5, 5, 5, 9, 0], [0, 0, 10, 10, 3]], np.int32)])      # an empty box, a box naming no image
+    stack = torch.from_numpy(np.ascontiguousarray(img))[None].to(dev)
+    b5 = torch.from_numpy(boxes5).to(dev)
+    for aa, key in ((True, "out_aa"), (False, "out_plain")):
+        tf = PairedTransform(size=size, device=dev, antialias=aa)
+        f32 = tf.boxes_batch(stack, b5)
+        h16 = tf.boxes_batch(stack, b5, dtype=dtype)
+        assert h16.dtype == dtype and h16.shape == f32.shape
+        assert torch.equal(h16, f32.to(dtype))                                   # 0 ulp from the rounded fp32 result
+        assert (h16[-2:] == 0).all()
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)                     # half an ulp at magnitude <= 4, plus the fp32 kernel's own bound
+        np.testing.assert_allclose(h16[:len(ib)].float().cpu().numpy(), g[key], atol=(3e-5 if aa else 2e-4) + 2 * ulp)
+    with pytest.raises(ValueError):
+        tf.boxes_batch(stack, b5, dtype=torch.float64)
