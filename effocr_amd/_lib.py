@@ -94,6 +94,9 @@ def _declare(lib):
         "effocr_knn_screen_flag_offset": (sz, [i64, i64, i32, i32]),
         "effocr_knn_ip_topk_screened": (i32, [f32p, i64, f32p, vp, i64, i32, i32, c.c_float, f32p, i64p, vp, sz, vp]),
         "effocr_convert_bf16": (i32, [f32p, i64, vp, vp]),
+        "effocr_bf16_blocked_bytes": (sz, [i64, i32]),
+        "effocr_convert_bf16_blocked": (i32, [f32p, i64, i32, vp, vp]),
+        "effocr_knn_ip_topk_screened2": (i32, [f32p, i64, f32p, vp, vp, i64, i32, i32, c.c_float, f32p, i64p, vp, sz, vp]),
         "effocr_l2_normalize": (i32, [f32p, i64, i32, f32p, vp]),
         "effocr_gather_rows": (i32, [f32p, i64p, i64, i32, f32p, vp]),
         "effocr_crop_transform": (i32, [vp, i32, i32, i64, vp, i32, i32, i32, c.POINTER(c.c_float), c.POINTER(c.c_float),

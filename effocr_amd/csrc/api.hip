@@ -929,6 +929,9 @@ int effocr_knn_set_option(const char* name, int value) {
   if (std::string(name) == "wg_target") { knn_set_wg_target(value); return EFFOCR_OK; }
   if (std::string(name) == "two_pass_screen") { knn_two_pass_screen(value); return EFFOCR_OK; }
   if (std::string(name) == "q16_tile") { knn_q16_tile(value); return EFFOCR_OK; }
+  if (std::string(name) == "qs") { knn_qs_option(0, value); return EFFOCR_OK; }
+  if (std::string(name) == "qs_wgs") { knn_qs_option(1, value); return EFFOCR_OK; }
+  if (std::string(name) == "qs_pool") { knn_qs_option(2, value); return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, std::string("knn_set_option: unknown option '") + name + "'");
 }
 
@@ -937,7 +940,23 @@ size_t effocr_knn_screen_flag_offset(int64_t nq, int64_t ntotal, int d, int k) {
 int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, int64_t ntotal, int d, int k,
                                 float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (nq > 0 && (!q_dev || !xb_dev || !xb_bf16_dev || !dist_dev || !idx_dev || !workspace_dev)) return fail(EFFOCR_EINVAL, "knn(screened): NULL device pointer");
-  return knn_ip_topk_screened(q_dev, nq, xb_dev, xb_bf16_dev, ntotal, d, k, xnorm_max, dist_dev, idx_dev, workspace_dev, workspace_bytes, S(stream));
+  return knn_ip_topk_screened(q_dev, nq, xb_dev, xb_bf16_dev, nullptr, ntotal, d, k, xnorm_max, dist_dev, idx_dev, workspace_dev, workspace_bytes, S(stream));
+}
+
+int effocr_knn_ip_topk_screened2(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, const void* xb_bf16_blk_dev,
+                                 int64_t ntotal, int d, int k, float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev,
+                                 size_t workspace_bytes, void* stream) {
+  if (nq > 0 && (!q_dev || !xb_dev || (!xb_bf16_dev && !xb_bf16_blk_dev) || !dist_dev || !idx_dev || !workspace_dev))
+    return fail(EFFOCR_EINVAL, "knn(screened): NULL device pointer");
+  return knn_ip_topk_screened(q_dev, nq, xb_dev, xb_bf16_dev, xb_bf16_blk_dev, ntotal, d, k, xnorm_max, dist_dev, idx_dev, workspace_dev, workspace_bytes, S(stream));
+}
+
+size_t effocr_bf16_blocked_bytes(int64_t n_rows, int d) { return n_rows <= 0 || d <= 0 ? 0 : (size_t)((n_rows + 63) / 64 * 64) * (size_t)d * 2; }
+
+int effocr_convert_bf16_blocked(const float* src_dev, int64_t n_rows, int d, void* dst_dev, void* stream) {
+  if (n_rows > 0 && (!src_dev || !dst_dev)) return fail(EFFOCR_EINVAL, "convert_bf16_blocked: NULL device pointer");
+  if (n_rows < 0 || d <= 0) return fail(EFFOCR_EINVAL, "convert_bf16_blocked: bad sizes");
+  return convert_bf16_blocked(src_dev, n_rows, d, dst_dev, S(stream));
 }
 
 int effocr_convert_bf16(const float* src_dev, int64_t n, void* dst_dev, void* stream) {

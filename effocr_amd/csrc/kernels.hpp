@@ -146,8 +146,13 @@ void knn_q16_tile(int on);            // A/B: 0 = <= 16 queries on the 32-wide s
 void knn_two_pass_screen(int on);     // A/B: 1 = the screened search collects candidates with a second bf16 scan (default 0: from pass 1's chunk lists)
 void knn_force_tile_kernel(int on);   // A/B: 1 = the 128-query tile kernel also for <= 32 queries (default 0: streaming kernel)
 size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k);   // byte offset of the int32 overflow flag in that workspace
-int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, int64_t N, int D, int k, float xnorm_max,
+// xb16: row-major bf16 copy (convert_bf16; may be NULL when xblk serves the call), xblk: fragment-blocked bf16 copy
+// (convert_bf16_blocked: [ceil(N / 64) * 2][D / 8][32][8], zero rows past N; may be NULL) — with it, D in {128, 384, 768} and k <= 16 the
+// screening pass is the Q-stationary kernel (knn_qs_kernel)
+int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, const void* xblk, int64_t N, int D, int k, float xnorm_max,
                          float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s);
+int convert_bf16_blocked(const float* src, int64_t N, int D, void* dst, hipStream_t s);
+void knn_qs_option(int which, int value);   // 0: on / off (A/B), 1: workgroups per launch (0 = one per CU), 2: pooled form on / off (A/B)
 int convert_bf16(const float* src, int64_t n, void* dst, hipStream_t s);
 int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s);
 int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);

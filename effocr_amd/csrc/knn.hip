@@ -156,6 +156,8 @@ struct KnnArgs {
   // k > 32: the result is produced 32 columns at a time.  Pass p writes columns [ocol, ocol + k) of the [B][ldo] outputs and
   // (AFTER) only ranks rows that come strictly AFTER the previous pass's last result (after_col) in the (score desc, id asc) order.
   int ldo, ocol, after_col;
+  // knn_qs_kernel<.., POOL>: maxima of the approximate scores per 16-row block, M [4 * pairs][B], and per chunk, C [nchunks][B]
+  float* pool_m; float* pool_c;
 };
 
 // E = float: exact scores (the product's definition).  E = __bf16: screening scores s^ from bf16-rounded operands
@@ -974,6 +976,526 @@ int launch_knn_stream_k(int kmax, int nqt, const KnnArgs& a, hipStream_t s) {
   }
   return fail(EFFOCR_EINVAL, "knn: internal");
 }
+// ---- Q-stationary bf16 screening kernel (round 5) ---------------------------------------------------------------------------------
+// Pass 1 of knn_ip_topk_screened for ANY index size when the caller keeps a FRAGMENT-BLOCKED bf16 copy of the index
+// (effocr_convert_bf16_blocked: cells [row / 32][k chunk of 8][row % 32][16 B], the layout of the encoder's weight copies).  The
+// 128-query tile kernel (knn_partial_kernel<bf16>) restages BOTH operands through LDS every 64 k with a workgroup barrier per stage
+// and ran at 22 % of the bf16 MFMA peak on BASELINE configs[3] (1M x 768, 1024 queries: 2.9 ms) and at 95 TFLOP/s on configs[1]'s own
+// search (10 k x 384: 83 us of a 141 us, seven-launch chain for 7.9 GFLOP).  Here the geometry is the projection phase of qkvattn.hip:
+//   * the QUERIES are stationary: wave w holds QT tiles of 32 queries as MFMA B-operand fragments in registers for the whole kernel
+//     (D / 16 fragments per tile: 96 registers at D = 384 with QT = 2 tiles = 256 queries per workgroup, 192 at D = 768 with QT = 1);
+//   * the INDEX streams: stage = 64 rows x 128 k (16 KB) through a 6-slot LDS ring by LDS-DMA, five stages ahead, counted vmcnt + one
+//     raw barrier in the middle of a stage; the blocked copy makes a stage a verbatim copy of 512-byte cells, so the A-operand
+//     fragment reads (row r31, k half) are conflict-free ds_read_b128 — no transposes, no swizzles, no bank conflicts;
+//   * swapped MFMA (rows = index rows, columns = queries): a lane's 16 accumulators of a tile belong to ONE query with ascending row
+//     ids, so the running top-KMAX is the same lane-local sorted register list as everywhere else in this file (max-tree quick reject,
+//     bitmask walk, strict compare: ties keep the lower id); the two half-wave lists of a query merge through LDS at the end.
+// Output = the per-chunk lists [chunk][B][KMAX] of approximate scores the merge / collect / re-rank chain already consumes: the screened
+// search stays BIT-IDENTICAL to the exact one (same eps bound: bf16 operand rounding + fp32 accumulation, any summation order).
+constexpr int QS_STAGE = 16384, QS_RING = 6;
+// POOL (the default dispatch): NO lists at all.  Lane-local lists cost more than the products they rank — the chip holds 65 536 lanes, so
+// every query owns 64 lists of N / 64 rows each and a list takes KMAX (1 + ln(N / 64 / KMAX)) insertions of ~70 instructions that no
+// other lane of the wave shares: measured 0.86 ms of the 2.46 ms kernel at 1M x 768 x 1024 queries, and 80 us of a 131 us search at
+// 10 000 rows (where a third of all scores gets inserted).  Instead a lane writes the MAXIMUM of its 16 accumulators per (row tile,
+// query): one value per 16-row block, M[block][query] (15 v_max + one coalesced store per tile), and keeps a running maximum per
+// chunk, C[chunk][query].  Selection happens afterwards on 1/16 of the values and by THRESHOLD, not by insertion (knn_pool_collect_kernel,
+// knn_pool_rerank_kernel below).
+template <int D, int QT, int KMAX, bool POOL = false>
+__global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
+  typedef bf16x8 V8;
+  constexpr int KC = D / 8, KT = D / 128, NXF = D / 16, R = QS_RING;
+  static_assert(D % 128 == 0 && KMAX <= 16, "knn_qs: D must be a multiple of 128, lists of at most 16 entries");
+  static_assert(QT * 32 * 2 * (2 * KMAX + 1) * 4 <= R * QS_STAGE / 4, "knn_qs: the end-of-kernel list merge must fit a wave's share of the ring");
+  __shared__ __attribute__((aligned(16))) char smem[R * QS_STAGE + 4 * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
+  const int w = wave_id();
+  char* scr = smem + R * QS_STAGE + w * 8192;                        // the wave's candidate scratch [32 slots][64 lanes] fp32
+  // logical id = chunk * nqt + query group: the query groups of a chunk are consecutive logical ids = the same XCD (xcd_remap) and
+  // dispatched together, so a chunk's index rows leave HBM once and serve every query group out of that XCD's L2
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qg = lid % a.nqt, chunk = lid / a.nqt;
+  const int npairs = (a.N + 63) / 64;
+  const int p0 = chunk * a.tiles_per_chunk;                          // 64-row pairs [p0, p1) of this chunk
+  const int p1 = min(p0 + a.tiles_per_chunk, npairs);
+  const int nst = (p1 - p0) * KT;                                    // ring stages of this workgroup (>= KT)
+  const char* Xb = static_cast<const char*>(a.xb);
+  const __bf16* Q = static_cast<const __bf16*>(a.q);
+
+  // ---- query fragments: lane (query r31 of tile, k half) holds k = 16 t + 8 half .. + 7 for every k16 step t
+  V8 qf[QT][NXF];
+  const int q0 = (qg * 4 + w) * QT * 32;                             // first query of this wave
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = q0 + qt * 32 + r31;
+    const __bf16* qr = Q + (int64_t)(qi < a.B ? qi : a.B - 1) * D + 8 * half;
+#pragma unroll
+    for (int t = 0; t < NXF; ++t) qf[qt][t] = *reinterpret_cast<const V8*>(qr + 16 * t);
+  }
+
+  // ---- ring: stage s = (pair p0 + s / KT, k slice s % KT); wave w copies row block w >> 1, k chunks (w & 1) * 8 .. + 8: 4 pieces of 1 KB
+  int ip = p0, ikt = 0, islot = 0, issued = 0;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned sW_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue_stage = [&]() __attribute__((always_inline)) {
+    const char* src = Xb + ((size_t)(2 * ip + (w >> 1)) * KC + ikt * 16 + (w & 1) * 8) * 512 + lane16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)(islot * QS_STAGE) + (unsigned)(((w >> 1) * 16 + (w & 1) * 8) * 512)));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    islot = islot + 1 == R ? 0 : islot + 1;
+    if (++ikt == KT) { ikt = 0; ++ip; }
+    ++issued;
+  };
+  for (int s0 = 0; s0 < R - 1 && s0 < nst; ++s0) issue_stage();
+
+  float ls[QT][KMAX];
+  int li[QT][KMAX];
+  float cmax[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    cmax[qt] = -FLT_MAX;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { ls[qt][t] = -FLT_MAX; li[qt][t] = ID_NONE; }
+  }
+
+  // stage 0 has landed (own pieces: everything issued behind it may stay in flight; fewer than R - 1 stages in all: wait for all)
+  if (nst >= R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  int slot = 0, s = 0;
+  const int fo = half * 512 + r31 * 16;                              // the lane's fragment inside a cell pair
+  // A-operand fragments are requested TWO k16 steps ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency,
+  // and at QT = 1 a k16 step is only two MFMAs (64 cycles) long while the four waves' reads run the LDS at its full rate
+  V8 f0 = *reinterpret_cast<const V8*>(smem + fo), f1 = *reinterpret_cast<const V8*>(smem + fo + 16 * 512);
+  V8 g0 = *reinterpret_cast<const V8*>(smem + fo + 2 * 512), g1 = *reinterpret_cast<const V8*>(smem + fo + 18 * 512);
+#pragma unroll 1
+  for (int p = p0; p < p1; ++p) {
+    f32x16 acc[2][QT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][qt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const char* st = smem + slot * QS_STAGE + fo;
+      const int nslot = slot + 1 == R ? 0 : slot + 1;
+      const char* stn = smem + nslot * QS_STAGE + fo;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks == 4) {
+          // middle of stage s: stage s + 1 has landed (own pieces), and past the barrier everybody's; every wave is done with stage
+          // s - 1, whose slot takes stage s + R - 1.  In the steady state R - 3 younger stages may stay in flight; at the end of
+          // the stream (nothing more to issue) wait for everything.
+          if (issued - (s + 2) >= R - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 4) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (issued < nst) issue_stage();
+        }
+        V8 h0, h1;
+        if (ks < 6) {
+          h0 = *reinterpret_cast<const V8*>(st + (2 * (ks + 2)) * 512);
+          h1 = *reinterpret_cast<const V8*>(st + (16 + 2 * (ks + 2)) * 512);
+        } else {                                           // stage s + 1 landed for everybody at this stage's barrier (past the end: a dead read)
+          h0 = *reinterpret_cast<const V8*>(stn + (2 * (ks - 6)) * 512);
+          h1 = *reinterpret_cast<const V8*>(stn + (16 + 2 * (ks - 6)) * 512);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          acc[0][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qf[qt][kt * 8 + ks], acc[0][qt], 0, 0, 0);
+          acc[1][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, qf[qt][kt * 8 + ks], acc[1][qt], 0, 0, 0);
+        }
+        f0 = g0; f1 = g1; g0 = h0; g1 = h1;
+      }
+      slot = nslot; ++s;
+    }
+    if constexpr (POOL) {
+      // block b = 4 p + 2 i + half = the 16 rows 64 p + 32 i + 4 half + (r & 3) + 8 (r >> 2) this lane holds of row tile i
+      const bool lastp = p == npairs - 1;                              // only the last pair can hold rows >= N (zero rows of the blocked copy)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const int qi = q0 + qt * 32 + r31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float m = -FLT_MAX;
+          if (lastp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = (p * 64 + i * 32 + 4 * half + (r & 3) + 8 * (r >> 2) < a.N) ? fmaxf(m, acc[i][qt][r]) : m;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][qt][r]);
+          }
+          if (qi < a.B) a.pool_m[(int64_t)(p * 4 + i * 2 + half) * a.B + qi] = m;
+          cmax[qt] = fmaxf(cmax[qt], m);
+        }
+      }
+      continue;
+    }
+#ifndef QS_NOINSERT
+    // ---- scores of rows 64 p .. 64 p + 63 against the wave's queries are complete: feed the lists (rows ascend with (i, r) per lane)
+    const int nbase = p * 64 + 4 * half;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float thr = ls[qt][KMAX - 1];
+      float mxs = acc[0][qt][0];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mxs = fmaxf(mxs, acc[i][qt][r]);
+      if (__any(mxs > thr)) {
+        uint32_t hits = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
+            hits |= (n < a.N && acc[i][qt][r] > thr) ? (1u << (i * 16 + r)) : 0u;
+          }
+        if (__any(hits != 0)) {
+          // PER-LANE walk over the lane's own hits (ascending bit = ascending row id): the candidates are parked in the wave's LDS
+          // scratch [slot][lane] so that a lane can fetch the score of ITS next hit; the loop runs max-over-lanes(popcount) times —
+          // typically 1-3 once the lists have warmed up — instead of once per distinct slot any lane hit (up to 32, each a full
+          // predicated insertion: that walk was 3x the MFMA time of a 768-wide pair on a 1M-row index).
+          float* sc_lds = reinterpret_cast<float*>(scr) + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { sc_lds[r * 64] = acc[0][qt][r]; sc_lds[(16 + r) * 64] = acc[1][qt][r]; }
+          uint32_t h = hits;
+          while (__any(h != 0)) {
+            const bool mine = h != 0;
+            const int b = mine ? __builtin_ctz(h) : 0;
+            h &= h - 1u;
+            const float sc = sc_lds[b * 64];
+            const int n = nbase + (b >> 4) * 32 + (b & 3) + 8 * ((b & 15) >> 2);
+            if (mine && sc > ls[qt][KMAX - 1]) topk_insert<KMAX>(ls[qt], li[qt], sc, n);
+          }
+        }
+      }
+    }
+#else
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { ls[qt][0] = fmaxf(ls[qt][0], acc[0][qt][0] + acc[1][qt][5]); }
+#endif
+  }
+
+  if constexpr (POOL) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float m = fmaxf(cmax[qt], __shfl_xor(cmax[qt], 32, 64));
+      const int qi = q0 + qt * 32 + r31;
+      if (half == 0 && qi < a.B) a.pool_c[(int64_t)chunk * a.B + qi] = m;
+    }
+    return;
+  }
+  // ---- the two half-wave lists of every query -> one chunk list.  The ring is dead (every stage consumed; the last wait was vmcnt(0)):
+  // each wave takes its quarter of it, [query slot][half] lists with an odd word stride.
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  constexpr int LST = 2 * KMAX + 1;                                  // words per (query, half) list: scores then ids, odd stride
+  float* mS = reinterpret_cast<float*>(smem + w * (R * QS_STAGE / 4));
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float* l = mS + ((qt * 32 + r31) * 2 + half) * LST;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { l[t] = ls[qt][t]; reinterpret_cast<int*>(l)[KMAX + t] = li[qt][t]; }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // wave-private region: LDS operations of a wave execute in order
+  for (int qs = lane; qs < QT * 32; qs += 64) {
+    const int qi = q0 + qs;
+    if (qi >= a.B) continue;
+    const float* la = mS + (qs * 2) * LST;
+    const float* lb = la + LST;
+    const int* ia = reinterpret_cast<const int*>(la) + KMAX;
+    const int* ib = reinterpret_cast<const int*>(lb) + KMAX;
+    int pa = 0, pb = 0;
+    const int64_t ob = ((int64_t)chunk * a.B + qi) * KMAX;
+    for (int t = 0; t < KMAX; ++t) {
+      float sa = -FLT_MAX, sb = -FLT_MAX; int xa = ID_NONE, xb = ID_NONE;
+      if (pa < KMAX) { sa = la[pa]; xa = ia[pa]; }
+      if (pb < KMAX) { sb = lb[pb]; xb = ib[pb]; }
+      const bool ta = before(sa, xa, sb, xb) || xb == ID_NONE;
+      a.pdist[ob + t] = ta ? sa : sb;
+      a.pidx[ob + t] = ta ? xa : xb;
+      pa += ta ? 1 : 0; pb += ta ? 0 : 1;
+    }
+  }
+}
+
+// fp32 [N][D] row-major -> bf16 fragment-blocked [ceil(N / 64) * 2][D / 8][32][8]; rows >= N are zero.  One thread per 16-byte cell slot.
+__global__ __launch_bounds__(256) void convert_bf16_blocked_kernel(const float* __restrict__ src, int64_t N, int D, __bf16* __restrict__ dst) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kc = D / 8;
+  const int64_t nrb = (N + 63) / 64 * 2;
+  if (id >= nrb * kc * 32) return;
+  const int row = (int)(id & 31);
+  const int64_t cell = id >> 5;
+  const int c = (int)(cell % kc);
+  const int64_t n = (cell / kc) * 32 + row;
+  u32x4 o = {0u, 0u, 0u, 0u};
+  if (n < N) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + n * D + c * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + n * D + c * 8 + 4);
+    const u32x2 lo = pack4<__bf16>(a[0], a[1], a[2], a[3]), hi = pack4<__bf16>(b[0], b[1], b[2], b[3]);
+    o = u32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+  *reinterpret_cast<u32x4*>(dst + id * 8) = o;
+}
+
+// ---- selection over the block maxima (pass 1 = knn_qs_kernel<.., POOL>) ------------------------------------------------------------
+// L(q) = the k-th largest CHUNK maximum of query q is a lower bound of m_k(q), the k-th largest BLOCK maximum (chunk maxima are block
+// maxima of distinct blocks), and m_k <= s^_(k): the k blocks with the largest maxima hold k distinct rows.  Hence a true top-k row r
+// (s_r >= s_(k), |s^ - s| <= eps) has s^_r >= s_(k) - eps >= s^_(k) - 2 eps >= m_k - 2 eps >= L - 2 eps, and so has its block's maximum.
+//   collect  every block with M[b][q] >= L(q) - 2 eps(q) -> the query's entry list (value, block), <= POOL_CAP entries (else: overflow
+//            flag -> the gated exact pass).  Workgroup = 64 queries (lane = query: coalesced rows of M) x a range of blocks.
+//   rerank   per query: m_k = the k-th largest collected value (all blocks >= L - 2 eps are there, so the k largest are), survivors =
+//            entries >= m_k - 2 eps, exact ascending-k fmaf chains of the survivors' 16 rows each, (score desc, id asc) top k.
+// Results stay bit-identical to the exact search: the candidate ROWS are a superset of the true top k, their scores the product's own.
+constexpr int POOL_CAP = 256;          // collected blocks per query
+constexpr int POOL_ROWS = 1024;        // rows re-ranked per query (64 surviving blocks)
+template <int KSEL>
+__global__ __launch_bounds__(256) void knn_pool_collect_kernel(const float* __restrict__ M, const float* __restrict__ C, int B, int nblk, int nchunks,
+                                                               int k, int blk_per_wg, const float* __restrict__ qnorm, float eps_scale,
+                                                               float* __restrict__ evalue, int* __restrict__ eblk, int* __restrict__ cnt,
+                                                               int* __restrict__ flag) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = blockIdx.y * 64 + lane;
+  const bool qok = q < B;
+  const int qc = qok ? q : B - 1;
+  // L(q): k-th largest of the chunk maxima — a sorted k-entry list per lane over <= 256 values, loaded eight at a time (one
+  // dependent round trip per value made this prologue most of the kernel on a 10 000-row index)
+  float top[KSEL];
+#pragma unroll
+  for (int t = 0; t < KSEL; ++t) top[t] = -FLT_MAX;
+  for (int c0 = 0; c0 < nchunks; c0 += 8) {
+    float cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cv[u] = (c0 + u < nchunks) ? C[(int64_t)(c0 + u) * B + qc] : -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float v = cv[u];
+      if (__any(v > top[KSEL - 1])) {
+#pragma unroll
+        for (int t = KSEL - 1; t >= 1; --t) {
+          const bool gp = v > top[t - 1], g = v > top[t];
+          top[t] = gp ? top[t - 1] : (g ? v : top[t]);
+        }
+        top[0] = v > top[0] ? v : top[0];
+      }
+    }
+  }
+  float L = top[0];
+#pragma unroll
+  for (int t = 1; t < KSEL; ++t) L = (t < k) ? top[t] : L;            // top[k - 1]
+  const float thr = L - eps_scale * qnorm[qc];
+  const int b0 = blockIdx.x * blk_per_wg;
+  int b1 = b0 + blk_per_wg;
+  b1 = b1 < nblk ? b1 : nblk;
+  for (int b = b0 + w; b < b1; b += 32) {                             // 4 waves x 8 loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (b + 4 * u < b1) ? M[(int64_t)(b + 4 * u) * B + qc] : -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (qok && b + 4 * u < b1 && v[u] >= thr) {
+        const int pos = atomicAdd(cnt + q, 1);
+        if (pos < POOL_CAP) { evalue[(int64_t)q * POOL_CAP + pos] = v[u]; eblk[(int64_t)q * POOL_CAP + pos] = b + 4 * u; }
+        else atomicOr(flag, 1);
+      }
+  }
+}
+
+// Stage A re-scores the 16 rows of every surviving block APPROXIMATELY from the blocked bf16 copy (4 lanes per row, a quarter of the k
+// range each; the block's rows sit in 64-byte runs of every cell: sector-efficient) — any bf16-product sum is within eps of the exact
+// score, so a true top-k row still has s^' >= tau — and only the rows that pass go to stage B, the exact ascending-k fmaf chain over the
+// fp32 row (1.5 - 3 KB scattered per row: re-ranking all 16 rows of every block exactly was 131 us of BASELINE configs[1]'s search and
+// 0.7 ms at 1M x 768 x 1024 queries).
+constexpr int POOL_EXACT = 256;        // rows re-ranked exactly per query
+template <int D>
+__global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __restrict__ q, const float* __restrict__ xb, const char* __restrict__ xblk,
+                                                              int N, int k, const float* __restrict__ evalue, const int* __restrict__ eblk,
+                                                              const int* __restrict__ cnt, const float* __restrict__ qnorm, float eps_scale,
+                                                              float* __restrict__ dist, int64_t* __restrict__ idx, int* __restrict__ flag) {
+  constexpr int KC = D / 8, CPL = KC / 4;                            // 16-byte k chunks per row / per lane of a row's quad
+  __shared__ float sV[POOL_CAP];
+  __shared__ int sB[POOL_CAP];
+  __shared__ int sSurv[POOL_ROWS / 16];
+  __shared__ float sS[POOL_EXACT];
+  __shared__ int sI[POOL_EXACT];
+  __shared__ int sN, sN2;
+  __shared__ float sTau;
+  __shared__ __attribute__((aligned(16))) float sQ[D];
+  static_assert(D % 128 == 0, "knn_pool_rerank: D must be a multiple of 128");
+  const int qg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = cnt[qg];
+  if (n > POOL_CAP) { if (tid == 0) atomicOr(flag, 1); return; }     // (the collect kernel raised the flag already)
+  if (tid == 0) { sN = 0; sN2 = 0; sTau = -FLT_MAX; }
+  for (int d = tid; d < D; d += 256) sQ[d] = q[(int64_t)qg * D + d];
+  float v = -FLT_MAX; int b = -1;
+  if (tid < n) { v = evalue[(int64_t)qg * POOL_CAP + tid]; b = eblk[(int64_t)qg * POOL_CAP + tid]; }
+  sV[tid] = v; sB[tid] = b;
+  __syncthreads();
+  // rank of this entry among the collected values (ties by block id): the entry of rank k - 1 is m_k
+  if (tid < n) {
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (sV[j] > v || (sV[j] == v && sB[j] < b)) ? 1 : 0;
+    const int kk = k < n ? k : n;                                      // fewer than k blocks in the whole index: everything survives
+    if (rank == kk - 1) sTau = v - eps_scale * qnorm[qg];
+  }
+  __syncthreads();
+  const float tau = sTau;
+  if (tid < n && v >= tau) {
+    const int pos = atomicAdd(&sN, 1);
+    if (pos < POOL_ROWS / 16) sSurv[pos] = b;
+  }
+  __syncthreads();
+  const int ns = sN;
+  if (ns > POOL_ROWS / 16) { if (tid == 0) atomicOr(flag, 1); return; }   // overflow: the gated exact pass recomputes everything
+  const float* qr = q + (int64_t)qg * D;
+  // ---- stage A: block bb = rows 64 (bb >> 2) + 32 ((bb >> 1) & 1) + 4 (bb & 1) + (r & 3) + 8 (r >> 2), r = 0..15; lane = (r, k quarter).
+  // The lane's quarter of the query stays in registers; TWO blocks' chunks are requested before the first is summed.
+  {
+    const int r = lane >> 2, kq = lane & 3;
+    auto row_of = [&](int bb) __attribute__((always_inline)) { return 64 * (bb >> 2) + 32 * ((bb >> 1) & 1) + 4 * (bb & 1) + (r & 3) + 8 * (r >> 2); };
+    auto load_blk = [&](int row, u32x4 (&xv)[CPL]) __attribute__((always_inline)) {
+      const char* cell = xblk + (((int64_t)(row >> 5) * KC + kq * CPL) * 32 + (row & 31)) * 16;
+#pragma unroll
+      for (int t = 0; t < CPL; ++t) xv[t] = *reinterpret_cast<const u32x4*>(cell + (size_t)t * 512);
+    };
+    auto finish = [&](int row, const u32x4 (&xv)[CPL]) __attribute__((always_inline)) {
+      float acc = 0.f;
+      int qo = 0;
+      asm volatile("" : "+v"(qo));                         // opaque: else the query reads are hoisted out of the block loop (D / 4 registers)
+      const float* qv = sQ + kq * CPL * 8 + qo;
+#pragma unroll
+      for (int t = 0; t < CPL; ++t) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qv + 8 * t), q1 = *reinterpret_cast<const f32x4*>(qv + 8 * t + 4);
+        acc = fmaf(__uint_as_float(xv[t][0] << 16), q0[0], acc); acc = fmaf(__uint_as_float(xv[t][0] & 0xffff0000u), q0[1], acc);
+        acc = fmaf(__uint_as_float(xv[t][1] << 16), q0[2], acc); acc = fmaf(__uint_as_float(xv[t][1] & 0xffff0000u), q0[3], acc);
+        acc = fmaf(__uint_as_float(xv[t][2] << 16), q1[0], acc); acc = fmaf(__uint_as_float(xv[t][2] & 0xffff0000u), q1[1], acc);
+        acc = fmaf(__uint_as_float(xv[t][3] << 16), q1[2], acc); acc = fmaf(__uint_as_float(xv[t][3] & 0xffff0000u), q1[3], acc);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (kq == 0 && row < N && acc >= tau) {
+        const int pos = atomicAdd(&sN2, 1);
+        if (pos < POOL_EXACT) sI[pos] = row;
+      }
+    };
+    // (one block at a time: <= 128 registers keep four workgroups = sixteen queries per CU in flight, which hides the latency chain
+    // cnt -> entries -> tau -> blocks -> rows better than a second block per wave did at two workgroups per CU)
+    for (int j = w; j < ns; j += 4) {
+      u32x4 xa[CPL];
+      const int ra = row_of(sSurv[j]);
+      load_blk(ra, xa);
+      finish(ra, xa);
+    }
+  }
+  __syncthreads();
+  const int n2 = sN2;
+  if (n2 > POOL_EXACT) { if (tid == 0) atomicOr(flag, 1); return; }
+  // ---- stage B: exact scores (the ascending-k fmaf chain) of the rows that passed.  One thread per row; the chain is serial but its
+  // LOADS are not: 64 floats of the row are requested at once (an 8-load batch per 16 FMAs left the thread waiting out a memory round
+  // trip per batch: 24 round trips per 384-wide row were most of this kernel), the query comes from LDS (broadcast reads).
+  {
+    float sc = -FLT_MAX; int id = ID_NONE;
+    if (tid < n2) {
+      id = sI[tid];
+      const float* xr = xb + (int64_t)id * D;
+      sc = 0.f;
+#pragma unroll 1
+      for (int d = 0; d < D; d += 64) {
+        f32x4 c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = *reinterpret_cast<const f32x4*>(xr + d + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(sQ + d + 4 * u);
+          sc = fmaf(a[0], c[u][0], sc); sc = fmaf(a[1], c[u][1], sc); sc = fmaf(a[2], c[u][2], sc); sc = fmaf(a[3], c[u][3], sc);
+        }
+      }
+    }
+    __syncthreads();                                                 // (sI is re-written below: every id has been read)
+    sS[tid] = sc; sI[tid] = id;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  constexpr int PER = POOL_EXACT / 64;
+  float ls[PER]; int li[PER];
+#pragma unroll
+  for (int t = 0; t < PER; ++t) { ls[t] = sS[lane + 64 * t]; li[t] = sI[lane + 64 * t]; }
+  for (int o = 0; o < k; ++o) {
+    float bs = -FLT_MAX; int bi = ID_NONE;
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+      if (before(ls[t], li[t], bs, bi)) { bs = ls[t]; bi = li[t]; }
+    float ws; int wi;
+    wave_best(bs, bi, ws, wi);
+    if (wi != ID_NONE) {
+#pragma unroll
+      for (int t = 0; t < PER; ++t)
+        if (li[t] == wi) { ls[t] = -FLT_MAX; li[t] = ID_NONE; }
+    }
+    if (lane == 0) {
+      dist[(int64_t)qg * k + o] = (wi == ID_NONE) ? -FLT_MAX : ws;
+      idx[(int64_t)qg * k + o] = (wi == ID_NONE) ? (int64_t)-1 : (int64_t)wi;
+    }
+  }
+}
+
+int g_knn_qs_wgs = 0;                 // workgroups a knn_qs launch aims for (0 = one per CU); knn_set_option("qs_wgs")
+bool g_knn_qs = true;                 // A/B switch (tests): 0 = the screened search ignores the blocked copy
+bool g_knn_qs_pool = true;            // A/B switch (tests): 0 = the Q-stationary pass keeps per-lane lists (merge / collect / re-rank chain)
+struct QsPlan { int qt, nqg, ppc, nchunks; };
+bool qs_applies(int64_t B, int64_t N, int D, int k) {
+  return g_knn_qs && !g_knn_two_pass && !g_knn_force_tile && (D == 128 || D == 384 || D == 768) && k <= 16 && N >= 64;
+}
+QsPlan qs_plan(int64_t B, int64_t N, int D) {
+  QsPlan p;
+  // two query tiles per wave (256 queries per workgroup, half the LDS fragment reads per MFMA) where the index is long enough to keep
+  // every CU busy anyway; one (128 queries) for 768-wide rows (192 fragment registers per tile) and for small indexes, where more,
+  // shorter workgroups win: the lists' warm-up insertions are a fixed cost per (query, workgroup)
+  p.qt = (D <= 384 && N >= 65536) ? 2 : 1;
+  p.nqg = (int)((B + 128 * p.qt - 1) / (128 * p.qt));
+  const int npairs = (int)((N + 63) / 64);
+  int want = (g_knn_qs_wgs > 0 ? g_knn_qs_wgs : device_cus()) / p.nqg;
+  if (want < 1) want = 1;
+  if (want > MAX_CHUNKS) want = MAX_CHUNKS;
+  if (want > npairs) want = npairs;
+  p.ppc = (npairs + want - 1) / want;
+  p.nchunks = (npairs + p.ppc - 1) / p.ppc;
+  return p;
+}
+int launch_knn_qs_pool(const KnnArgs& a, int D, int qt, hipStream_t s) {
+  const dim3 grid((unsigned)(a.nqt * a.nchunks)), blk(256);
+  if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2, 1, true>), grid, blk, 0, s, a);
+  else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1, 1, true>), grid, blk, 0, s, a);
+  else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1, 1, true>), grid, blk, 0, s, a);
+  else if (D == 128 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<128, 2, 1, true>), grid, blk, 0, s, a);
+  else if (D == 128 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<128, 1, 1, true>), grid, blk, 0, s, a);
+  else return fail(EFFOCR_EINVAL, "knn(qs): internal");
+  return check_launch("knn_qs_pool");
+}
+int launch_knn_qs(const KnnArgs& a, int D, int qt, hipStream_t s) {
+  const dim3 grid((unsigned)(a.nqt * a.nchunks)), blk(256);
+  if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2, 16>), grid, blk, 0, s, a);
+  else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1, 16>), grid, blk, 0, s, a);
+  else if (D == 128 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<128, 1, 16>), grid, blk, 0, s, a);
+  else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1, 16>), grid, blk, 0, s, a);
+  else if (D == 128 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<128, 2, 16>), grid, blk, 0, s, a);
+  else return fail(EFFOCR_EINVAL, "knn(qs): internal");
+  return check_launch("knn_qs");
+}
+
 // how many queries one streaming launch takes at (D, kmax): 64 where both query images and the merge lists fit the LDS, else 32
 int stream_queries(int D, int kmax) { return (D <= 384 && kmax <= 16) ? 64 : 32; }
 
@@ -1034,11 +1556,17 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
 
 // ---- screened search: bit-identical results to knn_ip_topk, for large indexes ------------------------------------------
 // Workspace layout: [exact-pass partial lists | qb bf16 | qnorm | adist | aidx | cnt | flag | cand]
-struct ScreenWs { size_t part, qb, qnorm, adist, aidx, cnt, flag, cand, total; };
+struct ScreenWs { size_t part, qb, qnorm, adist, aidx, cnt, flag, cand, pool_m, pool_c, pool_ev, pool_eb, total; };
 ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   ScreenWs w; size_t off = 0;
   auto take = [&](size_t n) { const size_t o = off; off = align_up(off + n, 256); return o; };
-  w.part = take(knn_workspace_bytes(B, N, D, k < 16 ? 16 : k));   // pass 1 keeps >= 16-entry chunk lists (see knn_ip_topk_screened)
+  size_t part = knn_workspace_bytes(B, N, D, k < 16 ? 16 : k);    // pass 1 keeps >= 16-entry chunk lists (see knn_ip_topk_screened)
+  if (k <= 16 && N >= 64) {                                        // ... and the Q-stationary pass its own chunking (MAX_CHUNKS at most)
+    const QsPlan qp = qs_plan(B, N, D);
+    const size_t need = align_up((size_t)qp.nchunks * (size_t)B * 16 * 8, 256) + 256;
+    part = part > need ? part : need;
+  }
+  w.part = take(part);
   w.qb = take((size_t)B * D * 2);
   w.qnorm = take((size_t)B * 4);
   w.adist = take((size_t)B * k * 4);
@@ -1046,6 +1574,14 @@ ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   w.cnt = take((size_t)B * 4);
   w.flag = take(256);
   w.cand = take((size_t)B * RR_CAP * 4);
+  w.pool_m = w.pool_c = w.pool_ev = w.pool_eb = 0;
+  if (k <= 16 && N >= 64) {                                        // block / chunk maxima + collected entries of the pooled Q-stationary pass
+    const QsPlan qp = qs_plan(B, N, D);
+    w.pool_m = take((size_t)((N + 63) / 64) * 4 * (size_t)B * 4);
+    w.pool_c = take((size_t)qp.nchunks * (size_t)B * 4);
+    w.pool_ev = take((size_t)B * POOL_CAP * 4);
+    w.pool_eb = take((size_t)B * POOL_CAP * 4);
+  }
   w.total = off;
   return w;
 }
@@ -1068,7 +1604,20 @@ int convert_bf16(const float* src, int64_t n, void* dst, hipStream_t s) {
   return check_launch("convert_bf16");
 }
 
-int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, int64_t N, int D, int k, float xnorm_max,
+int convert_bf16_blocked(const float* src, int64_t N, int D, void* dst, hipStream_t s) {
+  if (N <= 0) return EFFOCR_OK;
+  if (D % 8) return fail(EFFOCR_EUNSUPPORTED, "convert_bf16_blocked: the row length must be a multiple of 8");
+  const int64_t slots = (N + 63) / 64 * 2 * (D / 8) * 32;
+  hipLaunchKernelGGL(convert_bf16_blocked_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, src, N, D, static_cast<__bf16*>(dst));
+  return check_launch("convert_bf16_blocked");
+}
+void knn_qs_option(int which, int value) {
+  if (which == 0) g_knn_qs = value != 0;
+  else if (which == 2) g_knn_qs_pool = value != 0;
+  else g_knn_qs_wgs = value < 0 ? 0 : value;
+}
+
+int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, const void* xblk, int64_t N, int D, int k, float xnorm_max,
                          float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s) {
   if (B < 0 || N < 0 || D <= 0 || k <= 0 || !(xnorm_max >= 0.f)) return fail(EFFOCR_EINVAL, "knn(screened): bad sizes");
   if (B == 0) return EFFOCR_OK;
@@ -1105,7 +1654,54 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   // the screening pass STREAMS the bf16 index once per 64 queries (knn_stream_kernel<.., __bf16>) instead of running the 128-query tile
   // kernel; its chunk lists feed the same collect / re-rank / gated exact fallback.
   const float c = (0.00390625f + 0.0000152587890625f + 4.0f * (float)D * 5.9604645e-8f) * 1.0001f;   // |s^ - s| <= c |q| |x|, see pass 2
-  const bool stream16 = B <= 128 && N >= 65536 && D % 192 == 0 && D <= 768 && p.nchunks > 1 && kmax1 >= 16 && !g_knn_two_pass && !g_knn_force_tile;
+  const bool stream16 = B <= 128 && N >= 65536 && D % 192 == 0 && D <= 768 && p.nchunks > 1 && kmax1 >= 16 && !g_knn_two_pass && !g_knn_force_tile && xb16 != nullptr;
+  // The Q-stationary pass over the fragment-blocked bf16 copy (knn_qs_kernel): every call size it covers except the 17..128-query calls
+  // against a large index, which the streaming screen serves at the HBM rate.
+  const bool qs = xblk != nullptr && qs_applies(B, N, D, k) && !stream16;
+  if (!qs && xb16 == nullptr) return fail(EFFOCR_EINVAL, "knn(screened): this call needs the row-major bf16 copy of the index");
+  int chunks1 = p.nchunks;                                 // chunk lists pass 1 leaves for the merge / collect kernels
+  const QsPlan qsp = qs ? qs_plan(B, N, D) : QsPlan{};
+  if (qs && g_knn_qs_pool && qsp.nchunks >= 16) {
+    // pooled form (the default): pass 1 writes block / chunk maxima only, then threshold collect + block re-rank — four launches + the
+    // gated exact pair, no lists, no merge
+    KnnArgs b = a;
+    b.q = qb; b.xb = xblk; b.nqt = qsp.nqg; b.tiles_per_chunk = qsp.ppc; b.nchunks = qsp.nchunks;
+    b.pool_m = reinterpret_cast<float*>(W + w.pool_m); b.pool_c = reinterpret_cast<float*>(W + w.pool_c);
+    if ((rc = launch_knn_qs_pool(b, D, qsp.qt, s))) return rc;
+    const int nblk = (int)((N + 63) / 64) * 4;
+    // collect: ~2 workgroups per CU, 64 queries each
+    const int nqb = (int)((B + 63) / 64);
+    int per = (nblk * nqb + 2 * device_cus() - 1) / (2 * device_cus());
+    per = (per + 31) / 32 * 32;
+    if (per < 32) per = 32;
+    const dim3 cg((unsigned)((nblk + per - 1) / per), (unsigned)nqb);
+    float* ev = reinterpret_cast<float*>(W + w.pool_ev); int* eb = reinterpret_cast<int*>(W + w.pool_eb);
+    const float es = 2.0f * c * xnorm_max;
+    hipLaunchKernelGGL((knn_pool_collect_kernel<16>), cg, dim3(256), 0, s, b.pool_m, b.pool_c, (int)B, nblk, qsp.nchunks, k, per, qnorm, es, ev, eb, cnt, flag);
+    if ((rc = check_launch("knn_pool_collect"))) return rc;
+    const char* xk = static_cast<const char*>(xblk);
+    if (D == 384) hipLaunchKernelGGL((knn_pool_rerank_kernel<384>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
+    else if (D == 768) hipLaunchKernelGGL((knn_pool_rerank_kernel<768>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
+    else hipLaunchKernelGGL((knn_pool_rerank_kernel<128>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
+    if ((rc = check_launch("knn_pool_rerank"))) return rc;
+    KnnArgs e{};
+    e.q = q; e.B = (int)B; e.xb = xb; e.N = (int)N; e.D = D; e.k = k; e.ldo = k; e.ocol = 0; e.after_col = -1;
+    e.nqt = p.nqt; e.tiles_per_chunk = p.tpc; e.nchunks = p.nchunks;
+    e.pdist = a.pdist; e.dist = dist; e.idx = idx; e.run_flag = flag;
+    e.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
+    return launch_knn_k<float>(p.kmax, e, s);
+  }
+  if (qs) {
+    const QsPlan qp = qsp;
+    KnnArgs b = a;
+    b.q = qb; b.xb = xblk; b.nqt = qp.nqg; b.tiles_per_chunk = qp.ppc; b.nchunks = qp.nchunks;
+    b.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)qp.nchunks * (size_t)B * 16 * 4, 128));
+    if ((rc = launch_knn_qs(b, D, qp.qt, s))) return rc;
+    a.pidx = b.pidx;
+    chunks1 = qp.nchunks;
+    launch_knn_merge<16>(a.pdist, a.pidx, (int)B, chunks1, k, adist, aidx, nullptr, k, 0, s);
+    if ((rc = check_launch("knn_merge"))) return rc;
+  } else
   if (stream16) {
     a.qnorm = qnorm;
     a.eps_scale = 2.0f * c * xnorm_max;                    // the band of the re-rank's candidate set (below)
@@ -1127,11 +1723,11 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   // |s^ - s| <= eps = c * |q| * |x|: operand rounding (2^-8 + 2^-16) plus fp32 accumulation of both chains (4 d 2^-24),
   // 1e-4 relative slack for the fp32 norms.  A true top-k row has s >= s_(k), hence s^ >= s_(k) - eps >= s^_(k) - 2 eps.
   a.adist = adist; a.qnorm = qnorm; a.eps_scale = 2.0f * c * xnorm_max; a.cand = cand; a.cnt = cnt; a.cap = RR_CAP;
-  if (p.nchunks > 1 && !g_knn_two_pass) {                  // the candidates are already in pass 1's per-chunk lists
+  if (qs || (p.nchunks > 1 && !g_knn_two_pass)) {          // the candidates are already in pass 1's per-chunk lists
     const dim3 cg((unsigned)((B + 3) / 4));
-    switch (kmax1) {
-      case 16: hipLaunchKernelGGL((knn_collect_lists_kernel<16>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
-      default: hipLaunchKernelGGL((knn_collect_lists_kernel<32>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+    switch (qs ? 16 : kmax1) {
+      case 16: hipLaunchKernelGGL((knn_collect_lists_kernel<16>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, chunks1, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+      default: hipLaunchKernelGGL((knn_collect_lists_kernel<32>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, chunks1, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
     }
   } else
   switch (p.kmax) {
@@ -1147,7 +1743,8 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   KnnArgs e{};
   e.q = q; e.B = (int)B; e.xb = xb; e.N = (int)N; e.D = D; e.k = k; e.ldo = k; e.ocol = 0; e.after_col = -1;
   e.nqt = p.nqt; e.tiles_per_chunk = p.tpc; e.nchunks = p.nchunks;
-  e.pdist = a.pdist; e.pidx = a.pidx; e.dist = dist; e.idx = idx; e.run_flag = flag;
+  e.pdist = a.pdist; e.dist = dist; e.idx = idx; e.run_flag = flag;
+  e.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));   // its own split of the list area
   return launch_knn_k<float>(p.kmax, e, s);
 }
 

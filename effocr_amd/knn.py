@@ -44,7 +44,8 @@ class IndexFlatIP:
         self.screen_overflows = 0                # screened searches that had to re-run exactly (candidate cap exceeded)
         self._flag_pending = None                # (pinned host copy of the device overflow flag, event) of the last screened call
         self._xb16 = None                        # bf16 copy of the rows + max row norm, built lazily for the screening pass
-        self._xnorm_max = 0.0
+        self._xblk = None                        # fragment-blocked bf16 copy (effocr_convert_bf16_blocked): the Q-stationary screening pass
+        self._xnorm_max = None
 
     @property
     def ntotal(self):
@@ -62,11 +63,14 @@ class IndexFlatIP:
     def add(self, x):
         x = self._as_dev(x)
         self._xb = x.clone() if self.ntotal == 0 else torch.cat([self._xb, x], dim=0)
-        self._xb16 = None
+        self._drop_copies()
 
     def reset(self):
         self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
-        self._xb16 = None
+        self._drop_copies()
+
+    def _drop_copies(self):
+        self._xb16 = self._xblk = self._xnorm_max = None
 
     SCREEN_MAX_OVERFLOWS = 3   # after this many overflowing calls screening is switched off for this index
 
@@ -108,15 +112,34 @@ class IndexFlatIP:
         if self.ntotal >= self.SCREEN_MIN_ROWS and self.d % 192 == 0 and self.d <= 768 and 16 < nq <= 128:
             return True
         stream_cap = 64 if self.d <= 384 else 32
+        if self._qs_ok(k):
+            # round 5, the Q-stationary pooled screen (tools/knn_c2_time.py, same box): 10 k x 384 at 1024 queries 88 us (k = 10) / 51 us
+            # (k = 1) against 130 / 115 us on the round-4 chain and 160 / 97 us exact; 1M x 384 at 256 / 1024 queries 0.36 / 0.87 ms
+            # against 0.99 / 3.2 ms; 1M x 768 at 1024 queries 1.81 against 3.96 ms.  Calls of <= 256 queries against a small index stay
+            # exact (69 us: the chain's four dependent launches cost more than the products there).
+            return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512)
         # (k = 1 on a small index: the exact kernel keeps one-entry lists — 98 vs 111 us at 10 k rows x 1024 queries, tools/knn_c2_sweep.py)
         return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512 and k > 1)
 
-    def _screen_copy(self):
-        if self._xb16 is None:
-            self._xb16 = torch.empty((self.ntotal, self.d), dtype=torch.bfloat16, device=self.device)
-            with torch.cuda.device(self.device):
+    QS_DIMS = (128, 384, 768)  # embed dims of the Q-stationary screening kernel (ViT-tiny test width, ViT-S, ViT-B)
+    use_qs = True              # A/B: False = screening passes without the blocked copy (round-4 kernels)
+
+    def _qs_ok(self, k):
+        return self.use_qs and self.d in self.QS_DIMS and k <= 16 and self.ntotal >= 64
+
+    def _screen_copy(self, rowmajor=True, blocked=False):
+        """The bf16 copies of the rows a screening pass reads, built lazily per index change: row-major (the 128-query tile kernel,
+        the streaming screen) and / or fragment-blocked (the Q-stationary kernel) — plus an upper bound of every row norm."""
+        with torch.cuda.device(self.device):
+            if rowmajor and self._xb16 is None:
+                self._xb16 = torch.empty((self.ntotal, self.d), dtype=torch.bfloat16, device=self.device)
                 _lib.check(self._L.effocr_convert_bf16(_lib.ptr(self._xb), self.ntotal * self.d, _lib.ptr(self._xb16),
-                                                       _lib.current_stream(self.device)), "effocr_convert_bf16")
+                                                       _lib.current_stream(self.device)), "effocr_convert_bf16", self._L)
+            if blocked and self._xblk is None:
+                self._xblk = torch.empty(int(self._L.effocr_bf16_blocked_bytes(self.ntotal, self.d)), dtype=torch.uint8, device=self.device)
+                _lib.check(self._L.effocr_convert_bf16_blocked(_lib.ptr(self._xb), self.ntotal, self.d, _lib.ptr(self._xblk),
+                                                               _lib.current_stream(self.device)), "effocr_convert_bf16_blocked", self._L)
+        if self._xnorm_max is None:
             # an upper bound of every row norm (fp32 rounding slack included); one host read per index change
             self._xnorm_max = float(torch.linalg.vector_norm(self._xb, dim=1).max().item()) * (1.0 + 1e-5)
         return self._xb16
@@ -139,7 +162,7 @@ class IndexFlatIP:
             _lib.check(self._L.effocr_gather_rows(_lib.ptr(self._xb), _lib.ptr(rows), rows.numel(), self.d,
                                                   _lib.ptr(dst), _lib.current_stream(self.device)), "effocr_gather_rows")
         self._xb = dst
-        self._xb16 = None
+        self._drop_copies()
         return int(ids.size)
 
     def search_device(self, q, k):
@@ -155,13 +178,18 @@ class IndexFlatIP:
             return D, I
         self._poll_overflow()
         if self._use_screen(k, n):
-            xb16 = self._screen_copy()
+            qs = self._qs_ok(k)
+            # the streaming screen (17..128 queries against a large index) reads the row-major copy; everything else the blocked one
+            stream16 = self.ntotal >= self.SCREEN_MIN_ROWS and self.d % 192 == 0 and self.d <= 768 and 16 < n <= 128
+            self._screen_copy(rowmajor=stream16 or not qs, blocked=qs and not stream16)
             need = int(self._L.effocr_knn_screen_workspace_bytes(n, self.ntotal, self.d, k))
             with torch.cuda.device(self.device):
                 ws = self._workspace(need)
-                _lib.check(self._L.effocr_knn_ip_topk_screened(_lib.ptr(q), n, _lib.ptr(self._xb), _lib.ptr(xb16), self.ntotal, self.d, k,
-                                                               self._xnorm_max, _lib.ptr(D), _lib.ptr(I), _lib.ptr(ws),
-                                                               ws.numel(), _lib.current_stream(self.device)), "effocr_knn_ip_topk_screened")
+                _lib.check(self._L.effocr_knn_ip_topk_screened2(_lib.ptr(q), n, _lib.ptr(self._xb),
+                                                                _lib.ptr(self._xb16 if (stream16 or not qs) else None),
+                                                                _lib.ptr(self._xblk if (qs and not stream16) else None), self.ntotal, self.d, k,
+                                                                self._xnorm_max, _lib.ptr(D), _lib.ptr(I), _lib.ptr(ws),
+                                                                ws.numel(), _lib.current_stream(self.device)), "effocr_knn_ip_topk_screened", self._L)
                 if self._flag_pending is None:
                     off = int(self._L.effocr_knn_screen_flag_offset(n, self.ntotal, self.d, k))
                     host = torch.empty(1, dtype=torch.int32).pin_memory()

@@ -194,6 +194,19 @@ int effocr_knn_ip_topk_screened(const float* q_dev, int64_t nq, const float* xb_
                                 int k, float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev,
                                 size_t workspace_bytes, void* stream);
 int effocr_convert_bf16(const float* src_dev, int64_t n, void* dst_dev, void* stream);
+/* ABI 6: the screened search with a FRAGMENT-BLOCKED bf16 copy of the index (cells [row / 32][k chunk of 8][row % 32][16 B] — the layout
+ * of the encoder's weight copies; effocr_convert_bf16_blocked writes it, effocr_bf16_blocked_bytes sizes it: rows are padded to a
+ * multiple of 64 with zeros).  With it, d in {128, 384, 768} and k <= 16 the screening pass is the Q-STATIONARY kernel: the queries of a
+ * workgroup (256 at d <= 384, 128 at d = 768) live in registers as MFMA operand fragments, the index streams through a 6-slot LDS-DMA
+ * ring as verbatim 512-byte cells (conflict-free fragment reads, no transposes), per-lane register top-k lists — for EVERY index size:
+ * BASELINE configs[1]'s own 10 000-row search and configs[3]'s 1M x 768 alike.  xb_bf16_dev (row-major copy) may be NULL then, except
+ * for calls of 17..128 queries against >= 65 536 rows, which keep the streaming screen when it is given.  Results are bit-identical to
+ * effocr_knn_ip_topk either way.  effocr_knn_set_option: "qs" [1] (0: ignore the blocked copy, A/B), "qs_wgs" [0 = one per CU]. */
+size_t effocr_bf16_blocked_bytes(int64_t n_rows, int d);
+int effocr_convert_bf16_blocked(const float* src_dev, int64_t n_rows, int d, void* dst_dev, void* stream);
+int effocr_knn_ip_topk_screened2(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, const void* xb_bf16_blk_dev,
+                                 int64_t ntotal, int d, int k, float xnorm_max, float* dist_dev, int64_t* idx_dev, void* workspace_dev,
+                                 size_t workspace_bytes, void* stream);
 /* torch.nn.functional.normalize(x, p=2, dim=1) (infer_effocr.py:316; PML InferenceModel default) */
 int effocr_l2_normalize(const float* x_dev, int64_t n, int d, float* y_dev, void* stream);
 /* IndexFlat.remove_ids compaction (infer_effocr.py:211): dst[i] = src[keep_rows[i]] */

@@ -127,10 +127,11 @@ def test_l2_normalize_matches_oracle(dev):
 
 
 # ---------------------------------------------------------------- screened search (large indexes): bit-identical to the exact kernel
-def _both(dev, X, Q, k):
+def _both(dev, X, Q, k, use_qs=True):
     from effocr_amd.knn import IndexFlatIP
     ex = IndexFlatIP(X.shape[1], device=dev, screen=False)
     sc = IndexFlatIP(X.shape[1], device=dev, screen=True)
+    sc.use_qs = use_qs                                      # False: the screening kernels over the row-major bf16 copy (A/B switches of those)
     ex.add(X); sc.add(X)
     De, Ie = ex.search_device(Q, k)
     Ds, Is = sc.search_device(Q, k)
@@ -152,7 +153,7 @@ def test_screened_search_is_bit_identical(dev, N, D, B, k):
     L = _lib.lib()
     _lib.check(L.effocr_knn_set_option(b"two_pass_screen", 1), "knn_set_option")
     try:
-        _, _, D2, I2 = _both(dev, X, Q, k)
+        _, _, D2, I2 = _both(dev, X, Q, k, use_qs=False)
     finally:
         _lib.check(L.effocr_knn_set_option(b"two_pass_screen", 0), "knn_set_option")
     assert torch.equal(I2, Is) and torch.equal(D2.view(torch.int32), Ds.view(torch.int32))
@@ -186,10 +187,61 @@ def test_streaming_screen_is_bit_identical(dev, N, D, B, k):
     L = _lib.lib()
     _lib.check(L.effocr_knn_set_option(b"force_tile", 1), "knn_set_option")
     try:
-        _, _, D2, I2 = _both(dev, X, Q, k)
+        _, _, D2, I2 = _both(dev, X, Q, k, use_qs=False)
     finally:
         _lib.check(L.effocr_knn_set_option(b"force_tile", 0), "knn_set_option")
     assert torch.equal(I2, Is) and torch.equal(D2.view(torch.int32), Ds.view(torch.int32))
+
+
+@pytest.mark.parametrize("N,D,B,k", [(10_000, 384, 1024, 10), (10_000, 384, 64, 10), (9_999, 384, 128, 1), (10_000, 384, 1139, 1),
+                                     (70_001, 768, 300, 10), (5_000, 128, 40, 16), (300_000, 384, 513, 10), (64, 384, 5, 10),
+                                     (200_037, 768, 1024, 10), (777, 128, 257, 3)])
+def test_q_stationary_screen_is_bit_identical(dev, N, D, B, k):
+    """Round 5: with the fragment-blocked bf16 copy of the index the screening pass is knn_qs_kernel (queries stationary in registers,
+    index rows through an LDS-DMA ring) for EVERY index size — BASELINE configs[1]'s own 10 000 x 384 search at 1024 / 64 / 128 queries,
+    run_effocr's k = 1 call, configs[3]-like 768-wide rows, row counts that are not multiples of 64, query counts that are not
+    multiples of 32.  Ids and scores bit for bit those of the exact search AND of the round-4 screening kernels (A/B switch), exact
+    duplicates in ascending id order, a tight cluster, no overflow flag on benign data."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator(device=dev).manual_seed(N + D + B)
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    if N > 5000:
+        X[4000:4003] = X[50]                                 # exact duplicates: ascending id
+        X[3000:3008] = torch.nn.functional.normalize(X[3000:3001] + 2e-3 * torch.randn(8, D, generator=g, device=dev), dim=1)   # a tight cluster
+    X[N - 1] = X[min(50, N - 2)]                           # ... and one in the last (partial) 64-row pair
+    pick = torch.randint(0, N, (B,), generator=g, device=dev)
+    pick[0] = min(50, N - 2)
+    if B > 1:
+        pick[1] = 3000 if N > 5000 else 1
+    Q = torch.nn.functional.normalize(X[pick] + 0.05 * torch.randn(B, D, generator=g, device=dev), dim=1)
+    Q[0] = X[min(50, N - 2)]
+    ex = IndexFlatIP(D, device=dev, screen=False)
+    ex.add(X)
+    De, Ie = ex.search_device(Q, k)
+    sc = IndexFlatIP(D, device=dev, screen=True)
+    sc.add(X)
+    Ds, Is = sc.search_device(Q, k)
+    torch.cuda.synchronize()
+    assert sc._xblk is not None and sc._qs_ok(k)
+    assert torch.equal(Ie, Is) and torch.equal(De.view(torch.int32), Ds.view(torch.int32))
+    assert Is[0, 0].item() == min(50, N - 2)
+    if N >= 10_000:
+        assert _screen_flag(sc, B, k) == 0                  # the candidate lists did not overflow: no exact fallback ran
+    old = IndexFlatIP(D, device=dev, screen=True)
+    old.use_qs = False                                      # the round-4 screening kernels over the row-major copy
+    old.add(X)
+    Do, Io = old.search_device(Q, k)
+    assert old._xblk is None and torch.equal(Io, Is) and torch.equal(Do.view(torch.int32), Ds.view(torch.int32))
+    # another chunking of the same launch, and the list-keeping form of the pass (A/B switch: per-lane lists + merge / collect / re-rank
+    # instead of block maxima + threshold collect + block re-rank): identical
+    L = _lib.lib()
+    for opt, val, back in ((b"qs_wgs", 37, 0), (b"qs_pool", 0, 1)):
+        _lib.check(L.effocr_knn_set_option(opt, val), "knn_set_option")
+        try:
+            D3, I3 = sc.search_device(Q, k)
+        finally:
+            _lib.check(L.effocr_knn_set_option(opt, back), "knn_set_option")
+        assert torch.equal(I3, Is) and torch.equal(D3.view(torch.int32), Ds.view(torch.int32)), opt
 
 
 def test_screened_search_non_unit_rows_ties_and_overflow(dev):
@@ -252,10 +304,10 @@ def test_screened_auto_threshold_and_invalidation(dev):
     assert idx._use_screen(10, 65) and not idx._use_screen(10, 64)          # <= 64 queries (d <= 384): one launch of the exact streaming kernel
     q = idx._xb[:140].clone()
     D1, I1 = idx.search_device(q, 5)
-    assert idx._xb16 is not None and (I1[:, 0].cpu() == torch.arange(140)).all()
+    assert (idx._xb16 is not None or idx._xblk is not None) and (I1[:, 0].cpu() == torch.arange(140)).all()
     q = q[:4]
     idx.remove_ids(np.array([0]))
-    assert idx._xb16 is None
+    assert idx._xb16 is None and idx._xblk is None
     D2, I2 = idx.search_device(q[1:], 5)
     assert (I2[:, 0].cpu() == torch.arange(3)).all()        # rows shifted down by one
 
