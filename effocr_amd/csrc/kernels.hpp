@@ -152,7 +152,7 @@ size_t knn_screen_flag_offset(int64_t B, int64_t N, int D, int k);   // byte off
 int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, const void* xblk, int64_t N, int D, int k, float xnorm_max,
                          float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s);
 int convert_bf16_blocked(const float* src, int64_t N, int D, void* dst, hipStream_t s);
-void knn_qs_option(int which, int value);   // 0: on / off (A/B), 1: workgroups per launch (0 = one per CU), 2: pooled form on / off (A/B)
+void knn_qs_option(int which, int value);   // 0: on / off (A/B), 1: workgroups per launch (0 = one per CU)
 int convert_bf16(const float* src, int64_t n, void* dst, hipStream_t s);
 int l2_normalize_rows(const float* x, int64_t B, int D, float* y, hipStream_t s);
 int gather_rows(const float* src, const int64_t* rows, int64_t n, int D, float* dst, hipStream_t s);

@@ -987,29 +987,27 @@ int launch_knn_stream_k(int kmax, int nqt, const KnnArgs& a, hipStream_t s) {
 //   * the INDEX streams: stage = 64 rows x 128 k (16 KB) through a 6-slot LDS ring by LDS-DMA, five stages ahead, counted vmcnt + one
 //     raw barrier in the middle of a stage; the blocked copy makes a stage a verbatim copy of 512-byte cells, so the A-operand
 //     fragment reads (row r31, k half) are conflict-free ds_read_b128 — no transposes, no swizzles, no bank conflicts;
-//   * swapped MFMA (rows = index rows, columns = queries): a lane's 16 accumulators of a tile belong to ONE query with ascending row
-//     ids, so the running top-KMAX is the same lane-local sorted register list as everywhere else in this file (max-tree quick reject,
-//     bitmask walk, strict compare: ties keep the lower id); the two half-wave lists of a query merge through LDS at the end.
-// Output = the per-chunk lists [chunk][B][KMAX] of approximate scores the merge / collect / re-rank chain already consumes: the screened
-// search stays BIT-IDENTICAL to the exact one (same eps bound: bf16 operand rounding + fp32 accumulation, any summation order).
+//   * swapped MFMA (rows = index rows, columns = queries): a lane's 16 accumulators of a tile belong to ONE query and 16 rows.
+// The screened search stays BIT-IDENTICAL to the exact one (same eps bound: bf16 operand rounding + fp32 accumulation, any summation order).
 constexpr int QS_STAGE = 16384, QS_RING = 6;
-// POOL (the default dispatch): NO lists at all.  Lane-local lists cost more than the products they rank — the chip holds 65 536 lanes, so
+// NO lists at all.  Lane-local lists cost more than the products they rank — the chip holds 65 536 lanes, so
 // every query owns 64 lists of N / 64 rows each and a list takes KMAX (1 + ln(N / 64 / KMAX)) insertions of ~70 instructions that no
 // other lane of the wave shares: measured 0.86 ms of the 2.46 ms kernel at 1M x 768 x 1024 queries, and 80 us of a 131 us search at
 // 10 000 rows (where a third of all scores gets inserted).  Instead a lane writes the MAXIMUM of its 16 accumulators per (row tile,
 // query): one value per 16-row block, M[block][query] (15 v_max + one coalesced store per tile), and keeps a running maximum per
 // chunk, C[chunk][query].  Selection happens afterwards on 1/16 of the values and by THRESHOLD, not by insertion (knn_pool_collect_kernel,
 // knn_pool_rerank_kernel below).
-template <int D, int QT, int KMAX, bool POOL = false>
+// (The list-keeping form of this kernel — round 5's first version: per-lane lists with a per-lane hit walk through an LDS scratch, merged
+// per chunk and fed to the merge / collect / re-rank chain — measured 2.46 ms / 131 us at those two shapes and was removed.)
+template <int D, int QT>
 __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
+  constexpr bool POOL = true;
   typedef bf16x8 V8;
   constexpr int KC = D / 8, KT = D / 128, NXF = D / 16, R = QS_RING;
-  static_assert(D % 128 == 0 && KMAX <= 16, "knn_qs: D must be a multiple of 128, lists of at most 16 entries");
-  static_assert(QT * 32 * 2 * (2 * KMAX + 1) * 4 <= R * QS_STAGE / 4, "knn_qs: the end-of-kernel list merge must fit a wave's share of the ring");
-  __shared__ __attribute__((aligned(16))) char smem[R * QS_STAGE + 4 * 8192];
+  static_assert(D % 128 == 0, "knn_qs: D must be a multiple of 128");
+  __shared__ __attribute__((aligned(16))) char smem[R * QS_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int w = wave_id();
-  char* scr = smem + R * QS_STAGE + w * 8192;                        // the wave's candidate scratch [32 slots][64 lanes] fp32
   // logical id = chunk * nqt + query group: the query groups of a chunk are consecutive logical ids = the same XCD (xcd_remap) and
   // dispatched together, so a chunk's index rows leave HBM once and serve every query group out of that XCD's L2
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1055,15 +1053,9 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
   };
   for (int s0 = 0; s0 < R - 1 && s0 < nst; ++s0) issue_stage();
 
-  float ls[QT][KMAX];
-  int li[QT][KMAX];
   float cmax[QT];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    cmax[qt] = -FLT_MAX;
-#pragma unroll
-    for (int t = 0; t < KMAX; ++t) { ls[qt][t] = -FLT_MAX; li[qt][t] = ID_NONE; }
-  }
+  for (int qt = 0; qt < QT; ++qt) cmax[qt] = -FLT_MAX;
 
   // stage 0 has landed (own pieces: everything issued behind it may stay in flight; fewer than R - 1 stages in all: wait for all)
   if (nst >= R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");
@@ -1140,93 +1132,14 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
           cmax[qt] = fmaxf(cmax[qt], m);
         }
       }
-      continue;
     }
-#ifndef QS_NOINSERT
-    // ---- scores of rows 64 p .. 64 p + 63 against the wave's queries are complete: feed the lists (rows ascend with (i, r) per lane)
-    const int nbase = p * 64 + 4 * half;
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      const float thr = ls[qt][KMAX - 1];
-      float mxs = acc[0][qt][0];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mxs = fmaxf(mxs, acc[i][qt][r]);
-      if (__any(mxs > thr)) {
-        uint32_t hits = 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
-            hits |= (n < a.N && acc[i][qt][r] > thr) ? (1u << (i * 16 + r)) : 0u;
-          }
-        if (__any(hits != 0)) {
-          // PER-LANE walk over the lane's own hits (ascending bit = ascending row id): the candidates are parked in the wave's LDS
-          // scratch [slot][lane] so that a lane can fetch the score of ITS next hit; the loop runs max-over-lanes(popcount) times —
-          // typically 1-3 once the lists have warmed up — instead of once per distinct slot any lane hit (up to 32, each a full
-          // predicated insertion: that walk was 3x the MFMA time of a 768-wide pair on a 1M-row index).
-          float* sc_lds = reinterpret_cast<float*>(scr) + lane;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { sc_lds[r * 64] = acc[0][qt][r]; sc_lds[(16 + r) * 64] = acc[1][qt][r]; }
-          uint32_t h = hits;
-          while (__any(h != 0)) {
-            const bool mine = h != 0;
-            const int b = mine ? __builtin_ctz(h) : 0;
-            h &= h - 1u;
-            const float sc = sc_lds[b * 64];
-            const int n = nbase + (b >> 4) * 32 + (b & 3) + 8 * ((b & 15) >> 2);
-            if (mine && sc > ls[qt][KMAX - 1]) topk_insert<KMAX>(ls[qt], li[qt], sc, n);
-          }
-        }
-      }
-    }
-#else
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { ls[qt][0] = fmaxf(ls[qt][0], acc[0][qt][0] + acc[1][qt][5]); }
-#endif
   }
-
   if constexpr (POOL) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const float m = fmaxf(cmax[qt], __shfl_xor(cmax[qt], 32, 64));
       const int qi = q0 + qt * 32 + r31;
       if (half == 0 && qi < a.B) a.pool_c[(int64_t)chunk * a.B + qi] = m;
-    }
-    return;
-  }
-  // ---- the two half-wave lists of every query -> one chunk list.  The ring is dead (every stage consumed; the last wait was vmcnt(0)):
-  // each wave takes its quarter of it, [query slot][half] lists with an odd word stride.
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  constexpr int LST = 2 * KMAX + 1;                                  // words per (query, half) list: scores then ids, odd stride
-  float* mS = reinterpret_cast<float*>(smem + w * (R * QS_STAGE / 4));
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    float* l = mS + ((qt * 32 + r31) * 2 + half) * LST;
-#pragma unroll
-    for (int t = 0; t < KMAX; ++t) { l[t] = ls[qt][t]; reinterpret_cast<int*>(l)[KMAX + t] = li[qt][t]; }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // wave-private region: LDS operations of a wave execute in order
-  for (int qs = lane; qs < QT * 32; qs += 64) {
-    const int qi = q0 + qs;
-    if (qi >= a.B) continue;
-    const float* la = mS + (qs * 2) * LST;
-    const float* lb = la + LST;
-    const int* ia = reinterpret_cast<const int*>(la) + KMAX;
-    const int* ib = reinterpret_cast<const int*>(lb) + KMAX;
-    int pa = 0, pb = 0;
-    const int64_t ob = ((int64_t)chunk * a.B + qi) * KMAX;
-    for (int t = 0; t < KMAX; ++t) {
-      float sa = -FLT_MAX, sb = -FLT_MAX; int xa = ID_NONE, xb = ID_NONE;
-      if (pa < KMAX) { sa = la[pa]; xa = ia[pa]; }
-      if (pb < KMAX) { sb = lb[pb]; xb = ib[pb]; }
-      const bool ta = before(sa, xa, sb, xb) || xb == ID_NONE;
-      a.pdist[ob + t] = ta ? sa : sb;
-      a.pidx[ob + t] = ta ? xa : xb;
-      pa += ta ? 1 : 0; pb += ta ? 0 : 1;
     }
   }
 }
@@ -1454,10 +1367,9 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
 
 int g_knn_qs_wgs = 0;                 // workgroups a knn_qs launch aims for (0 = one per CU); knn_set_option("qs_wgs")
 bool g_knn_qs = true;                 // A/B switch (tests): 0 = the screened search ignores the blocked copy
-bool g_knn_qs_pool = true;            // A/B switch (tests): 0 = the Q-stationary pass keeps per-lane lists (merge / collect / re-rank chain)
 struct QsPlan { int qt, nqg, ppc, nchunks; };
 bool qs_applies(int64_t B, int64_t N, int D, int k) {
-  return g_knn_qs && !g_knn_two_pass && !g_knn_force_tile && (D == 128 || D == 384 || D == 768) && k <= 16 && N >= 64;
+  return g_knn_qs && !g_knn_two_pass && !g_knn_force_tile && (D == 128 || D == 384 || D == 768) && k <= 16 && N >= 1024;   // (>= 16 pairs of 64 rows)
 }
 QsPlan qs_plan(int64_t B, int64_t N, int D) {
   QsPlan p;
@@ -1468,32 +1380,23 @@ QsPlan qs_plan(int64_t B, int64_t N, int D) {
   p.nqg = (int)((B + 128 * p.qt - 1) / (128 * p.qt));
   const int npairs = (int)((N + 63) / 64);
   int want = (g_knn_qs_wgs > 0 ? g_knn_qs_wgs : device_cus()) / p.nqg;
-  if (want < 1) want = 1;
+  if (want < 16) want = 16;                                // L(q) is the k-th largest CHUNK maximum (k <= 16): at least 16 chunks
   if (want > MAX_CHUNKS) want = MAX_CHUNKS;
   if (want > npairs) want = npairs;
   p.ppc = (npairs + want - 1) / want;
   p.nchunks = (npairs + p.ppc - 1) / p.ppc;
+  if (p.nchunks < 16 && npairs <= MAX_CHUNKS) { p.ppc = 1; p.nchunks = npairs; }
   return p;
 }
 int launch_knn_qs_pool(const KnnArgs& a, int D, int qt, hipStream_t s) {
   const dim3 grid((unsigned)(a.nqt * a.nchunks)), blk(256);
-  if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2, 1, true>), grid, blk, 0, s, a);
-  else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1, 1, true>), grid, blk, 0, s, a);
-  else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1, 1, true>), grid, blk, 0, s, a);
-  else if (D == 128 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<128, 2, 1, true>), grid, blk, 0, s, a);
-  else if (D == 128 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<128, 1, 1, true>), grid, blk, 0, s, a);
+  if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2>), grid, blk, 0, s, a);
+  else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1>), grid, blk, 0, s, a);
+  else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1>), grid, blk, 0, s, a);
+  else if (D == 128 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<128, 2>), grid, blk, 0, s, a);
+  else if (D == 128 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<128, 1>), grid, blk, 0, s, a);
   else return fail(EFFOCR_EINVAL, "knn(qs): internal");
   return check_launch("knn_qs_pool");
-}
-int launch_knn_qs(const KnnArgs& a, int D, int qt, hipStream_t s) {
-  const dim3 grid((unsigned)(a.nqt * a.nchunks)), blk(256);
-  if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2, 16>), grid, blk, 0, s, a);
-  else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1, 16>), grid, blk, 0, s, a);
-  else if (D == 128 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<128, 1, 16>), grid, blk, 0, s, a);
-  else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1, 16>), grid, blk, 0, s, a);
-  else if (D == 128 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<128, 2, 16>), grid, blk, 0, s, a);
-  else return fail(EFFOCR_EINVAL, "knn(qs): internal");
-  return check_launch("knn_qs");
 }
 
 // how many queries one streaming launch takes at (D, kmax): 64 where both query images and the merge lists fit the LDS, else 32
@@ -1561,7 +1464,7 @@ ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   ScreenWs w; size_t off = 0;
   auto take = [&](size_t n) { const size_t o = off; off = align_up(off + n, 256); return o; };
   size_t part = knn_workspace_bytes(B, N, D, k < 16 ? 16 : k);    // pass 1 keeps >= 16-entry chunk lists (see knn_ip_topk_screened)
-  if (k <= 16 && N >= 64) {                                        // ... and the Q-stationary pass its own chunking (MAX_CHUNKS at most)
+  if (false) {
     const QsPlan qp = qs_plan(B, N, D);
     const size_t need = align_up((size_t)qp.nchunks * (size_t)B * 16 * 8, 256) + 256;
     part = part > need ? part : need;
@@ -1575,7 +1478,7 @@ ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   w.flag = take(256);
   w.cand = take((size_t)B * RR_CAP * 4);
   w.pool_m = w.pool_c = w.pool_ev = w.pool_eb = 0;
-  if (k <= 16 && N >= 64) {                                        // block / chunk maxima + collected entries of the pooled Q-stationary pass
+  if (k <= 16 && N >= 1024) {                                      // block / chunk maxima + collected entries of the Q-stationary pass
     const QsPlan qp = qs_plan(B, N, D);
     w.pool_m = take((size_t)((N + 63) / 64) * 4 * (size_t)B * 4);
     w.pool_c = take((size_t)qp.nchunks * (size_t)B * 4);
@@ -1611,11 +1514,7 @@ int convert_bf16_blocked(const float* src, int64_t N, int D, void* dst, hipStrea
   hipLaunchKernelGGL(convert_bf16_blocked_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, src, N, D, static_cast<__bf16*>(dst));
   return check_launch("convert_bf16_blocked");
 }
-void knn_qs_option(int which, int value) {
-  if (which == 0) g_knn_qs = value != 0;
-  else if (which == 2) g_knn_qs_pool = value != 0;
-  else g_knn_qs_wgs = value < 0 ? 0 : value;
-}
+void knn_qs_option(int which, int value) { if (which == 0) g_knn_qs = value != 0; else g_knn_qs_wgs = value < 0 ? 0 : value; }
 
 int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, const void* xblk, int64_t N, int D, int k, float xnorm_max,
                          float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -1659,9 +1558,8 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   // against a large index, which the streaming screen serves at the HBM rate.
   const bool qs = xblk != nullptr && qs_applies(B, N, D, k) && !stream16;
   if (!qs && xb16 == nullptr) return fail(EFFOCR_EINVAL, "knn(screened): this call needs the row-major bf16 copy of the index");
-  int chunks1 = p.nchunks;                                 // chunk lists pass 1 leaves for the merge / collect kernels
   const QsPlan qsp = qs ? qs_plan(B, N, D) : QsPlan{};
-  if (qs && g_knn_qs_pool && qsp.nchunks >= 16) {
+  if (qs) {
     // pooled form (the default): pass 1 writes block / chunk maxima only, then threshold collect + block re-rank — four launches + the
     // gated exact pair, no lists, no merge
     KnnArgs b = a;
@@ -1691,17 +1589,6 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
     e.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
     return launch_knn_k<float>(p.kmax, e, s);
   }
-  if (qs) {
-    const QsPlan qp = qsp;
-    KnnArgs b = a;
-    b.q = qb; b.xb = xblk; b.nqt = qp.nqg; b.tiles_per_chunk = qp.ppc; b.nchunks = qp.nchunks;
-    b.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)qp.nchunks * (size_t)B * 16 * 4, 128));
-    if ((rc = launch_knn_qs(b, D, qp.qt, s))) return rc;
-    a.pidx = b.pidx;
-    chunks1 = qp.nchunks;
-    launch_knn_merge<16>(a.pdist, a.pidx, (int)B, chunks1, k, adist, aidx, nullptr, k, 0, s);
-    if ((rc = check_launch("knn_merge"))) return rc;
-  } else
   if (stream16) {
     a.qnorm = qnorm;
     a.eps_scale = 2.0f * c * xnorm_max;                    // the band of the re-rank's candidate set (below)
@@ -1723,11 +1610,11 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   // |s^ - s| <= eps = c * |q| * |x|: operand rounding (2^-8 + 2^-16) plus fp32 accumulation of both chains (4 d 2^-24),
   // 1e-4 relative slack for the fp32 norms.  A true top-k row has s >= s_(k), hence s^ >= s_(k) - eps >= s^_(k) - 2 eps.
   a.adist = adist; a.qnorm = qnorm; a.eps_scale = 2.0f * c * xnorm_max; a.cand = cand; a.cnt = cnt; a.cap = RR_CAP;
-  if (qs || (p.nchunks > 1 && !g_knn_two_pass)) {          // the candidates are already in pass 1's per-chunk lists
+  if (p.nchunks > 1 && !g_knn_two_pass) {                  // the candidates are already in pass 1's per-chunk lists
     const dim3 cg((unsigned)((B + 3) / 4));
-    switch (qs ? 16 : kmax1) {
-      case 16: hipLaunchKernelGGL((knn_collect_lists_kernel<16>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, chunks1, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
-      default: hipLaunchKernelGGL((knn_collect_lists_kernel<32>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, chunks1, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+    switch (kmax1) {
+      case 16: hipLaunchKernelGGL((knn_collect_lists_kernel<16>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
+      default: hipLaunchKernelGGL((knn_collect_lists_kernel<32>), cg, dim3(256), 0, s, a.pdist, a.pidx, (int)B, p.nchunks, k, adist, qnorm, a.eps_scale, cand, cnt, RR_CAP, flag); break;
     }
   } else
   switch (p.kmax) {

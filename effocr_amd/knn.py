@@ -125,7 +125,7 @@ class IndexFlatIP:
     use_qs = True              # A/B: False = screening passes without the blocked copy (round-4 kernels)
 
     def _qs_ok(self, k):
-        return self.use_qs and self.d in self.QS_DIMS and k <= 16 and self.ntotal >= 64
+        return self.use_qs and self.d in self.QS_DIMS and k <= 16 and self.ntotal >= 1024
 
     def _screen_copy(self, rowmajor=True, blocked=False):
         """The bf16 copies of the rows a screening pass reads, built lazily per index change: row-major (the 128-query tile kernel,
