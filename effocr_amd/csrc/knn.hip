@@ -990,6 +990,7 @@ int launch_knn_stream_k(int kmax, int nqt, const KnnArgs& a, hipStream_t s) {
 //   * swapped MFMA (rows = index rows, columns = queries): a lane's 16 accumulators of a tile belong to ONE query and 16 rows.
 // The screened search stays BIT-IDENTICAL to the exact one (same eps bound: bf16 operand rounding + fp32 accumulation, any summation order).
 constexpr int QS_STAGE = 16384, QS_RING = 6;
+constexpr int QS_NSUB = 8;            // sub-chunk maxima per chunk (pass 1 -> knn_pool_bound_kernel)
 // NO lists at all.  Lane-local lists cost more than the products they rank — the chip holds 65 536 lanes, so
 // every query owns 64 lists of N / 64 rows each and a list takes KMAX (1 + ln(N / 64 / KMAX)) insertions of ~70 instructions that no
 // other lane of the wave shares: measured 0.86 ms of the 2.46 ms kernel at 1M x 768 x 1024 queries, and 80 us of a 131 us search at
@@ -1016,6 +1017,7 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
   const int p0 = chunk * a.tiles_per_chunk;                          // 64-row pairs [p0, p1) of this chunk
   const int p1 = min(p0 + a.tiles_per_chunk, npairs);
   const int nst = (p1 - p0) * KT;                                    // ring stages of this workgroup (>= KT)
+  const int sublen = (a.tiles_per_chunk + QS_NSUB - 1) / QS_NSUB;    // pairs per sub-chunk (the maxima the bound L(q) is taken over)
   const char* Xb = static_cast<const char*>(a.xb);
   const __bf16* Q = static_cast<const __bf16*>(a.q);
 
@@ -1132,16 +1134,26 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
           cmax[qt] = fmaxf(cmax[qt], m);
         }
       }
+      // end of a sub-chunk (QS_NSUB per chunk): its maximum per query -> C[chunk * QS_NSUB + sub][q], running maximum reset
+      if ((p - p0 + 1) % sublen == 0 || p == p1 - 1) {
+        const int sub = (p - p0) / sublen;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const float m = fmaxf(cmax[qt], __shfl_xor(cmax[qt], 32, 64));
+          const int qi = q0 + qt * 32 + r31;
+          if (half == 0 && qi < a.B) a.pool_c[(int64_t)(chunk * QS_NSUB + sub) * a.B + qi] = m;
+          cmax[qt] = -FLT_MAX;
+        }
+      }
     }
   }
-  if constexpr (POOL) {
+  // sub-chunk slots this chunk did not reach (a short last chunk): no block there
+  for (int sub = (p1 - p0 + sublen - 1) / sublen; sub < QS_NSUB; ++sub)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      const float m = fmaxf(cmax[qt], __shfl_xor(cmax[qt], 32, 64));
       const int qi = q0 + qt * 32 + r31;
-      if (half == 0 && qi < a.B) a.pool_c[(int64_t)chunk * a.B + qi] = m;
+      if (half == 0 && qi < a.B) a.pool_c[(int64_t)(chunk * QS_NSUB + sub) * a.B + qi] = -FLT_MAX;
     }
-  }
 }
 
 // fp32 [N][D] row-major -> bf16 fragment-blocked [ceil(N / 64) * 2][D / 8][32][8]; rows >= N are zero.  One thread per 16-byte cell slot.
@@ -1173,47 +1185,40 @@ __global__ __launch_bounds__(256) void convert_bf16_blocked_kernel(const float* 
 //   rerank   per query: m_k = the k-th largest collected value (all blocks >= L - 2 eps are there, so the k largest are), survivors =
 //            entries >= m_k - 2 eps, exact ascending-k fmaf chains of the survivors' 16 rows each, (score desc, id asc) top k.
 // Results stay bit-identical to the exact search: the candidate ROWS are a superset of the true top k, their scores the product's own.
-constexpr int POOL_CAP = 256;          // collected blocks per query
-constexpr int POOL_ROWS = 1024;        // rows re-ranked per query (64 surviving blocks)
-template <int KSEL>
-__global__ __launch_bounds__(256) void knn_pool_collect_kernel(const float* __restrict__ M, const float* __restrict__ C, int B, int nblk, int nchunks,
-                                                               int k, int blk_per_wg, const float* __restrict__ qnorm, float eps_scale,
-                                                               float* __restrict__ evalue, int* __restrict__ eblk, int* __restrict__ cnt,
-                                                               int* __restrict__ flag) {
+constexpr int POOL_CAP = 512;          // collected blocks per query
+constexpr int POOL_ROWS = 2048;        // rows re-scored per query in stage A (128 surviving blocks; the 2 eps band of a 768-wide index holds
+                                       // 35 rows on average and 58 at most over 256 queries against 1M random rows — each in its own block)
+// thr[q] = L(q) - 2 eps(q), L = the k-th largest of the nsub sub-chunk maxima of the query.  One workgroup per query, by RANK COUNTING:
+// a thread holds one value (nsub <= 256: BASELINE configs[1] and [3] alike; more: several) and counts the values that rank before it —
+// one memory round trip and a 256-step LDS loop (a per-lane sorted list over 64 queries per workgroup took 24 us on 16 workgroups).
+__global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __restrict__ C, int B, int nsub, int k, const float* __restrict__ qnorm,
+                                                             float eps_scale, float* __restrict__ thr) {
+  __shared__ float sC[MAX_CHUNKS * QS_NSUB];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < nsub; e += 256) sC[e] = C[(int64_t)e * B + q];
+  __syncthreads();
+  const int kk = k < nsub ? k : nsub;
+  for (int e = tid; e < nsub; e += 256) {
+    const float v = sC[e];
+    int rank = 0;
+    for (int j = 0; j < nsub; ++j) { const float u = sC[j]; rank += (u > v || (u == v && j < e)) ? 1 : 0; }
+    if (rank == kk - 1) thr[q] = v - eps_scale * qnorm[q];
+  }
+}
+
+// Workgroup = 64 queries (lane = query: coalesced rows of M) x a range of blocks, 4 waves x 8 loads in flight.
+__global__ __launch_bounds__(256) void knn_pool_collect_kernel(const float* __restrict__ M, const float* __restrict__ thrq, int B, int nblk,
+                                                               int blk_per_wg, float* __restrict__ evalue, int* __restrict__ eblk,
+                                                               int* __restrict__ cnt, int* __restrict__ flag) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int q = blockIdx.y * 64 + lane;
   const bool qok = q < B;
   const int qc = qok ? q : B - 1;
-  // L(q): k-th largest of the chunk maxima — a sorted k-entry list per lane over <= 256 values, loaded eight at a time (one
-  // dependent round trip per value made this prologue most of the kernel on a 10 000-row index)
-  float top[KSEL];
-#pragma unroll
-  for (int t = 0; t < KSEL; ++t) top[t] = -FLT_MAX;
-  for (int c0 = 0; c0 < nchunks; c0 += 8) {
-    float cv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) cv[u] = (c0 + u < nchunks) ? C[(int64_t)(c0 + u) * B + qc] : -FLT_MAX;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float v = cv[u];
-      if (__any(v > top[KSEL - 1])) {
-#pragma unroll
-        for (int t = KSEL - 1; t >= 1; --t) {
-          const bool gp = v > top[t - 1], g = v > top[t];
-          top[t] = gp ? top[t - 1] : (g ? v : top[t]);
-        }
-        top[0] = v > top[0] ? v : top[0];
-      }
-    }
-  }
-  float L = top[0];
-#pragma unroll
-  for (int t = 1; t < KSEL; ++t) L = (t < k) ? top[t] : L;            // top[k - 1]
-  const float thr = L - eps_scale * qnorm[qc];
+  const float thr = thrq[qc];
   const int b0 = blockIdx.x * blk_per_wg;
   int b1 = b0 + blk_per_wg;
   b1 = b1 < nblk ? b1 : nblk;
-  for (int b = b0 + w; b < b1; b += 32) {                             // 4 waves x 8 loads in flight
+  for (int b = b0 + w; b < b1; b += 32) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = (b + 4 * u < b1) ? M[(int64_t)(b + 4 * u) * B + qc] : -FLT_MAX;
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(256) void knn_pool_collect_kernel(const float* __re
 // score, so a true top-k row still has s^' >= tau — and only the rows that pass go to stage B, the exact ascending-k fmaf chain over the
 // fp32 row (1.5 - 3 KB scattered per row: re-ranking all 16 rows of every block exactly was 131 us of BASELINE configs[1]'s search and
 // 0.7 ms at 1M x 768 x 1024 queries).
-constexpr int POOL_EXACT = 256;        // rows re-ranked exactly per query
+constexpr int POOL_EXACT = 512;        // rows re-ranked exactly per query
 template <int D>
 __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __restrict__ q, const float* __restrict__ xb, const char* __restrict__ xblk,
                                                               int N, int k, const float* __restrict__ evalue, const int* __restrict__ eblk,
@@ -1253,12 +1258,11 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
   if (n > POOL_CAP) { if (tid == 0) atomicOr(flag, 1); return; }     // (the collect kernel raised the flag already)
   if (tid == 0) { sN = 0; sN2 = 0; sTau = -FLT_MAX; }
   for (int d = tid; d < D; d += 256) sQ[d] = q[(int64_t)qg * D + d];
-  float v = -FLT_MAX; int b = -1;
-  if (tid < n) { v = evalue[(int64_t)qg * POOL_CAP + tid]; b = eblk[(int64_t)qg * POOL_CAP + tid]; }
-  sV[tid] = v; sB[tid] = b;
+  for (int e = tid; e < n; e += 256) { sV[e] = evalue[(int64_t)qg * POOL_CAP + e]; sB[e] = eblk[(int64_t)qg * POOL_CAP + e]; }
   __syncthreads();
-  // rank of this entry among the collected values (ties by block id): the entry of rank k - 1 is m_k
-  if (tid < n) {
+  // rank of an entry among the collected values (ties by block id): the entry of rank k - 1 is m_k
+  for (int e = tid; e < n; e += 256) {
+    const float v = sV[e]; const int b = sB[e];
     int rank = 0;
     for (int j = 0; j < n; ++j) rank += (sV[j] > v || (sV[j] == v && sB[j] < b)) ? 1 : 0;
     const int kk = k < n ? k : n;                                      // fewer than k blocks in the whole index: everything survives
@@ -1266,10 +1270,11 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
   }
   __syncthreads();
   const float tau = sTau;
-  if (tid < n && v >= tau) {
-    const int pos = atomicAdd(&sN, 1);
-    if (pos < POOL_ROWS / 16) sSurv[pos] = b;
-  }
+  for (int e = tid; e < n; e += 256)
+    if (sV[e] >= tau) {
+      const int pos = atomicAdd(&sN, 1);
+      if (pos < POOL_ROWS / 16) sSurv[pos] = sB[e];
+    }
   __syncthreads();
   const int ns = sN;
   if (ns > POOL_ROWS / 16) { if (tid == 0) atomicOr(flag, 1); return; }   // overflow: the gated exact pass recomputes everything
@@ -1319,10 +1324,13 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
   // ---- stage B: exact scores (the ascending-k fmaf chain) of the rows that passed.  One thread per row; the chain is serial but its
   // LOADS are not: 64 floats of the row are requested at once (an 8-load batch per 16 FMAs left the thread waiting out a memory round
   // trip per batch: 24 round trips per 384-wide row were most of this kernel), the query comes from LDS (broadcast reads).
-  {
+  float scB[POOL_EXACT / 256]; int idB[POOL_EXACT / 256];
+#pragma unroll
+  for (int rr = 0; rr < POOL_EXACT / 256; ++rr) {
     float sc = -FLT_MAX; int id = ID_NONE;
-    if (tid < n2) {
-      id = sI[tid];
+    const int tix = tid + 256 * rr;
+    if (tix < n2) {
+      id = sI[tix];
       const float* xr = xb + (int64_t)id * D;
       sc = 0.f;
 #pragma unroll 1
@@ -1337,9 +1345,11 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
         }
       }
     }
-    __syncthreads();                                                 // (sI is re-written below: every id has been read)
-    sS[tid] = sc; sI[tid] = id;
+    scB[rr] = sc; idB[rr] = id;
   }
+  __syncthreads();                                                   // (sI is re-written below: every id has been read)
+#pragma unroll
+  for (int rr = 0; rr < POOL_EXACT / 256; ++rr) { sS[tid + 256 * rr] = scB[rr]; sI[tid + 256 * rr] = idB[rr]; }
   __syncthreads();
   if (tid >= 64) return;
   constexpr int PER = POOL_EXACT / 64;
@@ -1481,7 +1491,7 @@ ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   if (k <= 16 && N >= 1024) {                                      // block / chunk maxima + collected entries of the Q-stationary pass
     const QsPlan qp = qs_plan(B, N, D);
     w.pool_m = take((size_t)((N + 63) / 64) * 4 * (size_t)B * 4);
-    w.pool_c = take((size_t)qp.nchunks * (size_t)B * 4);
+    w.pool_c = take((size_t)qp.nchunks * QS_NSUB * (size_t)B * 4);
     w.pool_ev = take((size_t)B * POOL_CAP * 4);
     w.pool_eb = take((size_t)B * POOL_CAP * 4);
   }
@@ -1575,7 +1585,10 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
     const dim3 cg((unsigned)((nblk + per - 1) / per), (unsigned)nqb);
     float* ev = reinterpret_cast<float*>(W + w.pool_ev); int* eb = reinterpret_cast<int*>(W + w.pool_eb);
     const float es = 2.0f * c * xnorm_max;
-    hipLaunchKernelGGL((knn_pool_collect_kernel<16>), cg, dim3(256), 0, s, b.pool_m, b.pool_c, (int)B, nblk, qsp.nchunks, k, per, qnorm, es, ev, eb, cnt, flag);
+    float* thr = reinterpret_cast<float*>(W + w.adist);     // (the approximate top-k area is free on this path)
+    hipLaunchKernelGGL(knn_pool_bound_kernel, dim3((unsigned)B), dim3(256), 0, s, b.pool_c, (int)B, qsp.nchunks * QS_NSUB, k, qnorm, es, thr);
+    if ((rc = check_launch("knn_pool_bound"))) return rc;
+    hipLaunchKernelGGL(knn_pool_collect_kernel, cg, dim3(256), 0, s, b.pool_m, thr, (int)B, nblk, per, ev, eb, cnt, flag);
     if ((rc = check_launch("knn_pool_collect"))) return rc;
     const char* xk = static_cast<const char*>(xblk);
     if (D == 384) hipLaunchKernelGGL((knn_pool_rerank_kernel<384>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
