@@ -511,6 +511,31 @@ def small_batch_extras(a, enc, knn, sd, dev):
     x64 = torch.randn(64, 3, 224, 224, device=dev)
     t = _time_gpu(lambda: knn(enc.forward(x64, normalize=True), k=a.k), dev, 30)
     out["b64_device_resident"] = {"crops_per_s": round(64 / t, 1), "ms_per_call": round(1e3 * t, 3)}
+    # the reference's ONNX driver runs its 64-crop batches from N threads sharing ONE engine (infer_effocr_onnx_multi.py:207-223,350-364):
+    # the same device-resident call from 2 / 4 Python threads, each on its own HIP stream (per-stream workspaces; a 64-crop kernel fills
+    # at most 3/4 of the CUs, two streams' kernels overlap on the device)
+    for nthr in (2, 4):
+        calls = 40
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nthr)]
+        xs = [torch.randn(64, 3, 224, 224, device=dev) for _ in range(nthr)]
+
+        def run(i, n):
+            with torch.cuda.stream(streams[i]):
+                for _ in range(n):
+                    knn(enc.forward(xs[i], normalize=True), k=a.k)
+                streams[i].synchronize()
+        for i in range(nthr):
+            run(i, 2)
+        torch.cuda.synchronize(dev)
+        ths = [threading.Thread(target=run, args=(i, calls)) for i in range(nthr)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize(dev)
+        tt = time.perf_counter() - t0
+        out[f"b64_device_resident_{nthr}_streams"] = {"crops_per_s": round(64 * calls * nthr / tt, 1), "ms_per_call_per_stream": round(1e3 * tt / calls, 3)}
     eng = EffRecognizer(sd, arch=a.arch, precision=a.precision, device=dev, lanes=2)
     batch = np.random.default_rng(0).standard_normal((64, 3, 224, 224), dtype=np.float32)
     eng.run(batch)

@@ -931,6 +931,7 @@ int effocr_knn_set_option(const char* name, int value) {
   if (std::string(name) == "q16_tile") { knn_q16_tile(value); return EFFOCR_OK; }
   if (std::string(name) == "qs") { knn_qs_option(0, value); return EFFOCR_OK; }
   if (std::string(name) == "qs_wgs") { knn_qs_option(1, value); return EFFOCR_OK; }
+  if (std::string(name) == "stream_min_rows") { knn_qs_option(3, value); return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, std::string("knn_set_option: unknown option '") + name + "'");
 }
 

@@ -35,6 +35,7 @@ using namespace tile128;
 int g_knn_wg_target = 1024;          // workgroups a launch aims for (2 resident per CU); knn_set_option("wg_target")
 bool g_knn_force_tile = false;        // A/B switch (tests): 1 = always the 128-query tile kernel
 bool g_knn_q16 = true;                // A/B switch (tests): 0 = calls of <= 16 queries on the 32-wide tile as well
+int g_knn_stream_min_rows = 65536;    // 33..128 queries: index rows from which the streaming kernel (not the tile kernel) runs; knn_set_option("stream_min_rows")
 bool g_knn_two_pass = false;          // A/B switch (tests): 1 = screened search collects its candidates with a second scan of the index
 constexpr int ID_NONE = INT_MAX;          // internal sentinel id (ranks after every real id)
 constexpr int MAX_CHUNKS = 256;
@@ -1454,7 +1455,7 @@ int knn_ip_topk(const float* q, int64_t B, const float* xb, int64_t N, int D, in
   // chunking, same merge, same bits.  (Above that the 128-query tile kernel amortises the index traffic better.)
   const int sq = stream_queries(D, p.kmax);
   // (33..128 queries pay off only where the index does not fit the caches: at 10 k rows the tile kernel is faster, measured)
-  if (B <= 2 * sq && N >= (B <= 32 ? 4096 : 65536) && D % 128 == 0 && D <= 768 && !g_knn_force_tile) {
+  if (B <= 2 * sq && N >= (B <= 32 ? 4096 : g_knn_stream_min_rows) && D % 128 == 0 && D <= 768 && !g_knn_force_tile) {
     for (int64_t q0 = 0; q0 < B; q0 += sq) {
       KnnArgs b = a;
       b.B = (int)(B - q0 < sq ? B - q0 : sq);
@@ -1524,7 +1525,11 @@ int convert_bf16_blocked(const float* src, int64_t N, int D, void* dst, hipStrea
   hipLaunchKernelGGL(convert_bf16_blocked_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, src, N, D, static_cast<__bf16*>(dst));
   return check_launch("convert_bf16_blocked");
 }
-void knn_qs_option(int which, int value) { if (which == 0) g_knn_qs = value != 0; else g_knn_qs_wgs = value < 0 ? 0 : value; }
+void knn_qs_option(int which, int value) {
+  if (which == 0) g_knn_qs = value != 0;
+  else if (which == 3) g_knn_stream_min_rows = value < 4096 ? 4096 : value;
+  else g_knn_qs_wgs = value < 0 ? 0 : value;
+}
 
 int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void* xb16, const void* xblk, int64_t N, int D, int k, float xnorm_max,
                          float* dist, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t s) {

@@ -201,7 +201,12 @@ int effocr_convert_bf16(const float* src_dev, int64_t n, void* dst_dev, void* st
  * ring as verbatim 512-byte cells (conflict-free fragment reads, no transposes), per-lane register top-k lists — for EVERY index size:
  * BASELINE configs[1]'s own 10 000-row search and configs[3]'s 1M x 768 alike.  xb_bf16_dev (row-major copy) may be NULL then, except
  * for calls of 17..128 queries against >= 65 536 rows, which keep the streaming screen when it is given.  Results are bit-identical to
- * effocr_knn_ip_topk either way.  effocr_knn_set_option: "qs" [1] (0: ignore the blocked copy, A/B), "qs_wgs" [0 = one per CU]. */
+ * effocr_knn_ip_topk either way.  The pass writes only the MAXIMUM approximate score per 16-row block (and per sub-chunk); a rank-count
+ * kernel turns the sub-chunk maxima into a per-query threshold, a collect kernel gathers the blocks above it, and the re-rank kernel
+ * re-scores their rows from the blocked copy before the exact fmaf chains.  Workspace: effocr_knn_screen_workspace_bytes
+ * (it includes the block maxima: ntotal / 16 * nq * 4 bytes).  effocr_knn_set_option: "qs" [1] (0: ignore the blocked copy, A/B),
+ * "qs_wgs" [0 = one per CU], "stream_min_rows" [65536] (33..128 queries: index rows from which effocr_knn_ip_topk streams the index
+ * instead of running the tile kernel; measured slower below, tools/knn_small_time.py). */
 size_t effocr_bf16_blocked_bytes(int64_t n_rows, int d);
 int effocr_convert_bf16_blocked(const float* src_dev, int64_t n_rows, int d, void* dst_dev, void* stream);
 int effocr_knn_ip_topk_screened2(const float* q_dev, int64_t nq, const float* xb_dev, const void* xb_bf16_dev, const void* xb_bf16_blk_dev,

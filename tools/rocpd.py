@@ -9,6 +9,8 @@ import json, os, re, sqlite3, sys
 
 CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
     ("qkvattn_kernel", "qkv_attn_fused"), ("patch_embed_kernel", "patch_embed_fused"), ("knn_stream_kernel", "knn_stream"), ("knn_rerank", "knn_rerank"), ("knn_prep", "knn_prep"),
+    ("knn_qs_kernel", "knn_qs_screen"), ("knn_pool_bound", "knn_pool_bound"), ("knn_pool_collect", "knn_pool_collect"), ("knn_pool_rerank", "knn_pool_rerank"),
+    ("convert_bf16_blocked", "convert_bf16_blocked"), ("crop_transform_kernel", "crop_transform"),
     ("layernorm_blocked_kernel", "layernorm_blocked"), ("conv_igemm", "conv_igemm"),
     # mlp_fused_kernel<E, D, H, TNCW, PROJ>: whole panels + the split parts of the tail panels (TNCW chunks each) in one launch
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "proj_mlp_main"),
