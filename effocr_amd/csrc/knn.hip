@@ -1378,16 +1378,18 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
 
 int g_knn_qs_wgs = 0;                 // workgroups a knn_qs launch aims for (0 = one per CU); knn_set_option("qs_wgs")
 bool g_knn_qs = true;                 // A/B switch (tests): 0 = the screened search ignores the blocked copy
+int g_knn_qs_qt = 0;                  // A/B switch: query tiles per wave of the Q-stationary pass (0 = the rule in qs_plan, 1, 2)
 struct QsPlan { int qt, nqg, ppc, nchunks; };
 bool qs_applies(int64_t B, int64_t N, int D, int k) {
   return g_knn_qs && !g_knn_two_pass && !g_knn_force_tile && (D == 128 || D == 384 || D == 768) && k <= 16 && N >= 1024;   // (>= 16 pairs of 64 rows)
 }
 QsPlan qs_plan(int64_t B, int64_t N, int D) {
   QsPlan p;
-  // two query tiles per wave (256 queries per workgroup, half the LDS fragment reads per MFMA) where the index is long enough to keep
-  // every CU busy anyway; one (128 queries) for 768-wide rows (192 fragment registers per tile) and for small indexes, where more,
-  // shorter workgroups win: the lists' warm-up insertions are a fixed cost per (query, workgroup)
-  p.qt = (D <= 384 && N >= 65536) ? 2 : 1;
+  // two query tiles per wave (256 queries per workgroup: every A fragment read feeds two MFMAs — at one tile the four waves' reads run the
+  // LDS at its full rate) where the index is long enough to keep every CU busy anyway; at D = 768 that is 384 fragment registers (500 of
+  // 512 in all, no spill) and pays from 512 queries on at both widths (1M x 768 x 1024 q: 1.80 -> 1.54 ms, 256 q: 0.63 -> 0.87 ms; 1M x 384 x 256 q: 0.39 -> 0.66 ms); one tile for small
+  // indexes, where more, shorter workgroups win
+  p.qt = g_knn_qs_qt ? g_knn_qs_qt : ((N >= 65536 && B >= 512) ? 2 : 1);
   p.nqg = (int)((B + 128 * p.qt - 1) / (128 * p.qt));
   const int npairs = (int)((N + 63) / 64);
   int want = (g_knn_qs_wgs > 0 ? g_knn_qs_wgs : device_cus()) / p.nqg;
@@ -1404,6 +1406,7 @@ int launch_knn_qs_pool(const KnnArgs& a, int D, int qt, hipStream_t s) {
   if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2>), grid, blk, 0, s, a);
   else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1>), grid, blk, 0, s, a);
   else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1>), grid, blk, 0, s, a);
+  else if (D == 768 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<768, 2>), grid, blk, 0, s, a);
   else if (D == 128 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<128, 2>), grid, blk, 0, s, a);
   else if (D == 128 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<128, 1>), grid, blk, 0, s, a);
   else return fail(EFFOCR_EINVAL, "knn(qs): internal");
@@ -1528,6 +1531,7 @@ int convert_bf16_blocked(const float* src, int64_t N, int D, void* dst, hipStrea
 void knn_qs_option(int which, int value) {
   if (which == 0) g_knn_qs = value != 0;
   else if (which == 3) g_knn_stream_min_rows = value < 4096 ? 4096 : value;
+  else if (which == 4) g_knn_qs_qt = (value == 1 || value == 2) ? value : 0;
   else g_knn_qs_wgs = value < 0 ? 0 : value;
 }
 
