@@ -32,6 +32,7 @@ class IndexFlatIP:
     metric_type = 0          # faiss.METRIC_INNER_PRODUCT
     is_trained = True
 
+    SCREEN_WS_BYTES = 1 << 30   # bound on the pooled screen's block-maxima workspace per call (larger query batches are sliced)
     SCREEN_MIN_ROWS = 65536   # from this size on `search` uses the screened entry point (bit-identical results, ~4x faster at 1M rows)
 
     def __init__(self, d, device="cuda:0", screen="auto"):
@@ -177,6 +178,15 @@ class IndexFlatIP:
         if n == 0:
             return D, I
         self._poll_overflow()
+        # The pooled screen's workspace holds one fp32 maximum per (16 index rows, query): ntotal / 16 * n * 4 bytes.  Very large query
+        # batches against a large index go through it in slices of at most SCREEN_WS_BYTES of that (1M rows: 4 096 queries per slice).
+        if self._use_screen(k, n) and self._qs_ok(k) and self.ntotal * n // 4 > self.SCREEN_WS_BYTES:
+            per = max(512, (self.SCREEN_WS_BYTES * 4 // self.ntotal) // 256 * 256)
+            if per < n:
+                for lo in range(0, n, per):
+                    d_, i_ = self.search_device(q[lo:lo + per], k)
+                    D[lo:lo + per], I[lo:lo + per] = d_, i_
+                return D, I
         if self._use_screen(k, n):
             qs = self._qs_ok(k)
             # the streaming screen (17..128 queries against a large index) reads the row-major copy; everything else the blocked one

@@ -243,6 +243,26 @@ def test_q_stationary_screen_is_bit_identical(dev, N, D, B, k):
         assert torch.equal(I3, Is) and torch.equal(D3.view(torch.int32), Ds.view(torch.int32)), opt
 
 
+def test_large_query_batches_are_sliced(dev):
+    """The pooled screen keeps ntotal / 16 * nq * 4 bytes of block maxima: query batches beyond IndexFlatIP.SCREEN_WS_BYTES of that are
+    searched in slices — same results, bounded workspace."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, D, B, k = 70_000, 128, 1500, 10
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=g, device=dev), dim=1)
+    ref = IndexFlatIP(D, device=dev, screen=True)
+    ref.add(X)
+    Dr, Ir = ref.search_device(Q, k)
+    sl = IndexFlatIP(D, device=dev, screen=True)
+    sl.SCREEN_WS_BYTES = N * 600 // 4                       # forces slices of 512 queries
+    sl.add(X)
+    Ds, Is = sl.search_device(Q, k)
+    assert torch.equal(Ir, Is) and torch.equal(Dr.view(torch.int32), Ds.view(torch.int32))
+    ws = sl._ws[torch.cuda.current_stream(dev).cuda_stream]
+    assert ws.numel() < ref._ws[torch.cuda.current_stream(dev).cuda_stream].numel()
+
+
 def test_screened_search_non_unit_rows_ties_and_overflow(dev):
     """Rows of very different norms (the bound uses the max norm), exact duplicates (tie rule: lower id first) and
     a cluster of > 512 near-identical rows around some queries (candidate overflow -> gated exact fallback)."""
