@@ -1195,7 +1195,9 @@ constexpr int POOL_ROWS = 2048;        // rows re-scored per query in stage A (1
 __global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __restrict__ C, int B, int nsub, int k, const float* __restrict__ qnorm,
                                                              float eps_scale, float* __restrict__ thr) {
   __shared__ float sC[MAX_CHUNKS * QS_NSUB];
+  __shared__ float sL;
   const int q = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sL = -FLT_MAX;                             // no value of rank k - 1 (a NaN query: its maxima compare false): collect nothing real
   for (int e = tid; e < nsub; e += 256) sC[e] = C[(int64_t)e * B + q];
   __syncthreads();
   const int kk = k < nsub ? k : nsub;
@@ -1203,8 +1205,10 @@ __global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __rest
     const float v = sC[e];
     int rank = 0;
     for (int j = 0; j < nsub; ++j) { const float u = sC[j]; rank += (u > v || (u == v && j < e)) ? 1 : 0; }
-    if (rank == kk - 1) thr[q] = v - eps_scale * qnorm[q];
+    if (rank == kk - 1 && v == v) sL = v;                  // exactly one entry of a NaN-free set has this rank
   }
+  __syncthreads();
+  if (tid == 0) thr[q] = sL - eps_scale * qnorm[q];        // written on every call: never a stale threshold
 }
 
 // Workgroup = 64 queries (lane = query: coalesced rows of M) x a range of blocks, 4 waves x 8 loads in flight.

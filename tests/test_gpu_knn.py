@@ -243,6 +243,28 @@ def test_q_stationary_screen_is_bit_identical(dev, N, D, B, k):
         assert torch.equal(I3, Is) and torch.equal(D3.view(torch.int32), Ds.view(torch.int32)), opt
 
 
+def test_nan_query_through_the_pooled_screen(dev):
+    """A non-finite query (an f16 overflow upstream) must come back as (-FLT_MAX, -1) padding from the screened search too — never as a
+    plausible id, never as a stale threshold's leftovers — and must not disturb its neighbours' results."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, D, B, k = 10_000, 384, 600, 10
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=g, device=dev), dim=1)
+    ex = IndexFlatIP(D, device=dev, screen=False); ex.add(X)
+    De, Ie = ex.search_device(Q, k)
+    sc = IndexFlatIP(D, device=dev); sc.add(X)
+    assert sc._use_screen(k, B) and sc._qs_ok(k)
+    sc.search_device(Q, k)                                   # a clean call first: leaves thresholds behind in the workspace
+    Qn = Q.clone()
+    Qn[7] = float("nan")
+    Qn[300, 5] = float("inf")
+    Ds, Is = sc.search_device(Qn, k)
+    ok = torch.ones(B, dtype=torch.bool, device=dev); ok[7] = False; ok[300] = False
+    assert (Is[7] == -1).all() and (Is[300] == -1).all()
+    assert torch.equal(Is[ok], Ie[ok]) and torch.equal(Ds[ok].view(torch.int32), De[ok].view(torch.int32))
+
+
 def test_large_query_batches_are_sliced(dev):
     """The pooled screen keeps ntotal / 16 * nq * 4 bytes of block maxima: query batches beyond IndexFlatIP.SCREEN_WS_BYTES of that are
     searched in slices — same results, bounded workspace."""
