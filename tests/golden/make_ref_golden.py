@@ -325,7 +325,10 @@ def record_medianpad(du, rng):
 # ---------------------------------------------------------------------------------------------------------------------
 # run_effocr over oracle-backed engines
 CHARS = list("aenrwuosvcxzTHEQUICKBROWN-") + [chr(0x4E00 + i) for i in range(70)]
-ARCH, SIZE, SEED_ENC = "vit_tiny_test", 224, 21
+# REF_ARCH=vit_small_patch16_224 records the SAME driver cases over the real-size encoder (oracle A's ViT-S/16, fp32) into
+# ref_run_effocr_vits.{json,npz}: the strings of the reference's run_effocr / EffOCR.infer with BASELINE configs[1]'s architecture
+ARCH, SIZE, SEED_ENC = os.environ.get("REF_ARCH", "vit_tiny_test"), 224, 21
+SUFFIX = {"vit_tiny_test": "", "vit_small_patch16_224": "_vits"}[ARCH]
 
 
 def line_image(seed, H, W):
@@ -384,7 +387,7 @@ def make_world():
     from oracle.encoders_ref import encoder_forward
     w = {"enc_sd": init_state_dict(ARCH, seed=SEED_ENC, img_size=SIZE), "seen": {}, "tag": (0, "en")}
     rng = np.random.RandomState(5)
-    d = rng.standard_normal((32, 128)).astype(np.float32)
+    d = rng.standard_normal((32, {"vit_tiny_test": 128, "vit_small_patch16_224": 384}[ARCH])).astype(np.float32)
     w["index"] = np.ascontiguousarray(d / np.linalg.norm(d, axis=1, keepdims=True))
     w["chars"] = ["x"] * 32
 
@@ -551,9 +554,10 @@ def main():
         "letterbox": record_localizer_static(EffLocalizer, rng, arrays),
         "medianpad": record_medianpad(du, rng),
     }
-    with open(os.path.join(HERE, "ref_hostlogic.json"), "w") as f:
-        json.dump(fixture, f, ensure_ascii=False, separators=(",", ":"))
-    np.savez_compressed(os.path.join(HERE, "ref_hostlogic.npz"), **arrays)
+    if not SUFFIX:                                           # (the host-logic fixtures do not depend on the encoder)
+        with open(os.path.join(HERE, "ref_hostlogic.json"), "w") as f:
+            json.dump(fixture, f, ensure_ascii=False, separators=(",", ":"))
+        np.savez_compressed(os.path.join(HERE, "ref_hostlogic.npz"), **arrays)
     with tempfile.TemporaryDirectory() as tmp:
         w = make_world()
         record_run_effocr(multi, tmp, w)       # pass 1: only to see which crops the reference cuts
@@ -562,10 +566,10 @@ def main():
         cases, arr = record_run_effocr(multi, tmp, w)
         infer_cases, min_gap = record_infer(single, tmp, w)
         arr["index"] = w["index"]
-    with open(os.path.join(HERE, "ref_run_effocr.json"), "w") as f:
+    with open(os.path.join(HERE, f"ref_run_effocr{SUFFIX}.json"), "w") as f:
         json.dump({"chars": w["chars"], "arch": ARCH, "size": SIZE, "enc_seed": SEED_ENC, "cases": cases,
                    "infer": infer_cases, "infer_min_rank_gap": min_gap}, f, ensure_ascii=False, indent=0)
-    np.savez_compressed(os.path.join(HERE, "ref_run_effocr.npz"), **arr)
+    np.savez_compressed(os.path.join(HERE, f"ref_run_effocr{SUFFIX}.npz"), **arr)
     n = sum(len(v) for v in fixture.values() if isinstance(v, list))
     print(f"recorded {n} host-logic cases + {len(cases)} run_effocr runs from the imported reference")
     for c in cases:

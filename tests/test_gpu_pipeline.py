@@ -207,15 +207,19 @@ class _PresetLocalizer:
         return out, cnt
 
 
-def test_run_effocr_reproduces_the_references_own_strings(dev):
-    """tests/golden/ref_run_effocr.*: strings produced by the REFERENCE's run_effocr (infer_effocr_onnx_multi.py:227-397, imported and
+@pytest.mark.parametrize("suffix,precision", [("", "fp32"), ("_vits", "fp32"), ("_vits", "fp16"), ("_vits", "bf16")])
+def test_run_effocr_reproduces_the_references_own_strings(dev, suffix, precision):
+    """tests/golden/ref_run_effocr*.*: strings produced by the REFERENCE's run_effocr (infer_effocr_onnx_multi.py:227-397, imported and
     run by tests/golden/make_ref_golden.py over oracle-backed engines).  The product function — HIP crop transform, HIP encoder
     (fp32 mode), HIP k-NN, device box arithmetic, product line assembly — fed the same NMS rows must return them character for
-    character: en with / without case repair, jp, vertical, empty crops (zero image), negative and out-of-image coordinates."""
+    character: en with / without case repair, jp, vertical, empty crops (zero image), negative and out-of-image coordinates.
+    "_vits" (round 5): the same cases recorded over the real-size ViT-S/16 (BASELINE configs[1]'s architecture), replayed in the exact
+    fp32 mode AND in the engines' default fp16 mode (16-bit crop hand-off, fused kernels): the transcriptions must still be the
+    reference's, character for character."""
     from test_ref_golden import load_run_effocr_fixture
-    meta, index = load_run_effocr_fixture()
+    meta, index = load_run_effocr_fixture(suffix)
     enc_sd = init_state_dict(meta["arch"], seed=meta["enc_seed"], img_size=meta["size"])
-    rec = EffRecognizer(enc_sd, arch=meta["arch"], precision="fp32", img_size=meta["size"], device=dev)
+    rec = EffRecognizer(enc_sd, arch=meta["arch"], precision=precision, img_size=meta["size"], device=dev)
     tf = PairedTransform(size=meta["size"], device=dev)
     knn = FaissKNN(index_init_fn=IndexFlatIP, reset_before=False, reset_after=False, device=dev)
     knn.train(torch.from_numpy(index))
@@ -230,7 +234,8 @@ def test_run_effocr_reproduces_the_references_own_strings(dev):
     assert total > 300
 
 
-def test_line_recognizer_reproduces_the_references_infer(dev):
+@pytest.mark.parametrize("suffix", ["", "_vits"])
+def test_line_recognizer_reproduces_the_references_infer(dev, suffix):
     """tests/golden/ref_run_effocr.json["infer"]: what the REFERENCE's ``EffOCR.infer`` (infer_effocr.py:255-343, kNN branch with the
     default k = 10) returned over oracle-backed stages.  The product chain — LinePostprocessor, HIP crop transform, HIP encoder (fp32),
     HIP IndexFlatIP top-10, ``indices_to_chars``, en_postprocess — returns the same transcription and boxes; the ten-neighbour strings
@@ -240,7 +245,7 @@ def test_line_recognizer_reproduces_the_references_infer(dev):
     from effocr_amd.pipeline import Recognizer
     from effocr_amd.postprocess import LinePostprocessor, LineRecognizer
     from test_ref_golden import infer_case_inputs, load_run_effocr_fixture
-    meta, index = load_run_effocr_fixture()
+    meta, index = load_run_effocr_fixture(suffix)
     enc_sd = init_state_dict(meta["arch"], seed=meta["enc_seed"], img_size=meta["size"])
     enc = AutoEncoderFactory("timm", meta["arch"], precision="fp32", img_size=meta["size"])()
     enc.load_state_dict(enc_sd)

@@ -175,10 +175,12 @@ def line_image(seed, H, W):
     return np.ascontiguousarray(np.kron(cells, np.ones((8, 8, 1), np.uint8))[:H, :W])
 
 
-def load_run_effocr_fixture():
-    with open(os.path.join(G, "ref_run_effocr.json")) as f:
+def load_run_effocr_fixture(suffix=""):
+    """suffix "": the miniature encoder (vit_tiny_test); "_vits": the same driver cases recorded over oracle A's ViT-S/16 (BASELINE
+    configs[1]'s architecture; REF_ARCH=vit_small_patch16_224 python tests/golden/make_ref_golden.py)."""
+    with open(os.path.join(G, f"ref_run_effocr{suffix}.json")) as f:
         meta = json.load(f)
-    arrays = np.load(os.path.join(G, "ref_run_effocr.npz"))
+    arrays = np.load(os.path.join(G, f"ref_run_effocr{suffix}.npz"))
     for c in meta["cases"]:
         c["images"], c["rows"] = [], []
         for l in c["lines"]:
