@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // (fixed order) + bias2 (+ the old row), written back as the new residual row, then normalised — one launch instead of the
 // reduction kernel + this one (each launch of a small-batch forward costs ~7 us + its queue gap); the arithmetic of both is unchanged.
 struct LnReduce { const float* partial; const float* b2; float* xw; int nparts, tail_rb, add_x; };
-template <int D, typename TO, bool REDUCE = false>
+// NP (REDUCE): parts per row as a compile-time constant (2 / 4: what the fused MLP's launcher cuts; 0 = rd.nparts at run time) — with it
+// every partial-row load of a lane (12 chunks x NP parts at D = 384) is in flight at once; the run-time loop waited for each part in
+// turn (20 us per launch on 160 workgroups at 1024 crops, 16 us at 64 crops: round 5).  Same fixed summation order.
+template <int D, typename TO, bool REDUCE = false, int NP = 0>
 __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __restrict__ x, int64_t rows,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps,
@@ -65,11 +68,25 @@ __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __r
   if constexpr (REDUCE) {
     const int64_t per_rb = (int64_t)(D / 4) * 32;
     const bool live = rb * 32 + tl < rows;
+    f32x4 pvs[NP > 0 ? NQ : 1][NP > 0 ? NP : 1];
+    if constexpr (NP > 0) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          pvs[i][p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rd.partial) + ((int64_t)p * rd.tail_rb + rb) * per_rb + (int64_t)(c0 + 2 * i) * 32 + tl);
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int c = c0 + 2 * i;
       const int64_t rem = (int64_t)c * 32 + tl;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (NP > 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += pvs[i][p][e];
+      } else
       for (int p = 0; p < rd.nparts; ++p) {
         const f32x4 pv = reinterpret_cast<const f32x4*>(rd.partial)[((int64_t)p * rd.tail_rb + rb) * per_rb + rem];
 #pragma unroll
@@ -539,7 +556,9 @@ int launch_reduce_ln_blocked(float* x, int64_t rows, int D, const float* partial
   if (rows <= 0) return EFFOCR_OK;
   const dim3 grid((unsigned)((rows + 31) / 32));
   const LnReduce rd{partial, b2, x, nparts, tail_rb, add_x};
-  if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
+  if (D == 384 && nparts == 4) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true, 4>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
+  else if (D == 384 && nparts == 2) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true, 2>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
+  else if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
   else if (D == 128) hipLaunchKernelGGL((layernorm_blocked_kernel<128, TO, true>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
   else return fail(EFFOCR_EUNSUPPORTED, "reduce + layernorm(blocked): embed dim must be 128 or 384");
   return check_launch("reduce_layernorm_blocked");
