@@ -933,6 +933,7 @@ int effocr_knn_set_option(const char* name, int value) {
   if (std::string(name) == "qs_wgs") { knn_qs_option(1, value); return EFFOCR_OK; }
   if (std::string(name) == "stream_min_rows") { knn_qs_option(3, value); return EFFOCR_OK; }
   if (std::string(name) == "qs_qt") { knn_qs_option(4, value); return EFFOCR_OK; }
+  if (std::string(name) == "qs_fine") { knn_qs_option(5, value); return EFFOCR_OK; }
   return fail(EFFOCR_EINVAL, std::string("knn_set_option: unknown option '") + name + "'");
 }
 

@@ -159,6 +159,7 @@ struct KnnArgs {
   int ldo, ocol, after_col;
   // knn_qs_kernel<.., POOL>: maxima of the approximate scores per 16-row block, M [4 * pairs][B], and per chunk, C [nchunks][B]
   float* pool_m; float* pool_c;
+  int nsub;                         // sub-chunk maxima per chunk: min(QS_NSUB, pairs per chunk)
 };
 
 // E = float: exact scores (the product's definition).  E = __bf16: screening scores s^ from bf16-rounded operands
@@ -1001,7 +1002,9 @@ constexpr int QS_NSUB = 8;            // sub-chunk maxima per chunk (pass 1 -> k
 // knn_pool_rerank_kernel below).
 // (The list-keeping form of this kernel — round 5's first version: per-lane lists with a per-lane hit walk through an LDS scratch, merged
 // per chunk and fed to the merge / collect / re-rank chain — measured 2.46 ms / 131 us at those two shapes and was removed.)
-template <int D, int QT>
+// FINE: maxima per 4 consecutive rows (a register quad) instead of per 16 — four times the block maxima (N * B bytes), a quarter of the
+// rows the re-rank has to re-score per surviving block; used where that array stays small (N * B <= 64 M: BASELINE configs[1]'s own search).
+template <int D, int QT, bool FINE = false>
 __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
   constexpr bool POOL = true;
   typedef bf16x8 V8;
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
   const int p0 = chunk * a.tiles_per_chunk;                          // 64-row pairs [p0, p1) of this chunk
   const int p1 = min(p0 + a.tiles_per_chunk, npairs);
   const int nst = (p1 - p0) * KT;                                    // ring stages of this workgroup (>= KT)
-  const int sublen = (a.tiles_per_chunk + QS_NSUB - 1) / QS_NSUB;    // pairs per sub-chunk (the maxima the bound L(q) is taken over)
+  const int sublen = (a.tiles_per_chunk + a.nsub - 1) / a.nsub;    // pairs per sub-chunk (the maxima the bound L(q) is taken over)
   const char* Xb = static_cast<const char*>(a.xb);
   const __bf16* Q = static_cast<const __bf16*>(a.q);
 
@@ -1123,6 +1126,18 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
         const int qi = q0 + qt * 32 + r31;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+          if constexpr (FINE) {
+            // block b4 = (4 p + 2 i + half) * 4 + g = the 4 rows 64 p + 32 i + 4 half + 8 g + 0..3 (registers 4g .. 4g + 3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float m = -FLT_MAX;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                m = (!lastp || p * 64 + i * 32 + 4 * half + 8 * g + e < a.N) ? fmaxf(m, acc[i][qt][4 * g + e]) : m;
+              if (qi < a.B) a.pool_m[(int64_t)((p * 4 + i * 2 + half) * 4 + g) * a.B + qi] = m;
+              cmax[qt] = fmaxf(cmax[qt], m);
+            }
+          } else {
           float m = -FLT_MAX;
           if (lastp) {
 #pragma unroll
@@ -1133,6 +1148,7 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
           }
           if (qi < a.B) a.pool_m[(int64_t)(p * 4 + i * 2 + half) * a.B + qi] = m;
           cmax[qt] = fmaxf(cmax[qt], m);
+          }
         }
       }
       // end of a sub-chunk (QS_NSUB per chunk): its maximum per query -> C[chunk * QS_NSUB + sub][q], running maximum reset
@@ -1142,18 +1158,18 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
         for (int qt = 0; qt < QT; ++qt) {
           const float m = fmaxf(cmax[qt], __shfl_xor(cmax[qt], 32, 64));
           const int qi = q0 + qt * 32 + r31;
-          if (half == 0 && qi < a.B) a.pool_c[(int64_t)(chunk * QS_NSUB + sub) * a.B + qi] = m;
+          if (half == 0 && qi < a.B) a.pool_c[(int64_t)qi * (a.nchunks * a.nsub) + chunk * a.nsub + sub] = m;   // [query][sub-chunk]: one coalesced row per query for the bound kernel
           cmax[qt] = -FLT_MAX;
         }
       }
     }
   }
   // sub-chunk slots this chunk did not reach (a short last chunk): no block there
-  for (int sub = (p1 - p0 + sublen - 1) / sublen; sub < QS_NSUB; ++sub)
+  for (int sub = (p1 - p0 + sublen - 1) / sublen; sub < a.nsub; ++sub)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const int qi = q0 + qt * 32 + r31;
-      if (half == 0 && qi < a.B) a.pool_c[(int64_t)(chunk * QS_NSUB + sub) * a.B + qi] = -FLT_MAX;
+      if (half == 0 && qi < a.B) a.pool_c[(int64_t)qi * (a.nchunks * a.nsub) + chunk * a.nsub + sub] = -FLT_MAX;
     }
 }
 
@@ -1198,7 +1214,7 @@ __global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __rest
   __shared__ float sL;
   const int q = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) sL = -FLT_MAX;                             // no value of rank k - 1 (a NaN query: its maxima compare false): collect nothing real
-  for (int e = tid; e < nsub; e += 256) sC[e] = C[(int64_t)e * B + q];
+  for (int e = tid; e < nsub; e += 256) sC[e] = C[(int64_t)q * nsub + e];
   __syncthreads();
   const int kk = k < nsub ? k : nsub;
   for (int e = tid; e < nsub; e += 256) {
@@ -1243,7 +1259,7 @@ __global__ __launch_bounds__(256) void knn_pool_collect_kernel(const float* __re
 // fp32 row (1.5 - 3 KB scattered per row: re-ranking all 16 rows of every block exactly was 131 us of BASELINE configs[1]'s search and
 // 0.7 ms at 1M x 768 x 1024 queries).
 constexpr int POOL_EXACT = 512;        // rows re-ranked exactly per query
-template <int D>
+template <int D, bool FINE = false>
 __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __restrict__ q, const float* __restrict__ xb, const char* __restrict__ xblk,
                                                               int N, int k, const float* __restrict__ evalue, const int* __restrict__ eblk,
                                                               const int* __restrict__ cnt, const float* __restrict__ qnorm, float eps_scale,
@@ -1251,7 +1267,8 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
   constexpr int KC = D / 8, CPL = KC / 4;                            // 16-byte k chunks per row / per lane of a row's quad
   __shared__ float sV[POOL_CAP];
   __shared__ int sB[POOL_CAP];
-  __shared__ int sSurv[POOL_ROWS / 16];
+  constexpr int NSURV = FINE ? 256 : POOL_ROWS / 16;               // surviving blocks per query (4-row blocks: 1 024 rows; 16-row: 2 048)
+  __shared__ int sSurv[NSURV];
   __shared__ float sS[POOL_EXACT];
   __shared__ int sI[POOL_EXACT];
   __shared__ int sN, sN2;
@@ -1278,17 +1295,21 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
   for (int e = tid; e < n; e += 256)
     if (sV[e] >= tau) {
       const int pos = atomicAdd(&sN, 1);
-      if (pos < POOL_ROWS / 16) sSurv[pos] = sB[e];
+      if (pos < NSURV) sSurv[pos] = sB[e];
     }
   __syncthreads();
   const int ns = sN;
-  if (ns > POOL_ROWS / 16) { if (tid == 0) atomicOr(flag, 1); return; }   // overflow: the gated exact pass recomputes everything
+  if (ns > NSURV) { if (tid == 0) atomicOr(flag, 1); return; }   // overflow: the gated exact pass recomputes everything
   const float* qr = q + (int64_t)qg * D;
   // ---- stage A: block bb = rows 64 (bb >> 2) + 32 ((bb >> 1) & 1) + 4 (bb & 1) + (r & 3) + 8 (r >> 2), r = 0..15; lane = (r, k quarter).
   // The lane's quarter of the query stays in registers; TWO blocks' chunks are requested before the first is summed.
   {
     const int r = lane >> 2, kq = lane & 3;
-    auto row_of = [&](int bb) __attribute__((always_inline)) { return 64 * (bb >> 2) + 32 * ((bb >> 1) & 1) + 4 * (bb & 1) + (r & 3) + 8 * (r >> 2); };
+    // 16-row blocks: lane quad r covers row r of ONE block; 4-row blocks (FINE): the wave takes four blocks at a time, quad r = (block r >> 2, row r & 3)
+    auto row_of = [&](int bb) __attribute__((always_inline)) {
+      if constexpr (FINE) return 64 * (bb >> 4) + 32 * ((bb >> 3) & 1) + 4 * ((bb >> 2) & 1) + 8 * (bb & 3) + (r & 3);
+      else return 64 * (bb >> 2) + 32 * ((bb >> 1) & 1) + 4 * (bb & 1) + (r & 3) + 8 * (r >> 2);
+    };
     auto load_blk = [&](int row, u32x4 (&xv)[CPL]) __attribute__((always_inline)) {
       const char* cell = xblk + (((int64_t)(row >> 5) * KC + kq * CPL) * 32 + (row & 31)) * 16;
 #pragma unroll
@@ -1316,6 +1337,15 @@ __global__ __launch_bounds__(256) void knn_pool_rerank_kernel(const float* __res
     };
     // (one block at a time: <= 128 registers keep four workgroups = sixteen queries per CU in flight, which hides the latency chain
     // cnt -> entries -> tau -> blocks -> rows better than a second block per wave did at two workgroups per CU)
+    if constexpr (FINE) {
+      for (int j = w * 4; j < ns; j += 16) {
+        u32x4 xa[CPL];
+        const int jj = j + (r >> 2);
+        const int ra = jj < ns ? row_of(sSurv[jj]) : N;            // (past the survivors: row N is a zero row of the blocked copy or clamps below)
+        load_blk(ra < N ? ra : N - 1, xa);
+        finish(ra, xa);
+      }
+    } else
     for (int j = w; j < ns; j += 4) {
       u32x4 xa[CPL];
       const int ra = row_of(sSurv[j]);
@@ -1384,6 +1414,8 @@ int g_knn_qs_wgs = 0;                 // workgroups a knn_qs launch aims for (0 
 bool g_knn_qs = true;                 // A/B switch (tests): 0 = the screened search ignores the blocked copy
 int g_knn_qs_qt = 0;                  // A/B switch: query tiles per wave of the Q-stationary pass (0 = the rule in qs_plan, 1, 2)
 struct QsPlan { int qt, nqg, ppc, nchunks; };
+bool g_knn_qs_fine = true;            // A/B switch: 0 = 16-row blocks for every problem size
+bool qs_fine(int64_t B, int64_t N) { return g_knn_qs_fine && N * B <= ((int64_t)64 << 20); }   // 4-row block maxima: N * B bytes
 bool qs_applies(int64_t B, int64_t N, int D, int k) {
   return g_knn_qs && !g_knn_two_pass && !g_knn_force_tile && (D == 128 || D == 384 || D == 768) && k <= 16 && N >= 1024;   // (>= 16 pairs of 64 rows)
 }
@@ -1405,8 +1437,14 @@ QsPlan qs_plan(int64_t B, int64_t N, int D) {
   if (p.nchunks < 16 && npairs <= MAX_CHUNKS) { p.ppc = 1; p.nchunks = npairs; }
   return p;
 }
-int launch_knn_qs_pool(const KnnArgs& a, int D, int qt, hipStream_t s) {
+int launch_knn_qs_pool(const KnnArgs& a, int D, int qt, bool fine, hipStream_t s) {
   const dim3 grid((unsigned)(a.nqt * a.nchunks)), blk(256);
+  if (fine) {                                              // (small problems only: one query tile per wave)
+    if (D == 384) hipLaunchKernelGGL((knn_qs_kernel<384, 1, true>), grid, blk, 0, s, a);
+    else if (D == 768) hipLaunchKernelGGL((knn_qs_kernel<768, 1, true>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((knn_qs_kernel<128, 1, true>), grid, blk, 0, s, a);
+    return check_launch("knn_qs_pool");
+  }
   if (D == 384 && qt == 2) hipLaunchKernelGGL((knn_qs_kernel<384, 2>), grid, blk, 0, s, a);
   else if (D == 384 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<384, 1>), grid, blk, 0, s, a);
   else if (D == 768 && qt == 1) hipLaunchKernelGGL((knn_qs_kernel<768, 1>), grid, blk, 0, s, a);
@@ -1498,7 +1536,7 @@ ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   w.pool_m = w.pool_c = w.pool_ev = w.pool_eb = 0;
   if (k <= 16 && N >= 1024) {                                      // block / chunk maxima + collected entries of the Q-stationary pass
     const QsPlan qp = qs_plan(B, N, D);
-    w.pool_m = take((size_t)((N + 63) / 64) * 4 * (size_t)B * 4);
+    w.pool_m = take((size_t)((N + 63) / 64) * (qs_fine(B, N) ? 16 : 4) * (size_t)B * 4);
     w.pool_c = take((size_t)qp.nchunks * QS_NSUB * (size_t)B * 4);
     w.pool_ev = take((size_t)B * POOL_CAP * 4);
     w.pool_eb = take((size_t)B * POOL_CAP * 4);
@@ -1536,6 +1574,7 @@ void knn_qs_option(int which, int value) {
   if (which == 0) g_knn_qs = value != 0;
   else if (which == 3) g_knn_stream_min_rows = value < 4096 ? 4096 : value;
   else if (which == 4) g_knn_qs_qt = (value == 1 || value == 2) ? value : 0;
+  else if (which == 5) g_knn_qs_fine = value != 0;
   else g_knn_qs_wgs = value < 0 ? 0 : value;
 }
 
@@ -1588,8 +1627,10 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
     KnnArgs b = a;
     b.q = qb; b.xb = xblk; b.nqt = qsp.nqg; b.tiles_per_chunk = qsp.ppc; b.nchunks = qsp.nchunks;
     b.pool_m = reinterpret_cast<float*>(W + w.pool_m); b.pool_c = reinterpret_cast<float*>(W + w.pool_c);
-    if ((rc = launch_knn_qs_pool(b, D, qsp.qt, s))) return rc;
-    const int nblk = (int)((N + 63) / 64) * 4;
+    b.nsub = qsp.ppc < QS_NSUB ? qsp.ppc : QS_NSUB;
+    const bool fine = qs_fine(B, N) && qsp.qt == 1;
+    if ((rc = launch_knn_qs_pool(b, D, qsp.qt, fine, s))) return rc;
+    const int nblk = (int)((N + 63) / 64) * (fine ? 16 : 4);
     // collect: ~2 workgroups per CU, 64 queries each
     const int nqb = (int)((B + 63) / 64);
     int per = (nblk * nqb + 2 * device_cus() - 1) / (2 * device_cus());
@@ -1599,11 +1640,16 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
     float* ev = reinterpret_cast<float*>(W + w.pool_ev); int* eb = reinterpret_cast<int*>(W + w.pool_eb);
     const float es = 2.0f * c * xnorm_max;
     float* thr = reinterpret_cast<float*>(W + w.adist);     // (the approximate top-k area is free on this path)
-    hipLaunchKernelGGL(knn_pool_bound_kernel, dim3((unsigned)B), dim3(256), 0, s, b.pool_c, (int)B, qsp.nchunks * QS_NSUB, k, qnorm, es, thr);
+    hipLaunchKernelGGL(knn_pool_bound_kernel, dim3((unsigned)B), dim3(256), 0, s, b.pool_c, (int)B, qsp.nchunks * b.nsub, k, qnorm, es, thr);
     if ((rc = check_launch("knn_pool_bound"))) return rc;
     hipLaunchKernelGGL(knn_pool_collect_kernel, cg, dim3(256), 0, s, b.pool_m, thr, (int)B, nblk, per, ev, eb, cnt, flag);
     if ((rc = check_launch("knn_pool_collect"))) return rc;
     const char* xk = static_cast<const char*>(xblk);
+    if (fine) {
+      if (D == 384) hipLaunchKernelGGL((knn_pool_rerank_kernel<384, true>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
+      else if (D == 768) hipLaunchKernelGGL((knn_pool_rerank_kernel<768, true>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
+      else hipLaunchKernelGGL((knn_pool_rerank_kernel<128, true>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
+    } else
     if (D == 384) hipLaunchKernelGGL((knn_pool_rerank_kernel<384>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
     else if (D == 768) hipLaunchKernelGGL((knn_pool_rerank_kernel<768>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);
     else hipLaunchKernelGGL((knn_pool_rerank_kernel<128>), dim3((unsigned)B), dim3(256), 0, s, q, xb, xk, (int)N, k, ev, eb, cnt, qnorm, es, dist, idx, flag);

@@ -118,7 +118,11 @@ class IndexFlatIP:
             # (k = 1) against 130 / 115 us on the round-4 chain and 160 / 97 us exact; 1M x 384 at 256 / 1024 queries 0.36 / 0.87 ms
             # against 0.99 / 3.2 ms; 1M x 768 at 1024 queries 1.81 against 3.96 ms.  Calls of <= 256 queries against a small index stay
             # exact (69 us: the chain's four dependent launches cost more than the products there).
-            return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512)
+            # (end of round 5, 4-row block maxima for small problems: 10 k x 384 at 64 / 128 / 256 / 1024 queries, k = 10: 51 / 53 / 54 / 71 us
+            # against 69 / 69 / 71 / 159 us exact — the pooled chain wins from 33 queries on; k = 1, whose exact lists hold one entry:
+            # 40 us exact up to 256 queries, 54 vs 97 us at 1024)
+            return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or \
+                   (self.ntotal >= 8192 and (nq >= 512 or (k > 1 and nq > 32)))
         # (k = 1 on a small index: the exact kernel keeps one-entry lists — 98 vs 111 us at 10 k rows x 1024 queries, tools/knn_c2_sweep.py)
         return (self.ntotal >= self.SCREEN_MIN_ROWS and nq > stream_cap) or (self.ntotal >= 8192 and nq >= 512 and k > 1)
 

@@ -234,7 +234,7 @@ def test_q_stationary_screen_is_bit_identical(dev, N, D, B, k):
     assert old._xblk is None and torch.equal(Io, Is) and torch.equal(Do.view(torch.int32), Ds.view(torch.int32))
     # another chunking of the same launch: identical
     L = _lib.lib()
-    for opt, val, back in ((b"qs_wgs", 37, 0),):
+    for opt, val, back in ((b"qs_wgs", 37, 0), (b"qs_fine", 0, 1), (b"qs_qt", 1, 0), (b"qs_qt", 2, 0)):   # chunking / block granularity / query tiles per wave
         _lib.check(L.effocr_knn_set_option(opt, val), "knn_set_option")
         try:
             D3, I3 = sc.search_device(Q, k)
