@@ -1659,6 +1659,9 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
     e.nqt = p.nqt; e.tiles_per_chunk = p.tpc; e.nchunks = p.nchunks;
     e.pdist = a.pdist; e.dist = dist; e.idx = idx; e.run_flag = flag;
     e.pidx = reinterpret_cast<int*>(W + w.part + align_up((size_t)p.nchunks * (size_t)B * p.kmax * 4, 128));
+    // small indexes: the (gated, normally no-op) exact pass as ONE chunk per query tile — it writes the results itself, so the chain
+    // loses the no-op merge launch (~5 us of a 50 us search at the reference's call sizes); a real overflow then costs a few ms once
+    if (N <= 32768) { e.tiles_per_chunk = p.ntiles; e.nchunks = 1; }
     return launch_knn_k<float>(p.kmax, e, s);
   }
   if (stream16) {

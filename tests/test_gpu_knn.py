@@ -265,6 +265,30 @@ def test_nan_query_through_the_pooled_screen(dev):
     assert torch.equal(Is[ok], Ie[ok]) and torch.equal(Ds[ok].view(torch.int32), De[ok].view(torch.int32))
 
 
+@pytest.mark.parametrize("N,B", [(12_000, 600), (90_000, 300)])
+def test_pooled_screen_overflow_falls_back_exactly(dev, N, B):
+    """More near-identical rows around some queries than the pooled chain's caps hold (512 collected blocks / 1 024-2 048 re-scored rows):
+    the device flag un-gates the exact pass — one chunk per query tile on small indexes (no merge launch), the chunked form on large
+    ones — and ids and scores are those of the exact search, duplicates in ascending id order."""
+    from effocr_amd.knn import IndexFlatIP
+    g = torch.Generator(device=dev).manual_seed(N)
+    D, k = 384, 10
+    X = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1)
+    centre = torch.nn.functional.normalize(torch.randn(1, D, generator=g, device=dev), dim=1)
+    X[2000:5000] = torch.nn.functional.normalize(centre + 1e-4 * torch.randn(3000, D, generator=g, device=dev), dim=1)   # 3 000 near-identical rows
+    X[7000:7003] = X[100]
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=g, device=dev), dim=1)
+    Q[0], Q[1] = centre[0], X[100]
+    ex = IndexFlatIP(D, device=dev, screen=False); ex.add(X)
+    De, Ie = ex.search_device(Q, k)
+    sc = IndexFlatIP(D, device=dev, screen=True); sc.add(X)
+    Ds, Is = sc.search_device(Q, k)
+    torch.cuda.synchronize()
+    assert sc._xblk is not None and _screen_flag(sc, B, k) != 0
+    assert torch.equal(Ie, Is) and torch.equal(De.view(torch.int32), Ds.view(torch.int32))
+    assert Is[1, :4].tolist() == [100, 7000, 7001, 7002]
+
+
 def test_large_query_batches_are_sliced(dev):
     """The pooled screen keeps ntotal / 16 * nq * 4 bytes of block maxima: query batches beyond IndexFlatIP.SCREEN_WS_BYTES of that are
     searched in slices — same results, bounded workspace."""
@@ -342,7 +366,13 @@ def test_screened_auto_threshold_and_invalidation(dev):
     assert not idx._use_screen(10)
     idx.add(torch.nn.functional.normalize(torch.randn(70_000, 128, device=dev), dim=1))
     assert idx._use_screen(10) and not idx._use_screen(33)
-    assert idx._use_screen(10, 65) and not idx._use_screen(10, 64)          # <= 64 queries (d <= 384): one launch of the exact streaming kernel
+    # with the blocked copy's Q-stationary pass (d = 128 qualifies) the screened search wins from 33 queries on for k > 1; k = 1 keeps
+    # the exact streaming kernel up to 64 queries (d <= 384); without it (use_qs = False) the round-4 rule: > 64 queries
+    assert idx._use_screen(10, 33) and not idx._use_screen(10, 32)
+    assert idx._use_screen(1, 65) and not idx._use_screen(1, 64)
+    idx.use_qs = False
+    assert idx._use_screen(10, 65) and not idx._use_screen(10, 64)
+    idx.use_qs = True
     q = idx._xb[:140].clone()
     D1, I1 = idx.search_device(q, 5)
     assert (idx._xb16 is not None or idx._xblk is not None) and (I1[:, 0].cpu() == torch.arange(140)).all()
