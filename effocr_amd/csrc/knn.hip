@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
   const int nst = (p1 - p0) * KT;                                    // ring stages of this workgroup (>= KT)
   const int sublen = (a.tiles_per_chunk + a.nsub - 1) / a.nsub;    // pairs per sub-chunk (the maxima the bound L(q) is taken over)
   const char* Xb = static_cast<const char*>(a.xb);
-  const __bf16* Q = static_cast<const __bf16*>(a.q);
+  const float* Q = static_cast<const float*>(a.q);                    // fp32 queries, rounded to bf16 here (no separate conversion launch)
 
   // ---- query fragments: lane (query r31 of tile, k half) holds k = 16 t + 8 half .. + 7 for every k16 step t
   V8 qf[QT][NXF];
@@ -1031,9 +1031,13 @@ __global__ __launch_bounds__(256, 1) void knn_qs_kernel(KnnArgs a) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int qi = q0 + qt * 32 + r31;
-    const __bf16* qr = Q + (int64_t)(qi < a.B ? qi : a.B - 1) * D + 8 * half;
+    const float* qr = Q + (int64_t)(qi < a.B ? qi : a.B - 1) * D + 8 * half;
 #pragma unroll
-    for (int t = 0; t < NXF; ++t) qf[qt][t] = *reinterpret_cast<const V8*>(qr + 16 * t);
+    for (int t = 0; t < NXF; ++t) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(qr + 16 * t), hi = *reinterpret_cast<const f32x4*>(qr + 16 * t + 4);
+      const u32x2 p0 = pack4<__bf16>(lo[0], lo[1], lo[2], lo[3]), p1 = pack4<__bf16>(hi[0], hi[1], hi[2], hi[3]);
+      qf[qt][t] = __builtin_bit_cast(V8, u32x4{p0[0], p0[1], p1[0], p1[1]});
+    }
   }
 
   // ---- ring: stage s = (pair p0 + s / KT, k slice s % KT); wave w copies row block w >> 1, k chunks (w & 1) * 8 .. + 8: 4 pieces of 1 KB
@@ -1208,14 +1212,21 @@ constexpr int POOL_ROWS = 2048;        // rows re-scored per query in stage A (1
 // thr[q] = L(q) - 2 eps(q), L = the k-th largest of the nsub sub-chunk maxima of the query.  One workgroup per query, by RANK COUNTING:
 // a thread holds one value (nsub <= 256: BASELINE configs[1] and [3] alike; more: several) and counts the values that rank before it —
 // one memory round trip and a 256-step LDS loop (a per-lane sorted list over 64 queries per workgroup took 24 us on 16 workgroups).
-__global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __restrict__ C, int B, int nsub, int k, const float* __restrict__ qnorm,
-                                                             float eps_scale, float* __restrict__ thr) {
+__global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __restrict__ C, int B, int nsub, int k, const float* __restrict__ qv, int D,
+                                                             float* __restrict__ qnorm, float eps_scale, float* __restrict__ thr,
+                                                             int* __restrict__ cnt, int* __restrict__ flag) {
   __shared__ float sC[MAX_CHUNKS * QS_NSUB];
-  __shared__ float sL;
+  __shared__ float sL, sQ2[4];
   const int q = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) sL = -FLT_MAX;                             // no value of rank k - 1 (a NaN query: its maxima compare false): collect nothing real
-  for (int e = tid; e < nsub; e += 256) sC[e] = C[(int64_t)q * nsub + e];
+  if (tid == 0) { sL = -FLT_MAX; cnt[q] = 0; if (q == 0) *flag = 0; }   // (this kernel also does what knn_prep did for the older chains:
+  for (int e = tid; e < nsub; e += 256) sC[e] = C[(int64_t)q * nsub + e];   //  candidate counters, overflow flag, the query's L2 norm)
+  float ss = 0.f;
+  for (int d = tid; d < D; d += 256) { const float v = qv[(int64_t)q * D + d]; ss += v * v; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if ((tid & 63) == 0) sQ2[tid >> 6] = ss;
   __syncthreads();
+  const float qn = sqrtf((sQ2[0] + sQ2[1]) + (sQ2[2] + sQ2[3]));
   const int kk = k < nsub ? k : nsub;
   for (int e = tid; e < nsub; e += 256) {
     const float v = sC[e];
@@ -1224,7 +1235,7 @@ __global__ __launch_bounds__(256) void knn_pool_bound_kernel(const float* __rest
     if (rank == kk - 1 && v == v) sL = v;                  // exactly one entry of a NaN-free set has this rank
   }
   __syncthreads();
-  if (tid == 0) thr[q] = sL - eps_scale * qnorm[q];        // written on every call: never a stale threshold
+  if (tid == 0) { thr[q] = sL - eps_scale * qn; qnorm[q] = qn; }   // written on every call: never a stale threshold
 }
 
 // Workgroup = 64 queries (lane = query: coalesced rows of M) x a range of blocks, 4 waves x 8 loads in flight.
@@ -1597,9 +1608,7 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   int* cnt = reinterpret_cast<int*>(W + w.cnt);
   int* flag = reinterpret_cast<int*>(W + w.flag);
   int* cand = reinterpret_cast<int*>(W + w.cand);
-  hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, q, (int)B, D, qb, qnorm, cnt, flag);
-  int rc = check_launch("knn_prep");
-  if (rc) return rc;
+  int rc = EFFOCR_OK;
   KnnArgs a{};
   a.B = (int)B; a.N = (int)N; a.D = D; a.k = k; a.ldo = k; a.ocol = 0; a.after_col = -1;
   a.nqt = p.nqt; a.tiles_per_chunk = p.tpc; a.nchunks = p.nchunks;
@@ -1621,11 +1630,15 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   const bool qs = xblk != nullptr && qs_applies(B, N, D, k) && !stream16;
   if (!qs && xb16 == nullptr) return fail(EFFOCR_EINVAL, "knn(screened): this call needs the row-major bf16 copy of the index");
   const QsPlan qsp = qs ? qs_plan(B, N, D) : QsPlan{};
+  if (!qs) {                                               // (the Q-stationary chain rounds the queries itself and its bound kernel does the rest)
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, q, (int)B, D, qb, qnorm, cnt, flag);
+    if ((rc = check_launch("knn_prep"))) return rc;
+  }
   if (qs) {
     // pooled form (the default): pass 1 writes block / chunk maxima only, then threshold collect + block re-rank — four launches + the
     // gated exact pair, no lists, no merge
     KnnArgs b = a;
-    b.q = qb; b.xb = xblk; b.nqt = qsp.nqg; b.tiles_per_chunk = qsp.ppc; b.nchunks = qsp.nchunks;
+    b.q = q; b.xb = xblk; b.nqt = qsp.nqg; b.tiles_per_chunk = qsp.ppc; b.nchunks = qsp.nchunks;
     b.pool_m = reinterpret_cast<float*>(W + w.pool_m); b.pool_c = reinterpret_cast<float*>(W + w.pool_c);
     b.nsub = qsp.ppc < QS_NSUB ? qsp.ppc : QS_NSUB;
     const bool fine = qs_fine(B, N) && qsp.qt == 1;
@@ -1640,7 +1653,7 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
     float* ev = reinterpret_cast<float*>(W + w.pool_ev); int* eb = reinterpret_cast<int*>(W + w.pool_eb);
     const float es = 2.0f * c * xnorm_max;
     float* thr = reinterpret_cast<float*>(W + w.adist);     // (the approximate top-k area is free on this path)
-    hipLaunchKernelGGL(knn_pool_bound_kernel, dim3((unsigned)B), dim3(256), 0, s, b.pool_c, (int)B, qsp.nchunks * b.nsub, k, qnorm, es, thr);
+    hipLaunchKernelGGL(knn_pool_bound_kernel, dim3((unsigned)B), dim3(256), 0, s, b.pool_c, (int)B, qsp.nchunks * b.nsub, k, q, D, qnorm, es, thr, cnt, flag);
     if ((rc = check_launch("knn_pool_bound"))) return rc;
     hipLaunchKernelGGL(knn_pool_collect_kernel, cg, dim3(256), 0, s, b.pool_m, thr, (int)B, nblk, per, ev, eb, cnt, flag);
     if ((rc = check_launch("knn_pool_collect"))) return rc;
