@@ -447,12 +447,12 @@ int vit_forward(effocr_encoder* e, const void* x, int x16, int B, float* emb, in
   // the status word is STICKY: forwards only ever OR into it (final_cls_norm), effocr_encoder_check_status reads and clears it — so one
   // check covers every forward issued with this workspace since the previous check (sub-batches, slices of a large call, async callers)
   int* status = reinterpret_cast<int*>(ws + w.status);
-  if ((rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, nullptr, s))) return rc;
+  if (!patchf && (rc = set_cls_rows(F(e->off_clspos0), xs, B, T, D, blk, nullptr, s))) return rc;   // (the fused patch embedding writes the class-token rows itself)
   GemmArgs g{};
   if (patchf) {                                          // pixels -> tokens in one kernel: the patch rows never exist in HBM
     PatchArgs pa{};
     pa.x = x; pa.x16 = x16; pa.B = B; pa.H = e->img; pa.W = e->img; pa.Wb = wb + e->off_patchw_b; pa.bias = F(e->off_patchb); pa.pos = F(e->off_pos);
-    pa.out = xs; pa.D = D; pa.P = Pn;
+    pa.out = xs; pa.D = D; pa.P = Pn; pa.cls = F(e->off_clspos0);
     if ((rc = timed(e, "patch_embed_fused", 2.0 * B * Pn * Dd * 768.0, s, [&] { return patch_embed_fused(prec, pa, s); }))) return rc;
   } else {
   g.X = hb; g.ldx = 768; g.W = wb + e->off_patchw; g.ldw = 768; g.bias = F(e->off_patchb);

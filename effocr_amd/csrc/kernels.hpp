@@ -90,6 +90,8 @@ struct PatchArgs {
   int x16;                          // 1: x holds 16-bit values of the kernel's operand type (the crop transform's 16-bit hand-off)
   const void* Wb;                   // patch_embed.proj.weight [D, 768] fragment-blocked (16-bit), k = (c, py, px)
   const float* bias; const float* pos;   // [D]; pos_embed rows [1 + P, D] fp32
+  const float* cls;                 // optional [D]: cls_token + pos_embed[0] — the workgroup that holds an image's patch 0 also writes its class-token
+                                    // row img * (P + 1) (one launch less per forward: set_cls_rows)
   float* out;                       // fp32 residual stream, fragment-blocked: row img * (P + 1) + 1 + p
   int D, P;                         // embed dim, patches per image
 };

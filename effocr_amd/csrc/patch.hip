@@ -204,6 +204,12 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
         if (PATCH_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(ob + (f0 >> 2) * 512)); else *reinterpret_cast<f32x4*>(ob + (f0 >> 2) * 512) = o;
       }
     });
+    if (a.cls != nullptr && p == 0) {                      // the class-token row of this image (token 0 = row orow - 1), this slice's features
+      const int64_t crow = orow - 1;
+      char* cb = reinterpret_cast<char*>(a.out) + ((crow >> 5) * (a.D >> 2) + (n0 >> 2)) * 512 + (crow & 31) * 16;
+      for (int c = half; c < D / 4; c += 2)
+        *reinterpret_cast<f32x4*>(cb + c * 512) = *reinterpret_cast<const f32x4*>(a.cls + n0 + 4 * c);
+    }
   }
 }
 
