@@ -22,7 +22,9 @@ for li in range(16):
         x += w + int(rng.integers(2, 8))
 rows.append((0, 0, 900, 256, 3)); rows.append((100, 0, 700, 250, 5)); rows.append((5, 5, 5, 50, 1))      # down-scaling crops, an empty box
 bx = torch.tensor(rows, dtype=torch.int32, device=dev)
-for aa in (True, False):
+# run_effocr's own boxes (infer_effocr_onnx_multi.py:313-320): double-clipped to the full line height — 256-tall strips, padded to 256 x 256
+bx_c5 = bx.clone(); bx_c5[:, 1] = 0; bx_c5[:, 3] = 256
+for aa, bx in ((True, bx), (False, bx), (True, bx_c5)):
     tf = PairedTransform(size=224, antialias=aa, device=dev)
     out = tf.boxes_batch(imgs, bx)
     torch.cuda.synchronize()
