@@ -43,7 +43,7 @@ class HipEncoder:
         self._lock = threading.Lock()
         self._h = ctypes.c_void_p()
         _lib.check(self._L.effocr_encoder_create(arch.encode(), self.img_size, _lib.PREC[precision],
-                                                 ctypes.byref(self._h)), "effocr_encoder_create")
+                                                 ctypes.byref(self._h)), "effocr_encoder_create", self._L)
         self.embed_dim = int(self._L.effocr_encoder_embed_dim(self._h))
         sd = W.strip_prefix(state_dict)
         W.check_state_dict(arch, sd, self.img_size)
@@ -51,11 +51,11 @@ class HipEncoder:
             name = self._L.effocr_encoder_param_name(self._h, i).decode()
             t = sd[name].detach().to("cpu", torch.float32).contiguous()
             _lib.check(self._L.effocr_encoder_set_param(self._h, name.encode(), _lib.ptr(t), t.numel()),
-                       f"effocr_encoder_set_param({name})")
+                       f"effocr_encoder_set_param({name})", self._L)
         nbytes = int(self._L.effocr_encoder_weights_bytes(self._h))
         with torch.cuda.device(self.device):
             self._wblob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _lib.check(self._L.effocr_encoder_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_encoder_upload")
+            _lib.check(self._L.effocr_encoder_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_encoder_upload", self._L)
         self._ws = {}
 
     def __del__(self):
@@ -68,11 +68,11 @@ class HipEncoder:
 
     def set_chunk(self, crops_per_chunk):
         """Internal sub-batch size of the ViT forward (0 = whole batch); see effocr_encoder_set_chunk."""
-        _lib.check(self._L.effocr_encoder_set_chunk(self._h, int(crops_per_chunk)), "effocr_encoder_set_chunk")
+        _lib.check(self._L.effocr_encoder_set_chunk(self._h, int(crops_per_chunk)), "effocr_encoder_set_chunk", self._L)
         self._ws = {}
 
     def set_option(self, name, value):
-        _lib.check(self._L.effocr_encoder_set_option(self._h, name.encode(), int(value)), "effocr_encoder_set_option")
+        _lib.check(self._L.effocr_encoder_set_option(self._h, name.encode(), int(value)), "effocr_encoder_set_option", self._L)
         self._ws = {}
 
     def workspace_bytes(self, batch):
@@ -138,7 +138,7 @@ class HipEncoder:
     def profile_begin(self, only=None):
         """Arm the in-library profiler: every kernel class, or only the class named ``only``."""
         _lib.check(self._L.effocr_encoder_profile_begin(self._h, 2 if only else 1, only.encode() if only else None),
-                   "effocr_encoder_profile_begin")
+                   "effocr_encoder_profile_begin", self._L)
 
     def profile_collect(self):
         """-> {class: {"ms": total, "launches": n, "flops": total algorithmic FLOPs}} (synchronises)."""
@@ -149,7 +149,7 @@ class HipEncoder:
         for i in range(n):
             name, ms, cnt, work = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
             _lib.check(self._L.effocr_encoder_profile_get(self._h, i, ctypes.byref(name), ctypes.byref(ms),
-                                                          ctypes.byref(cnt), ctypes.byref(work)), "profile_get")
+                                                          ctypes.byref(cnt), ctypes.byref(work)), "profile_get", self._L)
             out[name.value.decode()] = {"ms": ms.value, "launches": cnt.value, "flops": work.value}
         return out
 

@@ -165,7 +165,7 @@ class IndexFlatIP:
         dst = torch.empty((rows.numel(), self.d), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._L.effocr_gather_rows(_lib.ptr(self._xb), _lib.ptr(rows), rows.numel(), self.d,
-                                                  _lib.ptr(dst), _lib.current_stream(self.device)), "effocr_gather_rows")
+                                                  _lib.ptr(dst), _lib.current_stream(self.device)), "effocr_gather_rows", self._L)
         self._xb = dst
         self._drop_copies()
         return int(ids.size)
@@ -217,7 +217,7 @@ class IndexFlatIP:
             ws = self._workspace(need)
             _lib.check(self._L.effocr_knn_ip_topk(_lib.ptr(q), n, _lib.ptr(self._xb), self.ntotal, self.d, k,
                                                   _lib.ptr(D), _lib.ptr(I), _lib.ptr(ws), ws.numel(),
-                                                  _lib.current_stream(self.device)), "effocr_knn_ip_topk")
+                                                  _lib.current_stream(self.device)), "effocr_knn_ip_topk", self._L)
         return D, I
 
     def search(self, x, k):

@@ -159,22 +159,22 @@ class HipLocalizer:
             raise ValueError("state dict does not match yolov5s: " + "; ".join(bad[:6]) + (f" (+{len(bad) - 6} more)" if len(bad) > 6 else ""))
         self._h = ctypes.c_void_p()
         _lib.check(self._L.effocr_localizer_create(b"yolov5s", self.nc, self.input_shape[0], self.input_shape[1], ctypes.byref(self._h)),
-                   "effocr_localizer_create")
+                   "effocr_localizer_create", self._L)
         for i in range(self._L.effocr_localizer_num_params(self._h)):
             name = self._L.effocr_localizer_param_name(self._h, i).decode()
             t = state_dict[name].detach().to("cpu", torch.float32).contiguous()
-            _lib.check(self._L.effocr_localizer_set_param(self._h, name.encode(), _lib.ptr(t), t.numel()), f"effocr_localizer_set_param({name})")
+            _lib.check(self._L.effocr_localizer_set_param(self._h, name.encode(), _lib.ptr(t), t.numel()), f"effocr_localizer_set_param({name})", self._L)
         nbytes = int(self._L.effocr_localizer_weights_bytes(self._h))
         with torch.cuda.device(self.device):
             self._wblob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _lib.check(self._L.effocr_localizer_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_localizer_upload")
+            _lib.check(self._L.effocr_localizer_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_localizer_upload", self._L)
         self.set_option("bf16_operands", 1 if precision == "bf16" else 0)
         self.num_predictions = int(self._L.effocr_localizer_num_predictions(self._h))
         self._ws = {}
         self._lock = threading.Lock()
 
     def set_option(self, name, value):
-        _lib.check(self._L.effocr_localizer_set_option(self._h, name.encode(), int(value)), "effocr_localizer_set_option")
+        _lib.check(self._L.effocr_localizer_set_option(self._h, name.encode(), int(value)), "effocr_localizer_set_option", self._L)
 
     def __del__(self):
         try:
@@ -207,7 +207,7 @@ class HipLocalizer:
         with self._lock, torch.cuda.device(self.device):
             ws = self._workspace("fwd", need)
             _lib.check(self._L.effocr_localizer_forward(self._h, _lib.ptr(x), B, _lib.ptr(pred), _lib.ptr(ws), ws.numel(),
-                                                        _lib.current_stream(self.device)), "effocr_localizer_forward")
+                                                        _lib.current_stream(self.device)), "effocr_localizer_forward", self._L)
         return pred
 
     def letterbox(self, image, bgr=False, out=None):
@@ -225,7 +225,7 @@ class HipLocalizer:
             raise ValueError("out must be a contiguous float32 [1,3,H,W] tensor on the localizer's device")
         with torch.cuda.device(self.device):
             _lib.check(self._L.effocr_letterbox(_lib.ptr(t), H, W, 3 * W, 1 if bgr else 0, self.input_shape[0], self.input_shape[1], nh, nw, top, left,
-                                                _lib.ptr(out), _lib.current_stream(self.device)), "effocr_letterbox")
+                                                _lib.ptr(out), _lib.current_stream(self.device)), "effocr_letterbox", self._L)
         return out
 
     def nms_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False, out=None, cnt=None):
@@ -248,7 +248,7 @@ class HipLocalizer:
             ws = self._workspace("nms", need)
             _lib.check(self._L.effocr_nms(_lib.ptr(pred), n, self.nc, float(conf_thres), float(iou_thres), int(max_det), MAX_NMS, MAX_WH,
                                           1 if agnostic else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(),
-                                          _lib.current_stream(self.device)), "effocr_nms")
+                                          _lib.current_stream(self.device)), "effocr_nms", self._L)
         return out, cnt
 
     def nms_batch_async(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False, out=None, cnt=None):
@@ -271,7 +271,7 @@ class HipLocalizer:
             ws = self._workspace("nms", max(need, 256))
             _lib.check(self._L.effocr_nms_batch(_lib.ptr(pred), B, n, self.nc, float(conf_thres), float(iou_thres), int(max_det), MAX_NMS, MAX_WH,
                                                 1 if agnostic else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(),
-                                                _lib.current_stream(self.device)), "effocr_nms_batch")
+                                                _lib.current_stream(self.device)), "effocr_nms_batch", self._L)
         return out, cnt
 
     def nms(self, pred, conf_thres, iou_thres, max_det=1000, agnostic=False):
