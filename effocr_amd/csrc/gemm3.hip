@@ -31,6 +31,16 @@ namespace {
 
 constexpr int G3RING = 4;
 
+// -DGEMM3_TRACE (tools/ab_build.sh variant, never shipped): wave 0 of every workgroup records s_memrealtime (100 MHz) at the milestones
+// of each of its first G3T_TILES tiles; tools/gemm3_timeline.py reads the last launch's table through effocr_debug_gemm3_stamps.
+#ifdef GEMM3_TRACE
+constexpr int G3T_WGS = 256, G3T_TILES = 48, G3T_N = 8;
+__device__ unsigned long long g3_stamps[G3T_WGS * G3T_TILES * G3T_N];
+#define G3_STAMP(k) tstamp[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define G3_STAMP(k)
+#endif
+
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
@@ -45,99 +55,90 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // those and finishes the normalisation.  Compile-time: a wave-uniform runtime flag put a branch around every store group of the epilogue
 // and the values held across them spilled next to the 256 accumulators.
 template <typename E, int NT, int JT, int EPI, typename TO, bool FOLD = false>
-__global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
   constexpr int TN = NT * 64, G3M = JT * 64;
   constexpr int XS = G3M * 64, WS = TN * 64, STAGE = XS + WS;          // bytes per 32-k stage
   constexpr int PX = XS / 1024, PW = WS / 1024, PP = (PX + PW) / 4;    // 1 KB DMA pieces: X, W, per wave
   static_assert((PX + PW) % 4 == 0, "pieces must split evenly over 4 waves");
-  __shared__ __attribute__((aligned(16))) char smem[G3RING * STAGE];
+  constexpr bool LNF = EPI != EPI_BIAS_RESID && FOLD;                  // consumer of a folded LayerNorm
+  // LDS: the ring, then this tile's bias and column sums (1 KB each) and, for a LayerNorm consumer, the row statistics of its G3M tokens
+  // (64 B each) — all of them DMA'd at the top of a tile and read in its epilogue: no vector-memory load sits between the main loop and
+  // the first store, and nothing of it occupies registers across the main loop.
+  constexpr int RINGB = G3RING * STAGE, BIAS_O = RINGB, LNS_O = RINGB + 1024, STAT_O = RINGB + 2048;
+  __shared__ __attribute__((aligned(16))) char smem[RINGB + 2048 + (LNF ? G3M * 64 : 0)];
   typedef typename Op16<E>::V8 V8;
   const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, half = lane >> 5;
   const int wv = wave_id(), wm = wv & 1, wn = wv >> 1;
   const int ntn = g.N / TN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  // tile order inside an XCD's run of consecutive ids: supertiles of GEMM3_SUPER row tiles, column-major inside — the ~32 workgroups an XCD
-  // runs at a time then share GEMM3_SUPER activation tiles and 32 / GEMM3_SUPER weight tiles (row-major order: 2.7 and all 9-12 of them,
-  // 5.8 MB against a 4 MB L2)
-  int mt, nt;
-  if (GEMM3_SUPER > 1) {
-    const int mtiles = (int)gridDim.x / ntn;
-    const int per = GEMM3_SUPER * ntn, grp = bid / per, rem = bid - grp * per;
-    const int rows = mtiles - grp * GEMM3_SUPER < GEMM3_SUPER ? mtiles - grp * GEMM3_SUPER : GEMM3_SUPER;
-    nt = rem / rows; mt = grp * GEMM3_SUPER + (rem - nt * rows);
-  } else { mt = bid / ntn; nt = bid - mt * ntn; }
-  const int m0 = mt * G3M, n0 = nt * TN;
-  const int nst = g.K >> 5;
+  const int mtiles = (g.M + G3M - 1) / G3M, ntiles = mtiles * ntn;
+  const int nst = g.K >> 5;                                            // a multiple of 4, >= 8 (gemm3_supported)
   const int kch = g.K >> 3;                                            // 16-byte chunks per operand row
   const int last_rb = (g.rows_alloc >> 5) - 1;                         // last addressable X row block
-
-  // Folded LayerNorm (consumer side): the row statistics of this lane's JT tokens are requested FIRST — oldest in the in-order VM queue, so
-  // they have landed when the ring's stage 0 has — and reduced to (rstd, -mean rstd) behind the first barrier.  (Loaded in the epilogue
-  // they were four dependent HBM round trips per tile, one per token tile: fc1 908 -> 863 TFLOP/s.)
-  constexpr bool LNF = EPI != EPI_BIAS_RESID && FOLD;
-  f32x4 stv[JT][4];
-  float rstd_j[JT], nmr_j[JT];
-  if constexpr (LNF) {
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const int m = m0 + wm * JT * 32 + j * 32 + r31;
-      const f32x4* st = reinterpret_cast<const f32x4*>(g.lnf_stats + (size_t)(m < g.M ? m : g.M - 1) * 16);
-#pragma unroll
-      for (int p2 = 0; p2 < 4; ++p2) stv[j][p2] = st[p2];               // slices 2 p2, 2 p2 + 1: (sum, sum of squares) each
-    }
-  }
-
-  // per-lane DMA sources; piece q (1 KB = two adjacent 16-B chunk cells of one 32-row block) lands at q KB
-  const char* src[PP];
-#pragma unroll
-  for (int i = 0; i < PP; ++i) {
-    const int q = wv * PP + i;
-    if (q < PX) {
-      int rb = (m0 >> 5) + (q >> 1);
-      rb = rb < last_rb ? rb : last_rb;                                // rows past the buffer: any valid block
-      src[i] = static_cast<const char*>(g.X) + ((size_t)rb * kch + 2 * (q & 1)) * 512 + lane * 16;
-    } else {
-      const int qq = q - PX;
-      src[i] = static_cast<const char*>(g.Wblk) + ((size_t)((n0 >> 5) + (qq >> 1)) * kch + 2 * (qq & 1)) * 512 + lane * 16;
-    }
-  }
-  auto issue_piece = [&](int s, int i) {                   // DMA piece i of stage s (caller checks s < nst)
-    char* dst = smem + (s & (G3RING - 1)) * STAGE + wv * PP * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * 2048),
-                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  // PERSISTENT tiles on a CONTINUOUS ring.  The launch has one workgroup per CU (the ring leaves room for one); workgroup b runs tiles
+  // b, b + G, b + 2G, ... and the last four stages of a tile already request the first four of the next one, so the ring never drains:
+  // the epilogue of tile t runs while stages 0-3 of tile t + 1 land, its stores drain under the first stages of t + 1, and the first
+  // k-step of a tile starts from a zero C operand instead of 256 zeroed accumulators.  (One tile per workgroup, measured by compiling
+  // parts out: 7.8 us of turn-around per K = 768 tile — last store acknowledged, launch, zeroing, a cold ring — and a residual epilogue of
+  // 27-36 us: 21 + 5 us of a 26 us qkv tile, 57 + 36 of a 97 us fc2 tile.)
+  // Tile order: virtual id v = round * G + b walks the XCD's contiguous run of ids (xcd_remap), inside it supertiles of GEMM3_SUPER row
+  // tiles, column-major — the ~32 workgroups an XCD runs at a time share GEMM3_SUPER activation tiles and 32 / GEMM3_SUPER weight tiles
+  // (row-major order: 2.7 and all 9-12 of them, 5.8 MB against a 4 MB L2).
+  auto tile_origin = [&](int v, int& m0_, int& n0_, int& nt_) {
+    const int bid = xcd_remap(v, ntiles);
+    int mt;
+    if (GEMM3_SUPER > 1) {
+      const int per = GEMM3_SUPER * ntn, grp = bid / per, rem = bid - grp * per;
+      const int rows = mtiles - grp * GEMM3_SUPER < GEMM3_SUPER ? mtiles - grp * GEMM3_SUPER : GEMM3_SUPER;
+      nt_ = rem / rows; mt = grp * GEMM3_SUPER + (rem - nt_ * rows);
+    } else { mt = bid / ntn; nt_ = bid - mt * ntn; }
+    m0_ = mt * G3M; n0_ = nt_ * TN;
   };
+  int v = blockIdx.x;
+  if (v >= ntiles) return;
+  int m0, n0, nt;
+  tile_origin(v, m0, n0, nt);
+
+  // DMA sources: piece q (1 KB = two adjacent 16-B chunk cells of one 32-row block) lands at q KB.  A piece's address is wave-uniform
+  // but for lane * 16: the bases live in SGPR pairs (the tile-to-tile set-up is scalar code, nothing of it occupies a vector register
+  // next to the 256 accumulators) and ONE vector offset, lane * 16 + stage * 2048, serves all of a stage's pieces.
+  const char* sb[PP];
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
-  for (int s = 0; s < G3RING; ++s)
-    if (s < nst) {
-#pragma unroll
-      for (int i = 0; i < PP; ++i) issue_piece(s, i);
+    for (int i = 0; i < PP; ++i) {
+      const int q = wv * PP + i;
+      if (q < PX) {
+        int rb = (m0_ >> 5) + (q >> 1);
+        rb = rb < last_rb ? rb : last_rb;                              // rows past the buffer: any valid block
+        sb[i] = static_cast<const char*>(g.X) + ((size_t)rb * kch + 2 * (q & 1)) * 512;
+      } else {
+        const int qq = q - PX;
+        sb[i] = static_cast<const char*>(g.Wblk) + ((size_t)((n0_ >> 5) + (qq >> 1)) * kch + 2 * (qq & 1)) * 512;
+      }
     }
-  // Steady state: the same piece as ONE inline-asm statement.  hipcc models __builtin_amdgcn_global_load_lds as an access to both
-  // address spaces ("pending flat") and makes its NEXT LDS wait s_waitcnt lgkmcnt(0): a DMA piece placed between two MFMAs
-  // drained the fragment reads issued around it (mlp_kernel.hpp: 70 of 73 LDS waits of the loop were full drains).  Completion
-  // is counted by hand either way (vmcnt at the stage barrier).  M0 = the piece's LDS address (saved / restored: the register is
-  // the compiler's), s_nop = the M0-write -> LDS-DMA wait state.
+  };
+  // One DMA piece as ONE inline-asm statement: 64 lanes x 16 B from base + voff to the LDS address in M0.  hipcc models
+  // __builtin_amdgcn_global_load_lds as an access to both address spaces ("pending flat") and makes its NEXT LDS wait s_waitcnt
+  // lgkmcnt(0): a DMA piece placed between two MFMAs drained the fragment reads issued around it (mlp_kernel.hpp: 70 of 73 LDS waits of
+  // the loop were full drains), and any ordinary load waited for next to it gets vmcnt(0).  Completion is counted by hand (vmcnt at the
+  // stage barriers).  M0 is saved / restored (the register is the compiler's), s_nop = the M0-write -> LDS-DMA wait state.
   const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  auto issue_piece_asm = [&](int s, int i) {
-    const char* p = src[i] + (size_t)s * 2048;
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_lds + (unsigned)((s & (G3RING - 1)) * STAGE) + (unsigned)((wv * PP + i) * 1024)));
+  auto dma = [&](unsigned voff, const char* base, unsigned lds) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %2\n\t"
+                 "s_mov_b32 m0, %3\n\t"
                  "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  };
+  // piece i of ring stage S (of the tile sb[] points at; voff = lane16 + (stage << 11))
+  auto ring_piece = [&](unsigned voff, int S, int i) {
+    dma(voff, sb[i], smem_lds + (unsigned)((S & (G3RING - 1)) * STAGE) + (unsigned)((wv * PP + i) * 1024));
   };
 
   f32x16 acc[NT][JT];                                                  // [feature tile][token tile]
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int xo = (wm * JT * 4 + half) * 512 + r31 * 16;                // (row block wm*JT + j, chunk 2*c4 + half)
   const int wo = XS + (wn * NT * 4 + half) * 512 + r31 * 16;
   struct Frags { V8 w[NT]; V8 x[JT]; };
@@ -150,11 +151,17 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   };
   // One k16 step: MFMA n = (feature tile n / JT, token tile n % JT); `between(n)` is issued in its shadow
   // (with one wave per SIMD, whatever sits between two MFMAs instead of under one idles the matrix pipe).
-  auto mma_step = [&](const Frags& f, auto&& between) {
+  // ZERO: the first step of a tile accumulates onto a zero operand (the accumulators still hold the previous tile).
+  auto mma_step = [&](const Frags& f, auto ZERO, auto&& between) {
     static_for<0, NMM>([&](auto N_) {
       constexpr int n = decltype(N_)::value;
       constexpr int i = n / JT, j = n % JT;
-      acc[i][j] = Op16<E>::mfma(f.w[i], f.x[j], acc[i][j]);
+      if constexpr (decltype(ZERO)::value) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[i][j] = Op16<E>::mfma(f.w[i], f.x[j], z);
+      } else {
+        acc[i][j] = Op16<E>::mfma(f.w[i], f.x[j], acc[i][j]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       between(N_);
       __builtin_amdgcn_sched_barrier(0);
@@ -165,179 +172,265 @@ __global__ __launch_bounds__(256, (JT == 2 ? 2 : 1)) void gemm3_kernel(GemmArgs 
   };
 
   Frags fa, fb;
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PP) : "memory");        // stage 0 (own pieces) ...
-  __builtin_amdgcn_s_barrier();                                        // ... and everybody's
-  asm volatile("" ::: "memory");
-  static_for<0, NF>([&](auto N_) { load_one(fa, smem, 0, N_); });
-  if constexpr (LNF) {
-    const int np = g.K >> 7;                                           // 128-feature slices the producer cut the row into (<= 8)
-    const float invk = 1.0f / (float)g.K;
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      float S = 0.f, SS = 0.f;
-#pragma unroll
-      for (int p2 = 0; p2 < 4; ++p2) {
-        if (2 * p2 < np) { S += stv[j][p2][0]; SS += stv[j][p2][1]; }
-        if (2 * p2 + 1 < np) { S += stv[j][p2][2]; SS += stv[j][p2][3]; }
-      }
-      const float mean = S * invk;
-      float var = SS * invk - mean * mean;
-      var = var > 0.f ? var : 0.f;
-      rstd_j[j] = 1.0f / sqrtf(var + g.lnf_eps);
-      nmr_j[j] = -mean * rstd_j[j];
-      asm volatile("" : "+v"(rstd_j[j]), "+v"(nmr_j[j]));              // pin the reduction HERE (sunk to its use in the epilogue, the 16 raw registers per token tile stayed live across the main loop and spilled)
-    }
-  }
-
-  // One stage.  MORE: stage s+4 exists (DMA it), NEXT: stage s+1 exists (prefetch its fragments).  Both are
-  // compile-time so that the steady state is ONE basic block: with a single wave per SIMD every scalar
-  // branch between two MFMAs is a bubble in the matrix pipe (measured: 57% -> see profiles/README.md).
-  auto stage = [&](int s, auto MORE, auto NEXT) {
-    constexpr bool more = decltype(MORE)::value, next = decltype(NEXT)::value;
+  // One stage s of a tile; in its second half it requests ring stage s + 4 — of this tile, or (WRAP, the last four stages; sb[] has been
+  // switched) stage s + 4 - nst of the next one.  WAIT: stage s + 1 is awaited by count — everything but the newest two stages' pieces
+  // of the in-order VM queue has completed.  Stages 0-2 of a tile do not wait: their successors were requested before the previous
+  // epilogue, which has seen them land (below), and a count would also wait for that epilogue's newest stores.  NEXT: stage s + 1
+  // belongs to this tile (prefetch its fragments).  All compile-time so that the steady state is ONE basic block: with a single wave
+  // per SIMD every scalar branch between two MFMAs is a bubble in the matrix pipe (measured: 57%, profiles/README.md).
+  auto stage = [&](int s, auto WAIT, auto WRAP, auto NEXT, auto FIRST) {
+    constexpr bool wait = decltype(WAIT)::value, wrap = decltype(WRAP)::value, next = decltype(NEXT)::value;
     const char* st = smem + (s & (G3RING - 1)) * STAGE;
     const char* stn = smem + ((s + 1) & (G3RING - 1)) * STAGE;
     // k16 step 0; the fragments of step 1 are read in its shadow
-    mma_step(fa, [&](auto N_) {
+    mma_step(fa, FIRST, [&](auto N_) {
       if constexpr (decltype(N_)::value < NF) load_one(fb, st, 1, N_);
     });
     // stage s+1 landed (own pieces; s+2, s+3 may stay in flight), every wave holds its stage-s fragments
     // in registers -> past the barrier slot s&3 is free for stage s+4
-    if constexpr (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (wait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // k16 step 1; in its shadow: DMA of stage s+4 and the fragments of stage s+1, step 0
-    mma_step(fb, [&](auto N_) {
+    const unsigned voff = lane16 + ((unsigned)(wrap ? s + 4 - nst : s + 4) << 11);
+    mma_step(fb, std::false_type{}, [&](auto N_) {
       constexpr int n = decltype(N_)::value;
-      if constexpr (more && n < PP) issue_piece_asm(s + 4, n);
+      if constexpr (n < PP) ring_piece(voff, s + 4, n);                // (nst % 4 == 0: the slot is (s + 4) & 3 either way)
       if constexpr (next && n < NF) load_one(fa, stn, 0, N_);
     });
   };
-  {
-    int s = 0;
-    for (; s + 4 < nst; ++s) stage(s, std::true_type{}, std::true_type{});
-    for (; s + 1 < nst; ++s) stage(s, std::false_type{}, std::true_type{});
-    stage(s, std::false_type{}, std::false_type{});
-  }
+  constexpr std::true_type T_{};
+  constexpr std::false_type F_{};
 
-  // ---- epilogue: lane = token (m0 + (wm*JT + j)*32 + r31), 4 consecutive features per (i, q): n = nb + 32 i + 8 q.
-  // Addresses: ONE 64-bit base per token tile j and operand, everything else is a compile-time offset — a lane's features (i, q) sit in
-  // fp32 chunk c4 + 8 i + 2 q and in 16-bit chunk c8 + 4 i + q (bytes 8 half .. 8 half + 7) of its row, chunks are 512 bytes apart.
-  // (blk_off per (i, q) cost a 64-bit multiply-add each and, next to 256 accumulators, spilled the bias registers.)
-  constexpr int CH = 16 / (int)sizeof(TO);                             // elements per 16-byte output chunk
-  const int ns = n0 + wn * NT * 32;                                    // first feature of the wave's slice (a multiple of 32)
-  const int nb = ns + 4 * half;
-  f32x4 bv[NT][4];
+  // ---- first tile: fill the ring and see it land
+  set_src(m0, n0);
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int S = 0; S < G3RING; ++S)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(g.bias + nb + i * 32 + 8 * q);
-  // LayerNorm folded into this linear (GemmArgs::lnf; wave-uniform): X holds the UN-normalised rows as 16-bit operands, W carries gamma,
-  // bias carries W.beta, and the row statistics arrive as per-slice partial sums written by the producer of the rows (below):
-  //     y = rstd (acc - mean s[n]) + bias[n],   s[n] = sum_k W'[n][k]
-  constexpr bool lnf = EPI != EPI_BIAS_RESID && FOLD;
-  constexpr bool do16 = EPI == EPI_BIAS_RESID && FOLD;                // producer: rows also as 16-bit operands ...
-  constexpr bool dost = do16;                                          // ... + per-slice (sum, sum of squares) of every row
-  f32x4 sv[NT][4];
-  if constexpr (lnf) {
+    for (int i = 0; i < PP; ++i) ring_piece(lane16 + ((unsigned)S << 11), S, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#ifdef GEMM3_TRACE
+  unsigned long long tstamp[G3T_N] = {};
+  int titer = 0;
+#endif
+  for (;;) {                                                           // ---- one tile per iteration
+    G3_STAMP(0)
+#ifdef GEMM3_TRACE
+    tstamp[7] = __builtin_amdgcn_s_memtime();
+#endif
+    // every wave has seen its pieces of stages 0-3 land and has left the previous epilogue (bias / statistics areas are free)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const int bl = lane < TN / 4 ? lane : TN / 4 - 1;                // (TN = 192: the last lanes repeat the last 16 bytes)
+      if (wv == 0) dma((unsigned)bl * 16u, reinterpret_cast<const char*>(g.bias + n0), smem_lds + BIAS_O);
+      if constexpr (LNF) {
+        if (wv == 1) dma((unsigned)bl * 16u, reinterpret_cast<const char*>(g.lnf_s + n0), smem_lds + LNS_O);
+#pragma unroll
+        for (int k = 0; k < JT; ++k) {                                 // 16 tokens x 64 B per piece
+          const int p = wv * JT + k;
+          int row = m0 + 16 * p;
+          row = row < g.rows_alloc - 16 ? row : g.rows_alloc - 16;     // (rows past M are never stored; the buffer has rows_alloc rows)
+          dma(lane16, reinterpret_cast<const char*>(g.lnf_stats + (size_t)row * 16), smem_lds + STAT_O + p * 1024);
+        }
+      }
+    }
+    G3_STAMP(1)
+    static_for<0, NF>([&](auto N_) { load_one(fa, smem, 0, N_); });
+    stage(0, F_, F_, T_, T_);
+    stage(1, F_, F_, T_, F_);
+    stage(2, F_, F_, T_, F_);
+    G3_STAMP(2)
+    int s = 3;
+#ifdef GEMM3_TRACE
+    stage(s, T_, F_, T_, F_); ++s;
+    G3_STAMP(3)
+#endif
+    for (; s + 4 < nst; ++s) stage(s, T_, F_, T_, F_);
+    // ---- the next tile (the last tile of a workgroup requests itself again and drains that before it exits: no branch here)
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < ntiles;
+    int m0n, n0n, ntn_;
+    tile_origin(has_next ? vn : v, m0n, n0n, ntn_);
+    set_src(m0n, n0n);
+    for (; s + 1 < nst; ++s) stage(s, T_, T_, T_, F_);
+    stage(s, T_, T_, F_, F_);
+    G3_STAMP(4)
+
+    // ---- epilogue: lane = token (m0 + (wm*JT + j)*32 + r31), 4 consecutive features per (i, q): n = nb + 32 i + 8 q.
+    // Addresses: ONE 64-bit base per token tile j and operand, everything else is a compile-time offset — a lane's features (i, q) sit in
+    // fp32 chunk c4 + 8 i + 2 q and in 16-bit chunk c8 + 4 i + q (bytes 8 half .. 8 half + 7) of its row, chunks are 512 bytes apart.
+    // (blk_off per (i, q) cost a 64-bit multiply-add each and, next to 256 accumulators, spilled the bias registers.)
+    constexpr int CH = 16 / (int)sizeof(TO);                           // elements per 16-byte output chunk
+    const int ns = n0 + wn * NT * 32;                                  // first feature of the wave's slice (a multiple of 32)
+    const int nbl = (wn * NT * 32 + 4 * half) * 4;                     // byte offset of the lane's first feature in the LDS bias / sums
+    f32x4 bv[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sv[i][q] = *reinterpret_cast<const f32x4*>(g.lnf_s + nb + i * 32 + 8 * q);
-  }
-#pragma unroll
-  for (int j = 0; j < JT; ++j) {
-    const int m = m0 + wm * JT * 32 + j * 32 + r31;
-    const bool ok = m < g.M;
-    const int mr = ok ? m : g.M - 1;
-    const int64_t rbi = mr >> 5;
-    const int rl = (mr & 31) * 16;
-    char* ob = static_cast<char*>(g.out) + (rbi * (g.N / CH) + ns / CH) * 512 + rl + (CH == 4 ? half * 512 : half * 8);
-    constexpr int OI = CH == 4 ? 8 * 512 : 4 * 512, OQ = CH == 4 ? 2 * 512 : 512;   // byte steps of i and q
-    float rstd = 1.f, nmr = 0.f;                                       // lnf: 1 / sqrt(var + eps), -mean * rstd of this lane's token
-    if constexpr (lnf) { rstd = rstd_j[j]; nmr = nmr_j[j]; }
-    if constexpr (EPI == EPI_BIAS_RESID) {
-      const char* rp = reinterpret_cast<const char*>(g.resid) + (rbi * (g.N / 4) + ns / 4) * 512 + rl + half * 512;
-      f32x4 rv[NT][4];
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(smem + BIAS_O + nbl + (i * 32 + 8 * q) * 4);
+    // LayerNorm folded into this linear (GemmArgs::lnf; wave-uniform): X holds the UN-normalised rows as 16-bit operands, W carries gamma,
+    // bias carries W.beta, and the row statistics arrive as per-slice partial sums written by the producer of the rows (below):
+    //     y = rstd (acc - mean s[n]) + bias[n],   s[n] = sum_k W'[n][k]
+    constexpr bool lnf = LNF;
+    constexpr bool do16 = EPI == EPI_BIAS_RESID && FOLD;              // producer: rows also as 16-bit operands ...
+    constexpr bool dost = do16;                                        // ... + per-slice (sum, sum of squares) of every row
+    f32x4 sv[NT][4];
+    if constexpr (lnf) {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          rv[i][q] = GEMM3_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + i * OI + q * OQ))
-                              : *reinterpret_cast<const f32x4*>(rp + i * OI + q * OQ);
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[i][q][e];
+        for (int q = 0; q < 4; ++q) sv[i][q] = *reinterpret_cast<const f32x4*>(smem + LNS_O + nbl + (i * 32 + 8 * q) * 4);
     }
-    float psum = 0.f, psq = 0.f;                                       // producer: this lane's share of the slice's (sum, sum of squares)
-    char* x16b = do16 ? static_cast<char*>(g.x16) + (rbi * (g.N / 8) + ns / 8) * 512 + rl + half * 8 : nullptr;
+    // Residual epilogue: the fp32 residual tile is read in chunks c = (token tile j, feature tile i) of four 16-byte loads per lane, RD
+    // chunks AHEAD and in FRONT of the stores of the chunk in hand.  (One token tile at a time — 16 loads, wait, add, 32 stores — put
+    // every load behind the previous token tile's stores in the in-order VM queue: four times [store acknowledge + load latency].  resid
+    // may alias out: a lane reads a value before the same lane overwrites it and nobody else touches it.)  The loads are younger than the
+    // ring requests of the next tile's stages 1-3: consuming one has seen those land.
+    constexpr int RD = 3, NC = JT * NT;
+    f32x4 rv[RD][4];
+    const char* rpj[JT];
+    auto load_chunk = [&](int c) {
+      const int j = c / NT, i = c % NT;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      float v[16];
+      for (int q = 0; q < 4; ++q) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(rpj[j] + i * (8 * 512) + q * (2 * 512));
+        rv[c % RD][q] = GEMM3_NT ? __builtin_nontemporal_load(p) : *p;
+      }
+    };
+    if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int m = m0 + wm * JT * 32 + j * 32 + r31;
+        const int mr = m < g.M ? m : g.M - 1;
+        rpj[j] = reinterpret_cast<const char*>(g.resid) + ((int64_t)(mr >> 5) * (g.N / 4) + ns / 4) * 512 + (mr & 31) * 16 + half * 512;
+      }
+#pragma unroll
+      for (int c = 0; c < RD && c < NC; ++c) load_chunk(c);
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int m = m0 + wm * JT * 32 + j * 32 + r31;
+      const bool ok = m < g.M;
+      const int mr = ok ? m : g.M - 1;
+      const int64_t rbi = mr >> 5;
+      const int rl = (mr & 31) * 16;
+      char* ob = static_cast<char*>(g.out) + (rbi * (g.N / CH) + ns / CH) * 512 + rl + (CH == 4 ? half * 512 : half * 8);
+      constexpr int OI = CH == 4 ? 8 * 512 : 4 * 512, OQ = CH == 4 ? 2 * 512 : 512;   // byte steps of i and q
+      float rstd = 1.f, nmr = 0.f;                                     // lnf: 1 / sqrt(var + eps), -mean * rstd of this lane's token
       if constexpr (lnf) {
-        // as two-element vector FMAs (v_pk_fma_f32 with the row scalars duplicated): left to itself the GELU variant scalarised the 512
-        // FMAs of a (i, j) tile pair — +22 % epilogue instructions, fc1 908 -> 840 TFLOP/s
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 r2 = {rstd, rstd}, n2 = {nmr, nmr};
+        const f32x4* st = reinterpret_cast<const f32x4*>(smem + STAT_O + (wm * JT * 32 + j * 32 + r31) * 64);
+        const int np = g.K >> 7;                                       // 128-feature slices the producer cut the row into (<= 8)
+        const float invk = 1.0f / (float)g.K;
+        float S = 0.f, SS = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int p2 = 0; p2 < 4; ++p2) {                               // slices 2 p2, 2 p2 + 1: (sum, sum of squares) each
+          const f32x4 t = st[p2];
+          if (2 * p2 < np) { S += t[0]; SS += t[1]; }
+          if (2 * p2 + 1 < np) { S += t[2]; SS += t[3]; }
+        }
+        const float mean = S * invk;
+        float var = SS * invk - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        rstd = 1.0f / sqrtf(var + g.lnf_eps);
+        nmr = -mean * rstd;
+      }
+      float psum = 0.f, psq = 0.f;                                     // producer: this lane's share of the slice's (sum, sum of squares)
+      char* x16b = do16 ? static_cast<char*>(g.x16) + (rbi * (g.N / 8) + ns / 8) * 512 + rl + half * 8 : nullptr;
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const f32x2 a2 = {acc[i][j][4 * q + e], acc[i][j][4 * q + e + 1]};
-            const f32x2 s2 = {sv[i][q][e], sv[i][q][e + 1]}, b2 = {bv[i][q][e], bv[i][q][e + 1]};
-            const f32x2 y2 = __builtin_elementwise_fma(a2, r2, __builtin_elementwise_fma(n2, s2, b2));
-            v[4 * q + e] = y2[0]; v[4 * q + e + 1] = y2[1];
+      for (int i = 0; i < NT; ++i) {
+        float v[16];
+        if constexpr (EPI == EPI_BIAS_RESID) {
+          const int c = j * NT + i;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[c % RD][q][e];
+          if (c + RD < NC) load_chunk(c + RD);
+        }
+        if constexpr (lnf) {
+          // as two-element vector FMAs (v_pk_fma_f32 with the row scalars duplicated): left to itself the GELU variant scalarised the 512
+          // FMAs of a (i, j) tile pair — +22 % epilogue instructions, fc1 908 -> 840 TFLOP/s
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 r2 = {rstd, rstd}, n2 = {nmr, nmr};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const f32x2 a2 = {acc[i][j][4 * q + e], acc[i][j][4 * q + e + 1]};
+              const f32x2 s2 = {sv[i][q][e], sv[i][q][e + 1]}, b2 = {bv[i][q][e], bv[i][q][e + 1]};
+              const f32x2 y2 = __builtin_elementwise_fma(a2, r2, __builtin_elementwise_fma(n2, s2, b2));
+              v[4 * q + e] = y2[0]; v[4 * q + e + 1] = y2[1];
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + bv[i][q][e];
+        }
+        if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { psum += v[e]; psq = __builtin_fmaf(v[e], v[e], psq); }
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) gelu_fold_n<E, 16>(v);       // (on the fp32 pre-activation; rounding it to 16 bits first, as the row-panel kernel's hand-over does, cost a convert + shift per value: 18 % of this epilogue's instructions)
+        if constexpr (EPI != EPI_BIAS_RESID) {
+          // no load of this epilogue is younger than the next tile's ring requests: see them land (own pieces) before the first store
+          // joins the queue — from here to stage 3 of the next tile nothing is awaited by count
+          if (j == 0 && i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#ifdef GEMM3_TRACE
+        if (j == 0 && i == 0) { asm volatile("" :: "v"(v[0]), "v"(v[15])); G3_STAMP(5) }
+#endif
+        if (ok) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            char* p = ob + i * OI + q * OQ;
+            if constexpr (sizeof(TO) == 4) {
+              const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+              if (GEMM3_NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = o;
+            } else {
+              const u32x2 o2 = pack4<TO>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+              if (GEMM3_NT & 2) __builtin_nontemporal_store(o2, reinterpret_cast<u32x2*>(p)); else *reinterpret_cast<u32x2*>(p) = o2;
+            }
+            if constexpr (EPI == EPI_BIAS_RESID) {
+              if constexpr (do16)                                        // the new residual row as 16-bit operands of the next (LayerNorm-folded) linear
+                *reinterpret_cast<u32x2*>(x16b + (i * 4 + q) * 512) = pack4<E>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
           }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + bv[i][q][e];
+        }
       }
       if constexpr (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { psum += v[e]; psq = __builtin_fmaf(v[e], v[e], psq); }
-      }
-      if constexpr (EPI == EPI_BIAS_GELU) gelu_fold_n<E, 16>(v);         // (on the fp32 pre-activation; rounding it to 16 bits first, as the row-panel kernel's hand-over does, cost a convert + shift per value: 18 % of this epilogue's instructions)
-      if (ok) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          char* p = ob + i * OI + q * OQ;
-          if constexpr (sizeof(TO) == 4) {
-            const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            if (GEMM3_NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = o;
-          } else {
-            const u32x2 o2 = pack4<TO>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            if (GEMM3_NT & 2) __builtin_nontemporal_store(o2, reinterpret_cast<u32x2*>(p)); else *reinterpret_cast<u32x2*>(p) = o2;
-          }
-          if constexpr (EPI == EPI_BIAS_RESID) {
-            if constexpr (do16)                                          // the new residual row as 16-bit operands of the next (LayerNorm-folded) linear
-              *reinterpret_cast<u32x2*>(x16b + (i * 4 + q) * 512) = pack4<E>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if constexpr (dost) {                                            // slice (column tile, wave half) of the row: both half-waves' shares, one writer
+          psum += __shfl_xor(psum, 32, 64);
+          psq += __shfl_xor(psq, 32, 64);
+          if (ok && half == 0) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2*>(g.stats + (size_t)mr * 16 + (nt * 2 + wn) * 2) = f32x2{psum, psq};
           }
         }
       }
     }
-    if constexpr (EPI == EPI_BIAS_RESID) {
-      if constexpr (dost) {                                              // slice (column tile, wave half) of the row: both half-waves' shares, one writer
-        psum += __shfl_xor(psum, 32, 64);
-        psq += __shfl_xor(psq, 32, 64);
-        if (ok && half == 0) {
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          *reinterpret_cast<f32x2*>(g.stats + (size_t)mr * 16 + (nt * 2 + wn) * 2) = f32x2{psum, psq};
-        }
-      }
+#ifdef GEMM3_TRACE
+    G3_STAMP(6)
+    if (wv == 0 && blockIdx.x < G3T_WGS && titer < G3T_TILES) {
+#pragma unroll
+      for (int k = 0; k < G3T_N; ++k) g3_stamps[((size_t)blockIdx.x * G3T_TILES + titer) * G3T_N + k] = tstamp[k];
     }
-  }
+    ++titer;
+#endif
+    if (!has_next) break;
+    v = vn; m0 = m0n; n0 = n0n; nt = ntn_;
+  }                                                                    // tiles
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the self-request of the last tile: nothing may land in LDS after the workgroup has gone
 }
 
 
 template <typename E, int NT, int JT>
 int launch3_tile(int epi, const GemmArgs& g, hipStream_t s) {
-  const int grid = ((g.M + JT * 64 - 1) / (JT * 64)) * (g.N / (NT * 64));
+  const int tiles = ((g.M + JT * 64 - 1) / (JT * 64)) * (g.N / (NT * 64)), slots = device_cus();
+  const int grid = tiles < slots ? tiles : slots;                        // persistent: one workgroup per CU walks tiles b, b + grid, ...
   const bool fold = g.lnf != 0 || g.stats != nullptr;
   if constexpr (NT != 4) {                                               // the folded LayerNorm is built for 256-wide tiles only (gemm3_nt checks)
     switch (epi) {
@@ -404,12 +497,12 @@ int launch3(int epi, const GemmArgs& g, hipStream_t s) {
 bool gemm3_lnfold_supported(int D) { return D % 256 == 0 && D / 128 <= 8; }   // (256-wide tiles on both sides: ViT-B 768, ViT-L 1024)
 
 bool gemm3_supported(int prec, int N, int K) {
-  return (prec == PREC_BF16 || prec == PREC_FP16) && N > 0 && (N % 256 == 0 || N % 192 == 0) && K >= 128 && K % 32 == 0;
+  return (prec == PREC_BF16 || prec == PREC_FP16) && N > 0 && (N % 256 == 0 || N % 192 == 0) && K >= 256 && K % 128 == 0;
 }
 
 int gemm3_nt(int prec, int epi, const GemmArgs& g_in, hipStream_t s) {
   if (g_in.M <= 0) return EFFOCR_OK;
-  if (!gemm3_supported(prec, g_in.N, g_in.K)) return fail(EFFOCR_EUNSUPPORTED, "gemm3: needs bf16/fp16, N % 192 == 0 or N % 256 == 0, K % 32 == 0, K >= 128");
+  if (!gemm3_supported(prec, g_in.N, g_in.K)) return fail(EFFOCR_EUNSUPPORTED, "gemm3: needs bf16/fp16, N % 192 == 0 or N % 256 == 0, K % 128 == 0, K >= 256");
   if (!g_in.Wblk || !g_in.blk_x || !g_in.blk_out) return fail(EFFOCR_EINVAL, "gemm3: operands and output must be fragment-blocked");
   GemmArgs g = g_in;
   if (g.rows_alloc <= 0) g.rows_alloc = ((g.M + 31) / 32) * 32;
@@ -424,3 +517,10 @@ int gemm3_nt(int prec, int epi, const GemmArgs& g_in, hipStream_t s) {
 }
 
 }  // namespace effocr
+
+#ifdef GEMM3_TRACE
+extern "C" int effocr_debug_gemm3_stamps(unsigned long long* out, int n) {
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(effocr::g3_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif

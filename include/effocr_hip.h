@@ -330,7 +330,7 @@ int effocr_op_attention(int precision, const void* qkv_dev, void* out_dev, int b
  * for fp32.  Buffers must be addressable up to `rows_alloc` rows (a multiple of 32, >= m).
  *   linear_blocked:    out = epilogue(x . w^T + bias); x_blk [m,k] and w_blk [n,k] in `precision`'s 16-bit
  *                      type, out_blk 16-bit (epilogue 0/1) or fp32 with fp32 resid_blk (epilogue 2, may alias
- *                      out); n % 192 == 0 or n % 256 == 0, k % 32 == 0, k >= 128 (the timm Linear layers of
+ *                      out); n % 192 == 0 or n % 256 == 0, k % 128 == 0, k >= 256 (the timm Linear layers of
  *                      ViT-S fc2 and of every ViT-B block; models/encoders.py:58,63)
  *   layernorm_blocked: fp32 x_blk [rows,d] -> 16-bit out_blk, d in {128, 384, 768} */
 int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev, const void* w_blk_dev,

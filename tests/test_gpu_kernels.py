@@ -169,10 +169,10 @@ def from_blocked(flat, rows, cols, rows_alloc):
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("epi", ["bias", "bias_gelu", "bias_resid"])
-@pytest.mark.parametrize("shape", [(197 * 40, 384, 1536), (300, 192, 128), (1000, 768, 768), (70000, 256, 160), (1, 2304, 768), (33, 3072, 768)])
+@pytest.mark.parametrize("shape", [(197 * 40, 384, 1536), (300, 192, 256), (1000, 768, 768), (70000, 256, 384), (1, 2304, 768), (33, 3072, 768), (70000, 768, 256), (140000, 192, 256)])
 def test_linear_blocked_gemm3(hip_lib, dev, prec, epi, shape):
     """gemm3 through effocr_op_linear_blocked: both tile widths (192 / 256), the small-tile tail launch
-    ((70000, 256): 274 token tiles -> one full round + tail), ragged last row blocks, K = 128 (4 stages = ring depth)."""
+    ((70000, 256): 274 token tiles -> one full round + tail), ragged last row blocks, several tiles per persistent workgroup ((70000, 768): 3; (140000, 192): 2), K = 256 (8 stages: the shortest tile the continuous ring runs: 3 + 1 + 4)."""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + 3 * N + K)
     x = torch.randn(M, K, generator=g).to(TDT[prec])
