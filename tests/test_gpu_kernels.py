@@ -209,10 +209,11 @@ def test_linear_blocked_argument_checks(hip_lib, dev):
     f = torch.zeros(1 << 12, dtype=torch.float32, device=dev)
     call = lambda m, n, k, ra: hip_lib.effocr_op_linear_blocked(0, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), None, _lib.ptr(z), m, n, k, ra, _stream(dev))
     assert call(32, 128, 128, 32) == -2          # N neither % 192 nor % 256
-    assert call(32, 192, 100, 32) == -2          # K % 32
-    assert call(32, 192, 128, 16) == -1          # rows_alloc < m
-    assert call(0, 192, 128, 0) == 0
-    assert hip_lib.effocr_op_linear_blocked(2, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), None, _lib.ptr(z), 32, 192, 128, 32, _stream(dev)) == -2   # fp32
+    assert call(32, 192, 320, 32) == -2          # K % 128
+    assert call(32, 192, 128, 32) == -2          # K < 256 (8 ring stages: the shortest tile the continuous ring runs)
+    assert call(32, 192, 256, 16) == -1          # rows_alloc < m
+    assert call(0, 192, 256, 0) == 0
+    assert hip_lib.effocr_op_linear_blocked(2, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), None, _lib.ptr(z), 32, 192, 256, 32, _stream(dev)) == -2   # fp32
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
