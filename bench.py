@@ -259,21 +259,28 @@ def main():
         torch.cuda.synchronize(dev)
 
     from effocr_amd import _lib as L_
-    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    clk = torch.zeros(8192, dtype=torch.int64, device=dev)    # two samples x 2048 CU keys x (shader ticks, 100 MHz ticks)
     clock_ghz = [None]
 
     def timed(step, steps):
         fence()
         t0 = time.perf_counter()
-        L_.check(L_.lib().effocr_clock_sample(L_.ptr(clk), L_.current_stream(dev)), "clock_sample")          # (inside the fences: two 1-thread kernels)
+        L_.check(L_.lib().effocr_clock_sample(L_.ptr(clk), L_.current_stream(dev)), "clock_sample")          # (inside the fences: two 1024-wave launches)
         for _ in range(steps):
             out = step()
-        L_.check(L_.lib().effocr_clock_sample(L_.ptr(clk[2:]), L_.current_stream(dev)), "clock_sample")
+        L_.check(L_.lib().effocr_clock_sample(L_.ptr(clk[4096:]), L_.current_stream(dev)), "clock_sample")
         fence()
         dt = time.perf_counter() - t0
-        c = clk.cpu().tolist()
-        if c[3] > c[1]:
-            clock_ghz[0] = round((c[2] - c[0]) / (c[3] - c[1]) * 0.1, 3)
+        c = clk.cpu().view(2, 2048, 2)                     # s_memtime is a per-CU counter: CU by CU
+        ok = (c[0, :, 1] > 0) & (c[1, :, 1] > c[0, :, 1])
+        if bool(ok.any()):
+            d = c[1, ok] - c[0, ok]
+            keep = d[:, 1] <= d[:, 1].min() * 5 // 4 + 1000   # (a CU one sample missed keeps an older pair)
+            st, rt = int(d[keep, 0].sum()), int(d[keep, 1].sum())
+        else:
+            st = rt = 0
+        if rt > 0:
+            clock_ghz[0] = round(st / rt * 0.1, 3)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -294,7 +301,7 @@ def main():
         tot = sum(v["ms"] for v in table.values())
         for n, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
-            print(f"  {n:18s} {v['ms']:8.3f} ms {100 * v['ms'] / tot:5.1f}%  x{v['launches']:3d}  {tf:8.1f} TFLOP/s", file=sys.stderr)
+            print(f"  {n:18s} {v['ms']:8.3f} ms {100 * v['ms'] / tot:5.1f}%  x{v['launches']:3d}  {tf:8.1f} TFLOP/s  {v.get('shader_ghz', 0.0):5.2f} GHz", file=sys.stderr)
         print(f"  {'sum of kernels':18s} {tot:8.3f} ms", file=sys.stderr)
 
     # ---- timed region: exactly K steps between barrier+synchronize fences; only the dominant class
@@ -367,6 +374,12 @@ def main():
             line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(fl / sec / 1e12, 2),
                                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(fl / sec / peak, 4),
                                 "flops_per_launch": fl, "avg_launch_us": round(sec * 1e6, 2), "launches": p["launches"], "traffic": None}
+            # the chip is power-limited: the shader clock this kernel class ran at in the fully profiled (untimed) step — two clock
+            # samples around every launch — and the fraction of the MFMA rate AT THAT CLOCK (the 2.5 PFLOP/s peak is quoted at 2.4 GHz)
+            ghz = table.get(dom, {}).get("shader_ghz", 0.0)
+            if ghz > 0:
+                line["roofline"]["shader_clock_GHz"] = round(ghz, 3)
+                line["roofline"]["frac_at_shader_clock"] = round(fl / sec / (peak * ghz / 2.4), 4)
             if a.arch == "vit_small_patch16_224" and a.batch == 1024 and world == 1:
                 tr, src = measured_traffic(dom)
                 line["roofline"]["traffic"] = tr
@@ -666,7 +679,8 @@ def c4_extras(a, dev):
             "encoder_ms": round(1e3 * te, 3),
             "encoder_mfma_frac": round(1024 * (FLOP_PER_CROP[arch] - (PRUNED_FLOP_PER_CROP[arch] if "cls_fc1_gelu" in table else 0.0)) / te / MFMA_PEAK[a.precision], 4),
             "encoder_mfma_frac_at_model_flops": round(1024 * FLOP_PER_CROP[arch] / te / MFMA_PEAK[a.precision], 4),
-            "kernel_TFLOPs": lin, "knn_ms": round(1e3 * tk, 3),
+            "kernel_TFLOPs": lin, "kernel_shader_clock_GHz": {n: round(v.get("shader_ghz", 0.0), 3) for n, v in table.items() if v["flops"] > 0 and v["ms"] > 0},
+            "knn_ms": round(1e3 * tk, 3),
             # the screened search is ONE bf16 scan of the index (1.536 GB, 1.573 TFLOP: the Q-stationary kernel over the blocked copy, block
             # maxima out) + threshold collect + two-stage re-rank
             "knn_hbm_frac_bf16_one_scan": round(N * D * 2.0 / tk / 8.0e12, 4), "knn_mfma_bf16_frac": round(2.0 * 1024 * N * D / tk / 2.5e15, 4),

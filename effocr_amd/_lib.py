@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip
 # Never loaded by the engines on their own; tests that compare those paths switch to it with use_library().
 SO_PATH_AB = os.path.join(_HERE, "libeffocr_hip_ab.so")
 
-ABI_VERSION = 6          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
+ABI_VERSION = 7          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
@@ -87,6 +87,7 @@ def _declare(lib):
         "effocr_encoder_profile_collect": (i32, [vp]),
         "effocr_encoder_profile_get": (i32, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(c.c_double), c.POINTER(i32),
                                              c.POINTER(c.c_double)]),
+        "effocr_encoder_profile_clock": (i32, [vp, i32, c.POINTER(c.c_double)]),
         "effocr_knn_workspace_bytes": (sz, [i64, i64, i32, i32]),
         "effocr_knn_ip_topk": (i32, [f32p, i64, f32p, i64, i32, i32, f32p, i64p, vp, sz, vp]),
         "effocr_knn_screen_workspace_bytes": (sz, [i64, i64, i32, i32]),

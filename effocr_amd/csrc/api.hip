@@ -96,6 +96,10 @@ struct effocr_encoder {
   std::vector<float> prof_ms;                     // filled by profile_collect
   std::vector<int> prof_cnt;
   std::vector<double> prof_work;                  // algorithmic flops (or bytes) per class, summed
+  // mode 1 also brackets every launch with two clock samples (s_memtime = shader clocks, s_memrealtime = 100 MHz) outside its event pair
+  unsigned long long* prof_clk = nullptr;         // device: [slot][2][2048 CU keys][2] = (memtime, realtime) per CU, before and after (16 MB, allocated by the first mode-1 run)
+  std::vector<double> prof_ghz;                   // filled by profile_collect (0 = not sampled)
+  static constexpr size_t PROF_CLK_SLOTS = 256;
 };
 
 namespace effocr {
@@ -392,9 +396,13 @@ int timed(effocr_encoder* e, const char* name, double work, hipStream_t s, F lau
   }
   const int cls = prof_class(e, name);
   const size_t slot = e->prof_used++;
+  const bool clk = e->prof_mode == 1 && slot < effocr_encoder::PROF_CLK_SLOTS &&
+                   (e->prof_clk || hipMalloc(&e->prof_clk, effocr_encoder::PROF_CLK_SLOTS * 8192 * sizeof(unsigned long long)) == hipSuccess && hipMemset(e->prof_clk, 0, effocr_encoder::PROF_CLK_SLOTS * 8192 * sizeof(unsigned long long)) == hipSuccess);
+  if (clk) (void)clock_sample(e->prof_clk + slot * 8192, s);
   (void)hipEventRecord(e->prof_pool[slot].first, s);
   const int rc = launch();
   (void)hipEventRecord(e->prof_pool[slot].second, s);
+  if (clk) (void)clock_sample(e->prof_clk + slot * 8192 + 4096, s);
   e->prof_rec.push_back({cls, (int)slot});
   e->prof_work[cls] += work;
   return rc;
@@ -732,6 +740,7 @@ int effocr_encoder_create(const char* arch, int img_size, int precision, effocr_
 void effocr_encoder_destroy(effocr_encoder_t* enc) {
   if (!enc) return;
   for (auto& ev : enc->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (enc->prof_clk) (void)hipFree(enc->prof_clk);
   delete enc;
 }
 int effocr_encoder_embed_dim(const effocr_encoder_t* enc) { return enc ? enc->D : 0; }
@@ -882,9 +891,34 @@ int effocr_encoder_profile_begin(effocr_encoder_t* enc, int mode, const char* on
 
 int effocr_encoder_profile_collect(effocr_encoder_t* enc) {
   if (!enc) return fail(EFFOCR_EINVAL, "profile_collect: NULL encoder");
+  const bool clk = enc->prof_mode == 1 && enc->prof_clk;
   enc->prof_mode = 0;
   enc->prof_ms.assign(enc->prof_names.size(), 0.f);
   enc->prof_cnt.assign(enc->prof_names.size(), 0);
+  enc->prof_ghz.assign(enc->prof_names.size(), 0.0);
+  if (clk && !enc->prof_rec.empty()) {            // shader clock of a class = sum of shader ticks / sum of 100 MHz ticks over its launches
+    if (hipEventSynchronize(enc->prof_pool[enc->prof_rec.back().second].second) != hipSuccess) return fail(EFFOCR_EHIP, "profile_collect: hipEventSynchronize failed");
+    if (hipDeviceSynchronize() != hipSuccess) return fail(EFFOCR_EHIP, "profile_collect: hipDeviceSynchronize failed");
+    const size_t n = enc->prof_used < effocr_encoder::PROF_CLK_SLOTS ? enc->prof_used : effocr_encoder::PROF_CLK_SLOTS;
+    std::vector<unsigned long long> h(n * 8192);
+    if (hipMemcpy(h.data(), enc->prof_clk, n * 8192 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return fail(EFFOCR_EHIP, "profile_collect: clock samples");
+    std::vector<double> st(enc->prof_names.size(), 0.0), rt(enc->prof_names.size(), 0.0);
+    for (const auto& r : enc->prof_rec) {
+      if ((size_t)r.second >= n) continue;
+      const unsigned long long* q = h.data() + (size_t)r.second * 8192;
+      unsigned long long dmin = ~0ull;              // a CU one of the two samples did not reach keeps an older pair: longer interval, skipped
+      for (int x = 0; x < 2048; ++x) {
+        const unsigned long long t0 = q[2 * x + 1], t1 = q[4096 + 2 * x + 1];
+        if (t0 && t1 > t0 && t1 - t0 < dmin) dmin = t1 - t0;
+      }
+      for (int x = 0; x < 2048; ++x) {
+        const unsigned long long t0 = q[2 * x + 1], t1 = q[4096 + 2 * x + 1];
+        if (!t0 || t1 <= t0 || t1 - t0 > dmin + dmin / 4 + 1000) continue;
+        st[r.first] += (double)(q[4096 + 2 * x] - q[2 * x]); rt[r.first] += (double)(t1 - t0);
+      }
+    }
+    for (size_t i = 0; i < st.size(); ++i) enc->prof_ghz[i] = rt[i] > 0 ? st[i] / rt[i] * 0.1 : 0.0;
+  }
   for (const auto& r : enc->prof_rec) {
     const auto& ev = enc->prof_pool[r.second];
     if (hipEventSynchronize(ev.second) != hipSuccess) return fail(EFFOCR_EHIP, "profile_collect: hipEventSynchronize failed");
@@ -904,6 +938,12 @@ int effocr_encoder_profile_get(const effocr_encoder_t* enc, int i, const char** 
   if (total_ms) *total_ms = enc->prof_ms[i];
   if (launches) *launches = enc->prof_cnt[i];
   if (total_work) *total_work = enc->prof_work[i];
+  return EFFOCR_OK;
+}
+
+int effocr_encoder_profile_clock(const effocr_encoder_t* enc, int i, double* shader_ghz) {
+  if (!enc || i < 0 || i >= (int)enc->prof_ghz.size() || !shader_ghz) return fail(EFFOCR_EINVAL, "profile_clock: bad argument");
+  *shader_ghz = enc->prof_ghz[i];
   return EFFOCR_OK;
 }
 

@@ -626,11 +626,17 @@ int attention(int prec, const void* qkv, void* out, int B, int T, int heads, int
 
 // (s_memtime ticks at the shader clock on gfx950, s_memrealtime at the constant 100 MHz reference: two samples give the average
 // shader clock over the interval between them — bench.py brackets its timed region with it)
+// s_memtime counts shader clocks PER CU (256 counters with unrelated offsets, tools/ubench/memtime_domain.hip): 1024 one-wave workgroups
+// cover the CUs, each stores { s_memtime, s_memrealtime (100 MHz, chip-wide) } into the pair of ITS CU — key = XCC_ID * 256 + (SE, SH, CU)
+// of HW_ID, 2048 pairs — so that two samples compare like with like.
 __global__ void clock_sample_kernel(unsigned long long* out) {
-  if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime(); out[1] = __builtin_amdgcn_s_memrealtime(); }
+  const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));          // HW_REG_HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;    // HW_REG_XCC_ID[3:0]
+  const unsigned key = xcc * 256u + ((hw >> 13) & 7u) * 32u + ((hw >> 12) & 1u) * 16u + ((hw >> 8) & 15u);
+  if (threadIdx.x == 0) { out[2 * key] = __builtin_amdgcn_s_memtime(); out[2 * key + 1] = __builtin_amdgcn_s_memrealtime(); }
 }
 int clock_sample(unsigned long long* out, hipStream_t s) {
-  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, s, out);
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(1024), dim3(64), 0, s, out);
   return check_launch("clock_sample");
 }
 

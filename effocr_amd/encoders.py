@@ -141,7 +141,8 @@ class HipEncoder:
                    "effocr_encoder_profile_begin", self._L)
 
     def profile_collect(self):
-        """-> {class: {"ms": total, "launches": n, "flops": total algorithmic FLOPs}} (synchronises)."""
+        """-> {class: {"ms": total, "launches": n, "flops": total algorithmic FLOPs, "shader_ghz": clock the class ran at (full
+        breakdowns only, else 0)}} (synchronises)."""
         n = self._L.effocr_encoder_profile_collect(self._h)
         if n < 0:
             _lib.check(n, "effocr_encoder_profile_collect")
@@ -150,7 +151,9 @@ class HipEncoder:
             name, ms, cnt, work = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
             _lib.check(self._L.effocr_encoder_profile_get(self._h, i, ctypes.byref(name), ctypes.byref(ms),
                                                           ctypes.byref(cnt), ctypes.byref(work)), "profile_get", self._L)
-            out[name.value.decode()] = {"ms": ms.value, "launches": cnt.value, "flops": work.value}
+            ghz = ctypes.c_double()
+            _lib.check(self._L.effocr_encoder_profile_clock(self._h, i, ctypes.byref(ghz)), "profile_clock", self._L)
+            out[name.value.decode()] = {"ms": ms.value, "launches": cnt.value, "flops": work.value, "shader_ghz": ghz.value}
         return out
 
 

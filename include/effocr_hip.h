@@ -29,7 +29,7 @@ extern "C" {
 /* bumped whenever an exported signature or the meaning of an argument changes (round 1: 1; round 2 added
  * arguments to effocr_op_mlp_blocked without a bump — callers must treat 1 as "unknown layout"); a caller built
  * against another value must refuse to call into the library (effocr_amd/_lib.py does) */
-#define EFFOCR_ABI_VERSION 6
+#define EFFOCR_ABI_VERSION 7
 
 enum effocr_status {
   EFFOCR_OK = 0,
@@ -93,10 +93,11 @@ int effocr_encoder_forward(effocr_encoder_t* enc, const float* x_dev, int batch,
 int effocr_encoder_forward_ex(effocr_encoder_t* enc, const void* x_dev, int x_dtype, int batch, float* emb_dev,
                               int l2_normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Measurement aid (bench.py): one tiny kernel on `stream` that stores { s_memtime (shader-clock ticks), s_memrealtime (100 MHz) } into
- * out_dev[0..1] (uint64).  Two samples bracket an interval: d(memtime) / d(memrealtime) x 100 MHz = the average shader clock under
- * that load — the chip is power-managed: tools/ubench/mfma_f16_vs_bf16.hip measures 2.37 GHz idle-data, 1.73 GHz (bf16) / 1.58 GHz (f16)
- * under saturated MFMA load with random operands. */
+/* Measurement aid (bench.py): one small launch on `stream` (1024 one-wave workgroups) that stores { s_memtime (shader-clock ticks),
+ * s_memrealtime (100 MHz) } of every CU it reaches into out_dev[2 key], out_dev[2 key + 1], key = XCC_ID * 256 + SE * 32 + SH * 16 + CU
+ * < 2048 (out_dev: 4096 uint64, zeroed by the caller; s_memtime is a per-CU counter, so two samples are compared CU by CU).
+ * d(memtime) / d(memrealtime) x 100 MHz = the average shader clock over the bracketed interval — the chip is power-managed:
+ * tools/ubench/mfma_f16_vs_bf16.hip measures 2.37 GHz idle-data, 1.73 GHz (bf16) / 1.58 GHz (f16) under saturated MFMA load. */
 int effocr_clock_sample(void* out_dev, void* stream);
 
 /* Status of EVERY forward issued with this workspace since the previous check (ViT; the CNN path is fp32 throughout and always
@@ -155,6 +156,10 @@ int effocr_encoder_profile_begin(effocr_encoder_t* enc, int mode, const char* on
 int effocr_encoder_profile_collect(effocr_encoder_t* enc);
 int effocr_encoder_profile_get(const effocr_encoder_t* enc, int i, const char** name, double* total_ms,
                                int* launches, double* total_work);
+/* mode 1 only: the shader clock (GHz) the launches of class i ran at — each launch is also bracketed, outside its event pair, by two
+ * samples of s_memtime (shader clocks) and s_memrealtime (100 MHz); 0 if not sampled.  The chip is power-limited: MFMA-dense kernels
+ * run at 1.2-1.4 GHz, not at the 2.4 GHz the 2.5 PFLOP/s peak is quoted at ("Clocks"). */
+int effocr_encoder_profile_clock(const effocr_encoder_t* enc, int i, double* shader_ghz);
 
 /* ------------------------------------------------------------------------------------------
  * k-NN engine.  Replaces faiss.IndexFlatIP as driven by pytorch_metric_learning's FaissKNN:
