@@ -34,7 +34,7 @@ constexpr int G3RING = 4;
 // -DGEMM3_TRACE (tools/ab_build.sh variant, never shipped): wave 0 of every workgroup records s_memrealtime (100 MHz) at the milestones
 // of each of its first G3T_TILES tiles; tools/gemm3_timeline.py reads the last launch's table through effocr_debug_gemm3_stamps.
 #ifdef GEMM3_TRACE
-constexpr int G3T_WGS = 256, G3T_TILES = 48, G3T_N = 8;
+constexpr int G3T_WGS = 256, G3T_TILES = 48, G3T_N = 10;     // 0-6 milestones, 7 s_memtime at the tile top, 8 / 9 shader ticks spent in the stage vmcnt waits / barriers
 __device__ unsigned long long g3_stamps[G3T_WGS * G3T_TILES * G3T_N];
 #define G3_STAMP(k) tstamp[k] = __builtin_amdgcn_s_memrealtime();
 #else
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
   };
 
   Frags fa, fb;
+#ifdef GEMM3_TRACE
+  unsigned long long tstamp[G3T_N] = {};
+  int titer = 0;
+#endif
   // One stage s of a tile; in its second half it requests ring stage s + 4 — of this tile, or (WRAP, the last four stages; sb[] has been
   // switched) stage s + 4 - nst of the next one.  WAIT: stage s + 1 is awaited by count — everything but the newest two stages' pieces
   // of the in-order VM queue has completed.  Stages 0-2 of a tile do not wait: their successors were requested before the previous
@@ -188,10 +192,20 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
     });
     // stage s+1 landed (own pieces; s+2, s+3 may stay in flight), every wave holds its stage-s fragments
     // in registers -> past the barrier slot s&3 is free for stage s+4
+#ifdef GEMM3_TRACE
+    const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (wait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef GEMM3_TRACE
+    const unsigned long long w1_ = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef GEMM3_TRACE
+    const unsigned long long w2_ = __builtin_amdgcn_s_memtime();
+    tstamp[8] += w1_ - w0_; tstamp[9] += w2_ - w1_;
+#endif
     // k16 step 1; in its shadow: DMA of stage s+4 and the fragments of stage s+1, step 0
     const unsigned voff = lane16 + ((unsigned)(wrap ? s + 4 - nst : s + 4) << 11);
     mma_step(fb, std::false_type{}, [&](auto N_) {
@@ -211,14 +225,10 @@ __global__ __launch_bounds__(256, 1) void gemm3_kernel(GemmArgs g) {
     for (int i = 0; i < PP; ++i) ring_piece(lane16 + ((unsigned)S << 11), S, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-#ifdef GEMM3_TRACE
-  unsigned long long tstamp[G3T_N] = {};
-  int titer = 0;
-#endif
   for (;;) {                                                           // ---- one tile per iteration
     G3_STAMP(0)
 #ifdef GEMM3_TRACE
-    tstamp[7] = __builtin_amdgcn_s_memtime();
+    tstamp[7] = __builtin_amdgcn_s_memtime(); tstamp[8] = 0; tstamp[9] = 0;
 #endif
     // every wave has seen its pieces of stages 0-3 land and has left the previous epilogue (bias / statistics areas are free)
     __builtin_amdgcn_s_barrier();

@@ -5,7 +5,7 @@
 set -e
 name=$1; extra=$2; shift 2
 cd "$(dirname "$0")/../effocr_amd/csrc"
-mkdir -p ../../tools/ab /tmp/ab_$name
+mkdir -p ../../tools/ab /tmp/ab_$name; rm -f /tmp/ab_$name/*.o
 objs=""
 for o in *.o; do
   src=${o%.o}.hip
@@ -13,7 +13,7 @@ for o in *.o; do
   if [[ " $* " == *" $src "* ]]; then
     flags=""; [ "$src" = qkvattn.hip ] && flags="-mllvm -amdgpu-mfma-vgpr-form"
     [[ "$src" == mlp*.hip ]] && flags="-fno-slp-vectorize"
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags $extra -c $src -o /tmp/ab_$name/$o 2>/dev/null &
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags $extra -c $src -o /tmp/ab_$name/$o 2>/tmp/ab_$name/${o%.o}.log &
     objs="$objs /tmp/ab_$name/$o"
   else
     objs="$objs $o"

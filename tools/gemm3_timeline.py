@@ -14,7 +14,7 @@ L = _lib.lib()
 lib = ctypes.CDLL(os.environ["EFFOCR_HIP_LIB"])
 M = 1024 * 197
 ra = (M + 127) // 128 * 128
-WGS, TILES, NS = 256, 48, 8
+WGS, TILES, NS = 256, 48, 10
 names = ["tile-top barrier + constants DMA issue", "stages 0-2 (no waits)", "stage 3 (first counted wait: store acks)", "stages 4 .. nst-1",
          "ring wait + first chunk (loads / GELU)", "rest of the epilogue (to the last store issued)"]
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -50,6 +50,8 @@ for name, N, K, epi in [("qkv", 2304, 768, "bias"), ("fc1", 3072, 768, "bias_gel
         print(f"   {n:52s} {sgi.mean():7.2f} us  {100 * sgi.mean() / (tot.mean() + gap.mean()):5.1f} %   (p10 {np.percentile(sgi, 10):.2f}, p90 {np.percentile(sgi, 90):.2f})")
     clk = np.diff(tt[:, :, 7], axis=1) / np.diff(tt[:, :, 0], axis=1) * 0.1   # shader clocks (s_memtime) per 100 MHz tick -> GHz
     print(f"   shader clock over a tile: mean {clk.mean():.3f} GHz (p10 {np.percentile(clk, 10):.3f}, p90 {np.percentile(clk, 90):.3f})")
+    cyc = np.diff(tt[:, :, 7], axis=1).mean()                                 # shader ticks per tile
+    print(f"   of {cyc:.0f} shader ticks per tile (wave 0): {tt[:, :, 8].mean():.0f} in the stages' vmcnt / lgkmcnt waits, {tt[:, :, 9].mean():.0f} at their barriers; MFMA issue minimum {K // 32 * 32 * 32} ticks")
     # how far apart are the workgroups?  start of tile k across workgroups
     sp = tt[:, :, 0].std(axis=0) / 100.0
     print(f"   spread (std over workgroups) of the tile-top time: first recorded tile {sp[0]:.2f} us, last {sp[-1]:.2f} us")
