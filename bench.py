@@ -506,7 +506,7 @@ def shard_proxy_extras(a, enc, knn, dev):
         if B > a.batch:
             continue
         x = torch.randn(B, 3, 224, 224, device=dev)
-        t = _time_gpu(lambda: knn(enc.forward(x, normalize=True), k=a.k), dev, max(10, 2048 // B), warm=3)
+        t = _time_gpu(lambda: knn(enc.forward(x, normalize=True), k=a.k), dev, max(30, 8192 // B), warm=5)   # (>= 0.1 s per size: ten-call samples moved by 6 % between runs on a power-managed clock)
         full = full or B / t
         out[f"ranks{n_ranks}_crops{B}"] = {"ms_per_step": round(1e3 * t, 3), "crops_per_s_per_gpu": round(B / t, 1),
                                            "fraction_of_the_1024_crop_rate": round(B / t / full, 4)}
