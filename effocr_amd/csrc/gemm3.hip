@@ -14,7 +14,9 @@
 //   * one wave per SIMD means nothing else hides a wave's own latencies, so the barrier sits in the MIDDLE
 //     of a stage: [read frags(s, k16=1)] [MFMAs k16=0] [wait stage s+1, barrier, DMA stage s+4 into the
 //     slot just vacated, read frags(s+1, k16=0)] [MFMAs k16=1] — both fragment reads fly under MFMAs;
-//   * MFMA issued swapped (A-operand = W rows): a lane owns 4 consecutive features of one token.
+//   * MFMA issued swapped (A-operand = W rows): a lane owns 4 consecutive features of one token;
+//   * tiles are PERSISTENT on a CONTINUOUS ring (round 5): one workgroup per CU walks tiles b, b + G, ...; the last four stages of a tile
+//     request the first four of the next one, the epilogue runs while they land, bias / column sums / row statistics come through LDS.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <type_traits>
