@@ -479,3 +479,29 @@ def test_vit_base_fused_patch_embedding_matches_the_unfused_pair(dev):
         pair = enc.forward(x.to(dev), normalize=True).cpu()
         assert rel_err(fused, ref) <= REL[prec] and rel_err(pair, ref) <= REL_AB[prec]
         assert rel_err(fused, pair) <= 2e-3 * (8 if prec == "bf16" else 1)
+
+
+def test_profiler_reports_times_work_and_shader_clocks(dev):
+    """effocr_encoder_profile_*: a full breakdown (mode 1) carries, per kernel class, launches, summed event time, algorithmic FLOPs and the
+    shader clock its launches ran at (two per-CU samples of s_memtime / s_memrealtime around every launch: a per-CU counter compared CU by CU
+    must give a physical clock, 0.5 - 2.6 GHz); the single-class mode (2) times only that class and samples no clocks; the profiled forward
+    returns the same embeddings as an unprofiled one."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=224), precision="bf16", device=dev)
+    x = torch.randn(160, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(2), device=dev)
+    ref = enc.forward(x, normalize=True)
+    enc.profile_begin()
+    got = enc.forward(x, normalize=True)
+    table = enc.profile_collect()
+    assert torch.equal(got, ref)
+    assert {"qkv_attn_fused", "proj_mlp_fused", "patch_embed_fused"} <= set(table)
+    assert table["qkv_attn_fused"]["launches"] == 12 and table["proj_mlp_fused"]["launches"] == 11
+    for name in ("qkv_attn_fused", "proj_mlp_fused"):
+        v = table[name]
+        assert v["ms"] > 0 and v["flops"] > 0 and 0.5 < v["shader_ghz"] < 2.6, (name, v)
+    enc.profile_begin(only="proj_mlp_fused")
+    enc.forward(x, normalize=True)
+    one = enc.profile_collect()
+    assert set(one) == {"proj_mlp_fused"} and one["proj_mlp_fused"]["launches"] == 11 and one["proj_mlp_fused"]["shader_ghz"] == 0.0
+    assert abs(one["proj_mlp_fused"]["flops"] - table["proj_mlp_fused"]["flops"]) < 1.0
