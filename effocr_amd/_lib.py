@@ -190,11 +190,16 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def require_gpu(device):
+def require_gpu(device=None):
+    """Resolve ``device`` to a concrete GPU.  ``None`` and an index-less ``"cuda"`` mean torch's CURRENT device — the semantics
+    of the reference's default ``--device cuda`` (infer_effocr.py:439,178) — so that with one process per GPU
+    (``torch.cuda.set_device(LOCAL_RANK)``) every engine of a rank lands on that rank's GPU, never on a literal GPU 0."""
     import torch
     if not torch.cuda.is_available():
         raise EffOCRHipError("no ROCm GPU visible: the EffOCR HIP path has no CPU fallback")
-    d = torch.device(device)
+    d = torch.device("cuda" if device is None else device)
     if d.type != "cuda":
         raise EffOCRHipError(f"device {device!r} is not a GPU: the EffOCR HIP path has no CPU fallback")
+    if d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
     return d

@@ -59,12 +59,44 @@ def _all_gather_list(out, pad, world, mx, group):
     dist.all_gather(chunks, pad.contiguous(), group=group)
 
 
+def pack_topk(d, i):
+    """(scores fp32 [n,k], ids int64 [n,k]) -> ONE int32 buffer [n, 3k] (score bits | id low/high words): the per-rank result
+    travels in a single collective, 12 bytes per neighbour, bit for bit."""
+    d = d.contiguous()
+    i = i.contiguous()
+    if d.dtype != torch.float32 or i.dtype != torch.int64 or d.shape != i.shape:
+        raise ValueError("pack_topk expects float32 scores and int64 ids of the same shape")
+    n, k = d.shape                                   # explicit sizes: a rank's shard may be EMPTY (fewer crops than ranks)
+    if n == 0:
+        return torch.empty((0, 3 * k), dtype=torch.int32, device=d.device)
+    return torch.cat([d.view(torch.int32).reshape(n, k), i.view(torch.int32).reshape(n, 2 * k)], dim=1)
+
+
+def unpack_topk(buf, k):
+    """Inverse of ``pack_topk``: int32 [n, 3k] -> (fp32 [n,k], int64 [n,k])."""
+    n = buf.shape[0]
+    if n == 0:
+        return (torch.empty((0, k), dtype=torch.float32, device=buf.device), torch.empty((0, k), dtype=torch.int64, device=buf.device))
+    d = torch.empty((n, k), dtype=torch.int32, device=buf.device).copy_(buf[:, :k]).view(torch.float32)   # fresh buffers: a view of a
+    # sliced row keeps the slice's offset / stride, which an int32 -> int64 reinterpretation rejects
+    i = torch.empty((n, 2 * k), dtype=torch.int32, device=buf.device).copy_(buf[:, k:]).view(torch.int64)
+    return d, i
+
+
+def all_gather_topk(d, i, n_total, group=None, always_collective=False):
+    """ONE all-gather of the packed ``(score, id)[n_r, k]`` lists -> ``([n_total,k] fp32, [n_total,k] int64)`` on every rank."""
+    k = d.shape[1]
+    if k == 0:
+        return all_gather_rows(d, n_total, group, always_collective), all_gather_rows(i, n_total, group, always_collective)
+    return unpack_topk(all_gather_rows(pack_topk(d, i), n_total, group, always_collective), k)
+
+
 class ShardedRecognizer:
     """Wraps a per-rank ``neighbors(crops) -> (distances, indices)`` callable (e.g.
     ``effocr_amd.pipeline.Recognizer.neighbors``): every rank passes the SAME full batch (or only
     its own slice with ``presharded=True``) and gets the full ``[B,k]`` results back.
 
-    ``status_fn`` (optional; derived from a bound ``Recognizer.neighbors``): called on every rank AFTER the gathers — the call's
+    ``status_fn`` (optional; derived from a bound ``Recognizer.neighbors``): called on every rank AFTER the gather — the call's
     synchronisation point — and raises if this rank's encoder produced a non-finite embedding (f16 operand overflow,
     EFFOCR_EOVERFLOW); the collectives have completed on every rank by then, so a raising rank leaves no peer waiting."""
 
@@ -95,7 +127,7 @@ class ShardedRecognizer:
             lo, hi = shard_bounds(n_total, rank, world)
             local = crops[lo:hi]
         d, i = self.neighbors_fn(local)
-        out = all_gather_rows(d, n_total, self.group), all_gather_rows(i, n_total, self.group)
+        out = all_gather_topk(d, i, n_total, self.group)          # ONE collective: scores and ids packed, 12 bytes per neighbour
         if self.status_fn is not None:
             self.status_fn()
         return out
@@ -140,9 +172,8 @@ class ShardedIndexSearch:
             return d, i
         world = dist.get_world_size(self.group)
         B = d.shape[0]
-        dg = all_gather_rows(d, B * world, self.group).reshape(world, B, k)      # equal blocks of B rows per rank
-        ig = all_gather_rows(i, B * world, self.group).reshape(world, B, k)
-        return merge_topk(dg, ig, k)
+        dg, ig = all_gather_topk(d, i, B * world, self.group)                    # equal blocks of B rows per rank, one collective
+        return merge_topk(dg.reshape(world, B, k), ig.reshape(world, B, k), k)
 
 
 def all_gather_texts(local_pairs, group=None):

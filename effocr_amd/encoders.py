@@ -34,7 +34,7 @@ class HipEncoder:
     """Device-resident encoder: C-ABI handle + weight blob + one grow-only workspace PER HIP STREAM (the Python lock
     covers only the enqueue; two threads forwarding on different streams must not share activation buffers)."""
 
-    def __init__(self, arch, state_dict, img_size=224, precision=DEFAULT_PRECISION, device="cuda:0"):
+    def __init__(self, arch, state_dict, img_size=224, precision=DEFAULT_PRECISION, device=None):
         if precision not in _lib.PREC:
             raise ValueError(f"precision must be one of {sorted(_lib.PREC)}, got {precision!r}")
         self.device = _lib.require_gpu(device)
@@ -177,9 +177,18 @@ def AutoEncoderFactory(backend, modelpath, precision=DEFAULT_PRECISION, img_size
             # no network the instance starts from a seeded random init until load_state_dict().
             self.model_name = model
             self._sd = W.init_state_dict(model, seed=seed, img_size=img_size)
-            self._device = torch.device("cuda:0" if str(device) == "cuda" else device)
+            self._device = self._resolve(device)
             self._engine = None
             self.training = False
+
+        @staticmethod
+        def _resolve(device):
+            # an index-less "cuda" is torch's CURRENT device (what nn.Module.to("cuda") means at infer_effocr.py:178), resolved when
+            # it is named: one process per GPU sets the device once, before building its engines
+            d = torch.device("cuda" if device is None else device)
+            if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+                d = torch.device("cuda", torch.cuda.current_device())
+            return d
 
         # -- checkpoint I/O (encoders.py:66-70) ------------------------------------------------
         @classmethod
@@ -199,7 +208,7 @@ def AutoEncoderFactory(backend, modelpath, precision=DEFAULT_PRECISION, img_size
 
         # -- nn.Module look-alikes used by infer_effocr.py:178-179,538-540 ---------------------
         def to(self, device):
-            device = torch.device("cuda:0" if str(device) == "cuda" else device)
+            device = self._resolve(device)
             if device != self._device:
                 self._device, self._engine = device, None
             return self

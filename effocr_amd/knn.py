@@ -35,7 +35,7 @@ class IndexFlatIP:
     SCREEN_WS_BYTES = 1 << 30   # bound on the pooled screen's block-maxima workspace per call (larger query batches are sliced)
     SCREEN_MIN_ROWS = 65536   # from this size on `search` uses the screened entry point (bit-identical results, ~4x faster at 1M rows)
 
-    def __init__(self, d, device="cuda:0", screen="auto"):
+    def __init__(self, d, device=None, screen="auto"):
         self.d = int(d)
         self.device = _lib.require_gpu(device)
         self._L = _lib.lib()
@@ -248,8 +248,7 @@ _OTHER_FOURCC = {b"IxF2": "IndexFlatL2", b"IxFl": "legacy IndexFlat", b"IxF1": "
 
 
 def read_index(path, device=None):
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
+    device = _lib.require_gpu(device)            # None / "cuda" = the current device
     with open(path, "rb") as f:
         buf = f.read()
     if buf[:4] != _FOURCC_IP:
@@ -279,8 +278,8 @@ class FaissKNN:
     def __init__(self, reset_before=True, reset_after=True, index_init_fn=None, gpus=None, device=None):
         # device None = the current HIP device (what PML / faiss-gpu do); one process per GPU sets it with
         # torch.cuda.set_device(local_rank)
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
+        if device is None and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())
         self.reset_before = reset_before
         self.reset_after = reset_after
         # the reference passes faiss.IndexFlatIP; any callable taking d works, default = ours
@@ -350,7 +349,7 @@ class InferenceModel:
         if data_device is None:                  # PML: the current device; here preferably the trunk's own device
             data_device = getattr(trunk, "_device", None) or getattr(trunk, "device", None)
             if data_device is None or isinstance(data_device, str) and data_device == "cuda":
-                data_device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
+                data_device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda"
         self.data_device = torch.device(data_device)
         self.dtype = dtype
 

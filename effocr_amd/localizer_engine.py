@@ -142,9 +142,7 @@ class HipLocalizer:
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         self.precision = precision
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cuda:0"
-        self.device = _lib.require_gpu(device)
+        self.device = _lib.require_gpu(device)       # None / "cuda" = the current device
         self._L = _lib.lib()
         key = "model.24.m.0.bias"
         if key not in state_dict:

@@ -42,7 +42,7 @@ class _Lane:
 class EffRecognizer:
 
     def __init__(self, model, num_cores=None, providers=None, arch=None, precision=DEFAULT_PRECISION, img_size=224,
-                 device="cuda:0", lanes=2):
+                 device=None, lanes=2):
         # num_cores / providers are ORT knobs (recognizer_engine.py:10-15): accepted and ignored.
         self.num_cores, self.providers = num_cores, providers
         if isinstance(model, dict):

@@ -68,10 +68,7 @@ class PairedTransform:
         self.device = torch.device(device) if device is not None else None
 
     def _dev(self):
-        d = _lib.require_gpu(self.device if self.device is not None else "cuda")
-        if d.index is None:
-            d = torch.device("cuda", torch.cuda.current_device())
-        self.device = d
+        self.device = d = _lib.require_gpu(self.device)      # None / "cuda" = the current device
         return d
 
     def upload(self, image):

@@ -43,6 +43,81 @@ def _worker(rank, world, port, n, out_dir):
         dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, n, out_dir):
+    """BASELINE configs[2]'s shape of the N > 1 path: 8 ranks, 1024 crops -> 128 per rank (and a ragged 1021), k = 10, and
+    exactly ONE collective per call (DESIGN 5 / north_star: "an RCCL all-gather of the per-rank transcriptions")."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import effocr_amd.dist as ed
+        from oracle import knn_ref
+        rng = np.random.default_rng(1)
+        X = rng.standard_normal((500, 32)).astype(np.float32)
+        X[7] = X[3]                                           # a duplicate row: the ascending-id tie rule crosses the gather intact
+        Q = rng.standard_normal((n, 32)).astype(np.float32)
+        seen = []
+
+        def neighbors(local):
+            seen.append(len(local))
+            d, i = knn_ref.flat_ip_search(local.numpy(), X, 10)
+            return torch.from_numpy(d), torch.from_numpy(i)
+
+        calls = {"n": 0}
+        real_list, real_into = dist.all_gather, dist.all_gather_into_tensor
+
+        def counted_list(*a, **k):
+            calls["n"] += 1
+            return real_list(*a, **k)
+
+        def counted_into(*a, **k):
+            calls["n"] += 1
+            return real_into(*a, **k)
+
+        dist.all_gather, dist.all_gather_into_tensor = counted_list, counted_into
+        try:
+            d, i = ed.ShardedRecognizer(neighbors)(torch.from_numpy(Q))
+        finally:
+            dist.all_gather, dist.all_gather_into_tensor = real_list, real_into
+        lo, hi = ed.shard_bounds(n, rank, world)
+        assert seen == [hi - lo] and calls["n"] == 1, (seen, calls)
+        assert d.dtype == torch.float32 and i.dtype == torch.int64 and tuple(i.shape) == (n, 10)
+        if rank in (0, world - 1):
+            np.save(os.path.join(out_dir, f"i{rank}.npy"), i.numpy())
+            np.save(os.path.join(out_dir, f"d{rank}.npy"), d.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1024, 1021, 5])
+def test_sharded_recognizer_world_size_8_one_collective(tmp_path, n):
+    from effocr_amd.dist import shard_sizes
+    from oracle import knn_ref
+    world, port = 8, _free_port()
+    if n == 1024:
+        assert shard_sizes(n, world) == [128] * 8
+    mp.spawn(_worker8, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((500, 32)).astype(np.float32)
+    X[7] = X[3]
+    Q = rng.standard_normal((n, 32)).astype(np.float32)
+    d_ref, i_ref = knn_ref.flat_ip_search(Q, X, 10)
+    for r in (0, world - 1):
+        assert np.array_equal(np.load(tmp_path / f"i{r}.npy"), i_ref)
+        assert np.array_equal(np.load(tmp_path / f"d{r}.npy").view(np.uint32), d_ref.view(np.uint32))
+
+
+def test_pack_topk_round_trip_is_bit_exact():
+    from effocr_amd.dist import pack_topk, unpack_topk
+    d = torch.tensor([[1.5, float("-inf"), torch.finfo(torch.float32).min], [float("nan"), -0.0, 1e-45]])
+    i = torch.tensor([[5, -1, (1 << 40) + 3], [0, -(1 << 35), 7]], dtype=torch.int64)
+    buf = pack_topk(d, i)
+    assert buf.dtype == torch.int32 and tuple(buf.shape) == (2, 9)
+    d2, i2 = unpack_topk(buf, 3)
+    assert torch.equal(d.view(torch.int32), d2.view(torch.int32)) and torch.equal(i, i2)
+    with pytest.raises(ValueError):
+        pack_topk(d.double(), i)
+
+
 @pytest.mark.parametrize("n", [64, 33, 1])
 def test_sharded_recognizer_world_size_2(tmp_path, n):
     from oracle import knn_ref
