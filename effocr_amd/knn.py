@@ -248,8 +248,7 @@ _OTHER_FOURCC = {b"IxF2": "IndexFlatL2", b"IxFl": "legacy IndexFlat", b"IxF1": "
 
 
 def read_index(path, device=None):
-    device = _lib.require_gpu(device)            # None / "cuda" = the current device
-    with open(path, "rb") as f:
+    with open(path, "rb") as f:                  # (device None / "cuda" = the current device: resolved by IndexFlatIP)
         buf = f.read()
     if buf[:4] != _FOURCC_IP:
         kind = _OTHER_FOURCC.get(bytes(buf[:4]))
