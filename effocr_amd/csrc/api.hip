@@ -421,6 +421,16 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
   w.att = a.take(M * D * es);
   size_t hb = M * e->vit.mlp * es, pb = (size_t)B * e->P * 768 * es;
   w.hbytes = hb > pb ? hb : pb;
+  {
+    // the fused MLP cuts the panels of a partially filled round of CUs 4- or 2-way over the hidden dimension and needs
+    // split x tail x 128 x D fp32 partial rows in this buffer (launch_mlp).  For calls of <= 32 crops the hidden-sized buffer is
+    // SMALLER than the 4-way partials (M x 1536 x 2 bytes against 4 x M x 384 x 4): the launcher then silently ran whole panels on a
+    // tenth of the chip (16 crops: 73 us per block on 25 CUs; round 6).  Size for the split the launcher will choose.
+    const size_t cus = (size_t)device_cus(), np = M / 128, tail = np % cus;
+    const size_t split = (tail && tail * 4 <= cus) ? 4 : (tail && tail * 2 <= cus) ? 2 : 0;
+    const size_t need = split * tail * 128 * D * 4;
+    if (need > w.hbytes) w.hbytes = need;
+  }
   w.h = a.take(w.hbytes);                   // patches (im2col rows) alias the MLP hidden buffer
   w.stats = a.take(M * 64);                 // per-row (sum, sum of squares) slice partials of the folded LayerNorm (gemm3 path)
   w.total = a.off;

@@ -43,6 +43,16 @@
 #ifndef MLP_ROWS_LATE
 #define MLP_ROWS_LATE 1                                  // rows of output group g+1 requested at the start of group g of the projection
 #endif
+#ifndef MLP_M0_ONCE
+#define MLP_M0_ONCE 1                                    // LDS-DMA base (M0) written once per ring stage instead of saved / set / restored per piece
+#endif
+#ifndef MLP_GELU_BURST
+#define MLP_GELU_BURST 2                                 // hand-over of a chunk: 0 = ~900 single instructions hosted in the MFMA gaps (rounds 3-5),
+                                                         // 1 = park hosted + GELU as 8 packed-fp32 bursts under A(c+1), 2 = bias + GELU + round in 8 fused bursts under B(c-1)
+#endif
+#ifndef MLP_DIAG
+#define MLP_DIAG 0                                       // timing ablations, WRONG results, never shipped (tools/ab_build.sh): 1 no hand-over ops,
+#endif                                                   // 2 no W-fragment reads in the steady state, 4 no steady-state DMA, 8 no mid-stage barrier
 #ifndef MLP_NT
 #define MLP_NT 15                                        // non-temporal: 1 row loads, 2 attention-fragment loads, 4 row stores, 8 second-output stores
 #endif
@@ -303,6 +313,19 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     constexpr int i = decltype(I_)::value;
     const char* src = stage_src(s) + lane16;
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sW_lds + (unsigned)((s & (R - 1)) * MLP_STAGE) + (unsigned)w * 4096u));
+#if MLP_M0_ONCE
+    // The four pieces of a stage share ONE LDS base: M0 is written with piece 0 and stays for pieces 1-3 (issued in later MFMA gaps of
+    // the same stage).  Nothing else in the main loop touches M0 (gfx9 LDS instructions do not use it; checked in the emitted code),
+    // and the compiler is told it is clobbered.  Before: save / set / wait state / restore around EVERY piece = 4 scalar instructions
+    // per piece, 384 of the loop body's 3 649 instructions per 384 MFMAs — in a loop that pays ~4.5 cycles per issued instruction.
+    if constexpr (i == 0)
+      asm volatile("s_mov_b32 m0, %1\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, off"
+                   :: "v"(src), "s"(dst) : "memory", "m0");
+    else
+      asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(src), "n"(i * 1024) : "memory", "m0");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %2\n\t"
@@ -310,6 +333,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
                  "global_load_lds_dwordx4 %1, off offset:%3\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst), "n"(i * 1024) : "memory");
+#endif
   };
 #pragma unroll
   for (int s0 = 0; s0 < R - 1; ++s0)
@@ -439,7 +463,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #if MLP_BARRIER_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (A/B) not needed: the slot refilled behind this barrier is stage s-1's, whose fragment
 #endif                                                  // reads were all consumed by MFMAs before stage s began; the reads in flight here are stage s's
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(MLP_DIAG & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #ifdef MLP_STAMP
     const unsigned long long t2_ = __builtin_amdgcn_s_memtime();
@@ -491,10 +515,104 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // ops [K0, K1) of a chunk hosted by a phase of NG MFMAs: the share of gap n
   auto host = [&](HSet* hs, const int cb, auto K0_, auto K1_, auto NG_, auto N_) __attribute__((always_inline)) {
     constexpr int K0 = decltype(K0_)::value, K1 = decltype(K1_)::value, NG = decltype(NG_)::value, n = decltype(N_)::value;
-    if constexpr (K1 > K0) {
+    if constexpr (K1 > K0 && !(MLP_DIAG & 1)) {
       constexpr int lo = CO::first_op(K0, K1, NG, n), hi = CO::first_op(K0, K1, NG, n + 1);
       sfor<lo, hi>([&](auto K_) { gop(*hs, cb, K_); });
     }
+  };
+
+  // ---- GELU as packed bursts (round 6).  What the measurements say (tools/ubench/pk_burst.hip, mfma_fill.hip; MLP_DIAG ablations,
+  // docs/EXPERIMENTS.md 6-2..6-4): behind an MFMA that also carries its W-fragment read + counted wait only ~2 further VALU instructions
+  // are free, every other one costs its full ~4.5 issue cycles — the ~700 scalar GELU instructions of a chunk hosted in the gaps cost
+  // as much as if no MFMA ran beside them (the hand-over list was 32 % of the kernel's time), while v_pk_*_f32 (two values per
+  // instruction, 5.0 cycles, bit-identical arithmetic) cannot be hosted at all (+17 cycles whenever one follows an MFMA).  So: the park
+  // ops (accumulator read + bias + round: scalar, ~1.8 per gap) stay hosted behind B(c-1); the GELU proper runs as EIGHT contiguous
+  // bursts per chunk — 8 values = 4 independent packed chains each, matrix pipe idle meanwhile — placed between the MFMAs of A(c+1).
+  // Same operations on the same values in the same order as the scalar list (gop): results are bit-identical.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto gelu_burst = [&](HSet& hs, auto O_) __attribute__((always_inline)) {
+    constexpr int o = decltype(O_)::value, DEG = GF::DEG;
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 bx[4], bu[4], bt[4], bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t wd = hs.u[o][j];
+      bx[j] = f32x2{unpack1<E>(wd, 0), unpack1<E>(wd, 1)};
+      bu[j] = f32x2{__builtin_amdgcn_fmed3f(bx[j][0], -GF::L, GF::L), __builtin_amdgcn_fmed3f(bx[j][1], -GF::L, GF::L)};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bt[j] = bu[j] * bu[j];
+    {
+      const float ch = GF::c(DEG), cl = GF::c(DEG - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bp[j] = __builtin_elementwise_fma(f32x2{ch, ch}, bt[j], f32x2{cl, cl});
+    }
+#pragma unroll
+    for (int k = DEG - 2; k >= 0; --k) {
+      const float ck = GF::c(k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bp[j] = __builtin_elementwise_fma(bp[j], bt[j], f32x2{ck, ck});
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bp[j] = __builtin_elementwise_fma(bu[j], bp[j], f32x2{0.5f, 0.5f});
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 r = bx[j] * bp[j];
+      hs.u[o][j] = pack2<E>(r[0], r[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // Mode 2 — ONE burst per octet does the whole hand-over: accumulators + bias (fp32) -> GELU -> round to the operand type.  No parked
+  // pre-activation (the GELU input is the fp32 sum: one rounding point fewer than rounds 3-5, i.e. what the unfused reference
+  // does), no pack / unpack round trip, nothing hosted in the gaps: per octet 8 v_accvgpr_read + 4 v_pk_add + 8 v_med3 + 36 packed
+  // + 4 v_cvt_pk = 60 instructions against 57 + 22 hosted.  All eight sit between the MFMAs of B(c-1) — A(c+1) overwrites acc1.
+  // The bias of the NEXT octet is read at the end of a burst (gb[]: its LDS latency hides behind the MFMAs that follow).
+  auto bias_octet = [&](const int cb, auto O_) __attribute__((always_inline)) {
+    constexpr int o = decltype(O_)::value;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      constexpr int dummy = 0; (void)dummy;
+      const int q = 2 * o + h;
+      gb[h] = *reinterpret_cast<const f32x4*>(sB1 + cb + (q >> 2) * 32 + 8 * (q & 3) + 4 * half);
+    }
+  };
+  auto fused_burst = [&](HSet& hs, const int cb, auto O_) __attribute__((always_inline)) {
+    constexpr int o = decltype(O_)::value, DEG = GF::DEG;
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 bx[4], bu[4], bt[4], bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                          // pair j of the octet = values 2(j&1), 2(j&1)+1 of quad 2o + (j>>1)
+      constexpr int dummy = 0; (void)dummy;
+      const int q = 2 * o + (j >> 1), i = q >> 2, r0 = 4 * (q & 3) + 2 * (j & 1);
+      const f32x2 av = {acc1[i][r0], acc1[i][r0 + 1]};
+      const f32x2 bv = {gb[j >> 1][2 * (j & 1)], gb[j >> 1][2 * (j & 1) + 1]};
+      bx[j] = av + bv;
+      bu[j] = f32x2{__builtin_amdgcn_fmed3f(bx[j][0], -GF::L, GF::L), __builtin_amdgcn_fmed3f(bx[j][1], -GF::L, GF::L)};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bt[j] = bu[j] * bu[j];
+    {
+      const float ch = GF::c(DEG), cl = GF::c(DEG - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bp[j] = __builtin_elementwise_fma(f32x2{ch, ch}, bt[j], f32x2{cl, cl});
+    }
+#pragma unroll
+    for (int k = DEG - 2; k >= 0; --k) {
+      const float ck = GF::c(k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bp[j] = __builtin_elementwise_fma(bp[j], bt[j], f32x2{ck, ck});
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bp[j] = __builtin_elementwise_fma(bu[j], bp[j], f32x2{0.5f, 0.5f});
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 r = bx[j] * bp[j];
+      hs.u[o][j] = pack2<E>(r[0], r[1]);
+    }
+    if constexpr (o < 7) bias_octet(cb, std::integral_constant<int, o + 1>{});
+    else bias_octet(cb + 128, std::integral_constant<int, 0>{});        // next chunk's first octet (past the last chunk: a harmless read inside sB1 / sB2)
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // REM = ring stages that follow this one in the panel's stream (compile time, clamped): the stage DMAs stage
@@ -522,9 +640,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         constexpr int i = decltype(I)::value;
         mfma1(C4, I, wf.w[i]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
+        if constexpr (MLP_DIAG & 2) asm volatile("" : "+v"(wf.w[i]));
+        else if constexpr (c4 < 3) wf.w[i] = *reinterpret_cast<const V8*>(st + wo + (i * 8 + 2 * (c4 + 1)) * 512);
         else if constexpr (next) wf.w[i] = *reinterpret_cast<const V8*>(stn + wo + (i * 8) * 512);
-        if constexpr (more && c4 >= 2 && (i & 1) == 0) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});   // behind the barrier: slot of stage s-1 is free
+        if constexpr (more && c4 >= 2 && (i & 1) == 0 && !(MLP_DIAG & 4)) issue_piece_asm(s + R - 1, std::integral_constant<int, (c4 - 2) * 2 + (i >> 1)>{});   // behind the barrier: slot of stage s-1 is free
       });
     });
     ++s;
@@ -543,6 +662,11 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
           const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc1[i] = Op16<E>::mfma(wfrag, xf[0], z);        // the chunk's accumulators start from the instruction's zero operand
         } else acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
+        if constexpr (MLP_GELU_BURST == 2) {
+        } else if constexpr (MLP_GELU_BURST == 1 && !(MLP_DIAG & 1)) {       // K1 > K0: this phase A carries the GELU of the chunk parked in `hd`
+          constexpr int n = ks * 16 + c4 * 4 + i, per = SA * 16 / 8;
+          if constexpr (decltype(K1_)::value > decltype(K0_)::value && n % per == per / 2) gelu_burst(*hd, std::integral_constant<int, n / per>{});
+        } else
         host(hd, cb, K0_, K1_, std::integral_constant<int, SA * 16>{}, std::integral_constant<int, ks * 16 + c4 * 4 + i>{});
       }, std::false_type{});
     });
@@ -556,6 +680,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
         const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
         acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
+        if constexpr (MLP_GELU_BURST == 2) {
+          constexpr int n = sb * 16 + c4 * 4 + i, per = SB * 16 / 8;
+          if constexpr (decltype(K1_)::value > decltype(K0_)::value && n % per == per / 2 && !(MLP_DIAG & 1)) fused_burst(*hd, cb, std::integral_constant<int, n / per>{});
+        } else
         host(hd, cb, K0_, K1_, std::integral_constant<int, SB * 16>{}, std::integral_constant<int, sb * 16 + c4 * 4 + i>{});
       }, std::false_type{});
     });
@@ -618,12 +746,18 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // fill the other — its park ops and the first part of its GELU behind B(c-1)'s MFMAs, the rest behind A(c+1)'s:
   //   A(0) | park(0) | A(1)+gelu(0) | { B(c-1)+ops(c)[0,KB) | A(c+1)+ops(c)[KB,N) } c=1..NC-2 | B(NC-2)+ops(NC-1)[0,KB) | ops(NC-1)[KB,N) | B(NC-1)
   // (only the first chunk's park and the last chunk's second part run without MFMAs beside them)
-  constexpr int KB = CO::split(SB * 16, SA * 16);
+  constexpr int KB = MLP_GELU_BURST ? CO::NPARK : CO::split(SB * 16, SA * 16);   // (bursts: B(c-1) hosts exactly the park ops)
   typedef std::integral_constant<int, 0> K0_; typedef std::integral_constant<int, CO::NPARK> KP_;
   typedef std::integral_constant<int, KB> KB_; typedef std::integral_constant<int, CO::N> KN_;
   HSet S2[2];
   const int cb0 = c0 * 128;
   phase_a_h(Far{}, nullptr, 0, K0_{}, K0_{});                               // A(0)
+  if constexpr (MLP_GELU_BURST == 2) {
+    if constexpr (!(MLP_DIAG & 1)) {
+      bias_octet(cb0, std::integral_constant<int, 0>{});
+      sfor<0, 8>([&](auto O_) { fused_burst(S2[0], cb0, O_); });            // hand-over(0): the only one without MFMAs around it
+    }
+  } else if constexpr (!(MLP_DIAG & 1))
   sfor<0, CO::NPARK>([&](auto K_) { gop(S2[0], cb0, K_); });              // park(0)
   MLP_STAMP_AT(6)
   phase_a_h(Far{}, &S2[0], cb0, KP_{}, KN_{});                            // A(1) + gelu(0)
@@ -645,6 +779,9 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   MLP_STAMP_AT(7)
   pair_step(std::integral_constant<int, (NC - 2) & 1>{}, std::integral_constant<int, 2 * SB>{}, NC - 2);      // B(NC-3) | A(NC-1)
   phase_b_h(std::integral_constant<int, SB>{}, S2[(NC - 2) & 1], &S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K0_{}, KB_{});   // B(NC-2)
+  if constexpr (MLP_GELU_BURST == 2) {
+  } else if constexpr (MLP_GELU_BURST == 1 && !(MLP_DIAG & 1)) sfor<0, 8>([&](auto O_) { gelu_burst(S2[(NC - 1) & 1], O_); });
+  else if constexpr (!(MLP_DIAG & 1))
   sfor<KB, CO::N>([&](auto K_) { gop(S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K_); });
   phase_b_h(std::integral_constant<int, 0>{}, S2[(NC - 1) & 1], nullptr, 0, K0_{}, K0_{});                     // B(NC-1)
   MLP_STAMP_AT(8)

@@ -30,8 +30,9 @@ def report(db):
     groups.append(cur)
     # the script prints markers in order: ... 64-crop calls, then 128-crop calls; the last group of each half
     n64 = int(os.environ.get("SC_CALLS", "6"))
-    calls = groups[-2 * n64:]
-    for label, g in (("64 crops", calls[n64 - 1]), ("128 crops", calls[-1])):
+    sizes = [int(v) for v in os.environ.get("SC_SIZES", "64,128").split(",")]
+    calls = groups[-len(sizes) * n64:]
+    for label, g in [(f"{B} crops", calls[(j + 1) * n64 - 1]) for j, B in enumerate(sizes)]:
         t0 = g[0][1]
         span, busy = (g[-1][2] - t0) / 1e3, sum(e - s for _, s, e in g) / 1e3
         print(f"== one call of {label}: {len(g)} launches, span {span:.1f} us, kernels busy {busy:.1f} us, idle {span - busy:.1f} us")
@@ -66,7 +67,7 @@ for o in sys.argv[1:]:
 idx = IndexFlatIP(384, device=dev)
 idx.add(torch.nn.functional.normalize(torch.randn(10000, 384, generator=torch.Generator().manual_seed(0)), dim=1))
 n_calls = int(os.environ.get("SC_CALLS", "6"))
-for B in (64, 128):
+for B in [int(v) for v in os.environ.get("SC_SIZES", "64,128").split(",")]:
     x = torch.randn(B, 3, 224, 224, device=dev)
     for i in range(n_calls):
         torch.cuda.synchronize(); time.sleep(0.06)

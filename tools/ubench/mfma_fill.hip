@@ -20,6 +20,28 @@ template <int KIND, int K> __device__ __forceinline__ void fill(float (&f)[16], 
     else if constexpr (KIND == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(f[(idx * K + j) & 15]));
     else if constexpr (KIND == 6) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
     else if constexpr (KIND == 7) { if (j & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(f[(idx * K + j) & 15])); else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c)); }
+    else if constexpr (KIND == 8) asm volatile("v_pk_fma_f16 %0, %0, %1, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
+    else if constexpr (KIND == 9) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
+    else if constexpr (KIND == 10) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
+    else if constexpr (KIND == 11) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(f[(idx * K + j) & 15]));
+    else if constexpr (KIND == 12) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[(idx * K + j) & 15]));
+    else if constexpr (KIND == 13) asm volatile("s_mov_b32 s40, s41" ::: "s40");
+    else if constexpr (KIND == 14) asm volatile("s_waitcnt lgkmcnt(0)");
+    else if constexpr (KIND == 15) {          // the fused MLP's real gap: ds_read_b128 + satisfied counted wait + 2 scalar + (K-4) v_fma
+      if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[idx & 3]) : "v"((unsigned)(size_t)lds + (threadIdx.x & 63) * 16 + (idx & 3) * 1024));
+      else if (j == 1) asm volatile("s_waitcnt lgkmcnt(1)");
+      else if (j == 2 || j == 3) asm volatile("s_mov_b32 s40, s41" ::: "s40");
+      else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(idx * K + j) & 15]) : "v"(c));
+    } else if constexpr (KIND == 16) {        // sigmoid-form GELU value: mul, fma, mul, exp, add, rcp, mul  (7 per value; K values per gap)
+      float& x = f[(idx * K + j) & 15];
+      asm volatile("v_mul_f32 %0, %1, %1\n\tv_fma_f32 %0, %0, %2, %2\n\tv_mul_f32 %0, %0, %1\n\tv_exp_f32 %0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_rcp_f32 %0, %0\n\tv_mul_f32 %1, %1, %0"
+                   : "=&v"(p[j & 7][0]), "+v"(x) : "v"(c));
+    } else if constexpr (KIND == 17) {        // the same seven as two interleaved values (independent chains adjacent)
+      float& x = f[(idx * K + j) & 7]; float& y = f[8 + ((idx * K + j) & 7)];
+      asm volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %3, %3\n\tv_fma_f32 %0, %0, %4, %4\n\tv_fma_f32 %1, %1, %4, %4\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3\n\t"
+                   "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_mul_f32 %2, %2, %0\n\tv_mul_f32 %3, %3, %1"
+                   : "=&v"(p[j & 7][0]), "=&v"(p[j & 7][1]), "+v"(x), "+v"(y) : "v"(c));
+    }
     else asm volatile("s_nop 0");
   }
 }
@@ -88,5 +110,16 @@ int main() {
   run<6, 4>("v_cvt_pk_bf16_f32", out, ticks); run<6, 6>("v_cvt_pk_bf16_f32", out, ticks);
   run<7, 4>("fma/exp alternating", out, ticks); run<7, 6>("fma/exp alternating", out, ticks); run<7, 8>("fma/exp alternating", out, ticks);
   run<4, 4>("s_nop 0", out, ticks); run<4, 8>("s_nop 0", out, ticks);
+  // round 6: packed 16-bit VALU, conversions, reciprocal, scalar issue, the fused MLP's real gap mix, sigmoid-form GELU
+  run<8, 2>("v_pk_fma_f16", out, ticks); run<8, 4>("v_pk_fma_f16", out, ticks); run<8, 6>("v_pk_fma_f16", out, ticks); run<8, 8>("v_pk_fma_f16", out, ticks);
+  run<9, 4>("v_pk_mul_f16", out, ticks); run<9, 6>("v_pk_mul_f16", out, ticks); run<9, 8>("v_pk_mul_f16", out, ticks);
+  run<10, 4>("v_pk_max_f16", out, ticks); run<10, 6>("v_pk_max_f16", out, ticks);
+  run<11, 4>("v_cvt_f32_f16", out, ticks); run<11, 6>("v_cvt_f32_f16", out, ticks);
+  run<12, 1>("v_rcp_f32", out, ticks); run<12, 2>("v_rcp_f32", out, ticks); run<12, 4>("v_rcp_f32", out, ticks);
+  run<13, 2>("s_mov_b32", out, ticks); run<13, 4>("s_mov_b32", out, ticks); run<13, 8>("s_mov_b32", out, ticks);
+  run<14, 1>("s_waitcnt lgkmcnt(0)", out, ticks); run<14, 2>("s_waitcnt lgkmcnt(0)", out, ticks);
+  run<15, 4>("ds_read+wait+2 salu (+K-4 fma)", out, ticks); run<15, 6>("ds_read+wait+2 salu (+K-4 fma)", out, ticks); run<15, 8>("ds_read+wait+2 salu (+K-4 fma)", out, ticks); run<15, 9>("ds_read+wait+2 salu (+K-4 fma)", out, ticks); run<15, 10>("ds_read+wait+2 salu (+K-4 fma)", out, ticks);
+  run<16, 1>("sigmoid gelu value (7 ops)", out, ticks);
+  run<17, 1>("2 sigmoid gelu values (14 ops)", out, ticks);
   return 0;
 }
