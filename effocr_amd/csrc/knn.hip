@@ -1545,7 +1545,8 @@ ScreenWs screen_ws(int64_t B, int64_t N, int D, int k) {
   w.flag = take(256);
   w.cand = take((size_t)B * RR_CAP * 4);
   w.pool_m = w.pool_c = w.pool_ev = w.pool_eb = 0;
-  if (k <= 16 && N >= 1024) {                                      // block / chunk maxima + collected entries of the Q-stationary pass
+  if (k <= 16 && N >= 1024 && (D == 128 || D == 384 || D == 768)) {   // block / chunk maxima + collected entries of the Q-stationary pass (only the widths it exists
+                                                                      // for: a 1M x 512 index with 8 192 queries must not pay 2 GB for arrays no kernel writes; advisor, round 5)
     const QsPlan qp = qs_plan(B, N, D);
     w.pool_m = take((size_t)((N + 63) / 64) * (qs_fine(B, N) ? 16 : 4) * (size_t)B * 4);
     w.pool_c = take((size_t)qp.nchunks * QS_NSUB * (size_t)B * 4);
@@ -1628,7 +1629,12 @@ int knn_ip_topk_screened(const float* q, int64_t B, const float* xb, const void*
   // The Q-stationary pass over the fragment-blocked bf16 copy (knn_qs_kernel): every call size it covers except the 17..128-query calls
   // against a large index, which the streaming screen serves at the HBM rate.
   const bool qs = xblk != nullptr && qs_applies(B, N, D, k) && !stream16;
-  if (!qs && xb16 == nullptr) return fail(EFFOCR_EINVAL, "knn(screened): this call needs the row-major bf16 copy of the index");
+  // Neither screening pass can run (the caller handed over only the blocked copy and a process-global A/B option switched the Q-stationary
+  // pass off): the exact search gives the same ids and score bits — never an error for a switch the caller cannot see (advisor, round 5).
+  if (!qs && xb16 == nullptr) {
+    if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) return fail(EFFOCR_EHIP, "knn(screened): clearing the overflow flag failed");
+    return knn_ip_topk(q, B, xb, N, D, k, dist, idx, ws, ws_bytes, s);   // (its partial lists live in w.part, the front of the same workspace)
+  }
   const QsPlan qsp = qs ? qs_plan(B, N, D) : QsPlan{};
   if (!qs) {                                               // (the Q-stationary chain rounds the queries itself and its bound kernel does the rest)
     hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, q, (int)B, D, qb, qnorm, cnt, flag);

@@ -69,11 +69,11 @@ class HipEncoder:
     def set_chunk(self, crops_per_chunk):
         """Internal sub-batch size of the ViT forward (0 = whole batch); see effocr_encoder_set_chunk."""
         _lib.check(self._L.effocr_encoder_set_chunk(self._h, int(crops_per_chunk)), "effocr_encoder_set_chunk", self._L)
-        self._ws = {}
+        # (the per-stream workspaces stay: they are grow-only scratch, re-sized by the next forward if it needs more, and their first
+        # word is the sticky status — dropping them would drop an unchecked overflow)
 
     def set_option(self, name, value):
         _lib.check(self._L.effocr_encoder_set_option(self._h, name.encode(), int(value)), "effocr_encoder_set_option", self._L)
-        self._ws = {}
 
     def workspace_bytes(self, batch):
         return int(self._L.effocr_encoder_workspace_bytes(self._h, int(batch)))
@@ -108,10 +108,13 @@ class HipEncoder:
             key = torch.cuda.current_stream(self.device).cuda_stream
             ws = self._ws.get(key)
             if ws is None or ws.numel() < need:
-                self._ws.pop(key, None)
+                old = self._ws.pop(key, None)
                 ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                ws[:256].zero_()                                # the sticky status word starts clean (effocr_encoder_check_status)
-                self._ws[key] = ws
+                if old is None:
+                    ws[:256].zero_()                            # the sticky status word starts clean (effocr_encoder_check_status)
+                else:
+                    ws[:256].copy_(old[:256])                   # ... and SURVIVES a larger workspace: an overflow recorded by an earlier, not yet
+                self._ws[key] = ws                              # checked forward on this stream must still be reported by the next check
             x_dtype = _lib.PREC["fp32"] if x.dtype == torch.float32 else _lib.PREC[self.precision]
             _lib.check(self._L.effocr_encoder_forward_ex(self._h, _lib.ptr(x), x_dtype, B, _lib.ptr(emb), 1 if normalize else 0,
                                                          _lib.ptr(ws), ws.numel(),

@@ -17,6 +17,7 @@ compacts.  Defined here because faiss leaves them open: the dot product is the a
 chain and equal scores rank by ascending id.
 """
 import struct
+import threading
 
 import numpy as np
 import torch
@@ -47,6 +48,8 @@ class IndexFlatIP:
         self._xb16 = None                        # bf16 copy of the rows + max row norm, built lazily for the screening pass
         self._xblk = None                        # fragment-blocked bf16 copy (effocr_convert_bf16_blocked): the Q-stationary screening pass
         self._xnorm_max = None
+        self._copy_lock = threading.Lock()       # the lazy copies are built once, by whichever caller thread gets here first ...
+        self._copy_ev = {}                       # ... and every OTHER stream waits for the builder's event before reading them
 
     @property
     def ntotal(self):
@@ -72,6 +75,7 @@ class IndexFlatIP:
 
     def _drop_copies(self):
         self._xb16 = self._xblk = self._xnorm_max = None
+        self._copy_ev = {}
 
     SCREEN_MAX_OVERFLOWS = 3   # after this many overflowing calls screening is switched off for this index
 
@@ -87,12 +91,14 @@ class IndexFlatIP:
         """Non-blocking look at the previous screened call's device flag: an index full of near-duplicate rows (one
         glyph in many fonts) can exceed the 512-candidate cap, in which case that call ALSO ran the exact pass; after
         SCREEN_MAX_OVERFLOWS such calls the index stops screening (results are identical either way)."""
-        if self._flag_pending is None:
+        pending = self._flag_pending             # (one read: another caller thread may clear the attribute between a test and an unpack)
+        if pending is None:
             return
-        host, ev = self._flag_pending
+        host, ev = pending
         if not ev.query():
             return
-        self._flag_pending = None
+        if self._flag_pending is pending:
+            self._flag_pending = None
         if int(host.item()) != 0:
             self.screen_overflows += 1
             if self.screen == "auto" and self.screen_overflows >= self.SCREEN_MAX_OVERFLOWS:
@@ -135,18 +141,34 @@ class IndexFlatIP:
     def _screen_copy(self, rowmajor=True, blocked=False):
         """The bf16 copies of the rows a screening pass reads, built lazily per index change: row-major (the 128-query tile kernel,
         the streaming screen) and / or fragment-blocked (the Q-stationary kernel) — plus an upper bound of every row norm."""
-        with torch.cuda.device(self.device):
+        # One index is shared by N caller threads on their own HIP streams (the reference's driver: infer_effocr_onnx_multi.py:207-223).
+        # The copies are built under a lock on the first caller's stream; an event recorded behind each build makes every other
+        # stream wait for it — without it a second stream could screen against a half-written copy and return wrong ids.
+        with self._copy_lock, torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
             if rowmajor and self._xb16 is None:
-                self._xb16 = torch.empty((self.ntotal, self.d), dtype=torch.bfloat16, device=self.device)
-                _lib.check(self._L.effocr_convert_bf16(_lib.ptr(self._xb), self.ntotal * self.d, _lib.ptr(self._xb16),
+                xb16 = torch.empty((self.ntotal, self.d), dtype=torch.bfloat16, device=self.device)
+                _lib.check(self._L.effocr_convert_bf16(_lib.ptr(self._xb), self.ntotal * self.d, _lib.ptr(xb16),
                                                        _lib.current_stream(self.device)), "effocr_convert_bf16", self._L)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._copy_ev["rowmajor"] = (ev, cur.cuda_stream)
+                self._xb16 = xb16
             if blocked and self._xblk is None:
-                self._xblk = torch.empty(int(self._L.effocr_bf16_blocked_bytes(self.ntotal, self.d)), dtype=torch.uint8, device=self.device)
-                _lib.check(self._L.effocr_convert_bf16_blocked(_lib.ptr(self._xb), self.ntotal, self.d, _lib.ptr(self._xblk),
+                xblk = torch.empty(int(self._L.effocr_bf16_blocked_bytes(self.ntotal, self.d)), dtype=torch.uint8, device=self.device)
+                _lib.check(self._L.effocr_convert_bf16_blocked(_lib.ptr(self._xb), self.ntotal, self.d, _lib.ptr(xblk),
                                                                _lib.current_stream(self.device)), "effocr_convert_bf16_blocked", self._L)
-        if self._xnorm_max is None:
-            # an upper bound of every row norm (fp32 rounding slack included); one host read per index change
-            self._xnorm_max = float(torch.linalg.vector_norm(self._xb, dim=1).max().item()) * (1.0 + 1e-5)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._copy_ev["blocked"] = (ev, cur.cuda_stream)
+                self._xblk = xblk
+            for kind, want in (("rowmajor", rowmajor), ("blocked", blocked)):
+                rec = self._copy_ev.get(kind)
+                if want and rec is not None and rec[1] != cur.cuda_stream:
+                    cur.wait_event(rec[0])
+            if self._xnorm_max is None:
+                # an upper bound of every row norm (fp32 rounding slack included); one host read per index change
+                self._xnorm_max = float(torch.linalg.vector_norm(self._xb, dim=1).max().item()) * (1.0 + 1e-5)
         return self._xb16
 
     def reconstruct_n(self, i0=0, n=None):

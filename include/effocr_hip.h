@@ -203,7 +203,7 @@ int effocr_convert_bf16(const float* src_dev, int64_t n, void* dst_dev, void* st
  * of the encoder's weight copies; effocr_convert_bf16_blocked writes it, effocr_bf16_blocked_bytes sizes it: rows are padded to a
  * multiple of 64 with zeros).  With it, d in {128, 384, 768} and k <= 16 the screening pass is the Q-STATIONARY kernel: the queries of a
  * workgroup (256 at d <= 384, 128 at d = 768) live in registers as MFMA operand fragments, the index streams through a 6-slot LDS-DMA
- * ring as verbatim 512-byte cells (conflict-free fragment reads, no transposes), per-lane register top-k lists — for EVERY index size:
+ * ring as verbatim 512-byte cells (conflict-free fragment reads, no transposes), NO per-lane lists (block maxima only, below) — for EVERY index size:
  * BASELINE configs[1]'s own 10 000-row search and configs[3]'s 1M x 768 alike.  xb_bf16_dev (row-major copy) may be NULL then, except
  * for calls of 17..128 queries against >= 65 536 rows, which keep the streaming screen when it is given.  Results are bit-identical to
  * effocr_knn_ip_topk either way.  The pass writes only the MAXIMUM approximate score per 16-row block (and per sub-chunk); a rank-count
