@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip
 # Never loaded by the engines on their own; tests that compare those paths switch to it with use_library().
 SO_PATH_AB = os.path.join(_HERE, "libeffocr_hip_ab.so")
 
-ABI_VERSION = 7          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
+ABI_VERSION = 8          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 
@@ -124,6 +124,7 @@ def _declare(lib):
         "effocr_nms_batch_workspace_bytes": (sz, [i32, i32, i32]),
         "effocr_nms": (i32, [f32p, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
         "effocr_nms_batch": (i32, [f32p, i32, i32, i32, c.c_float, c.c_float, i32, i32, c.c_float, i32, f32p, vp, vp, sz, vp]),
+        "effocr_parse_char_boxes": (i32, [f32p, vp, i32, i32, i32, i32, i32, i32, f32p, vp, vp, vp, vp]),
         "effocr_op_linear": (i32, [i32, i32, vp, vp, f32p, f32p, vp, i32, i32, i32, vp]),
         "effocr_op_layernorm": (i32, [i32, f32p, i64, i32, f32p, f32p, c.c_float, vp, vp]),
         "effocr_op_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),

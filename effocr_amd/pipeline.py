@@ -229,53 +229,85 @@ def word_end_indices(char_rights, word_lefts):
     return out
 
 
-_PINNED_GUARD = threading.Lock()
-_PINNED = {}          # (device, bytes rounded up) -> pinned uint8 staging buffer of run_effocr's uploads (grow-only, one per size class)
+_PREFETCH = None
 
 
-_COPIERS = None
-
-
-def _copiers():
-    global _COPIERS
-    if _COPIERS is None:
+def _prefetcher():
+    global _PREFETCH
+    if _PREFETCH is None:
         from concurrent.futures import ThreadPoolExecutor
-        _COPIERS = ThreadPoolExecutor(max_workers=4, thread_name_prefix="effocr-upload")
-    return _COPIERS
+        _PREFETCH = ThreadPoolExecutor(max_workers=1, thread_name_prefix="effocr-upload")
+    return _PREFETCH
 
 
-def _upload_lines(imgs, dev):
-    """HWC uint8 images of ONE geometry (numpy, or uint8 tensors already on ``dev``) -> one [L,H,W,3] device tensor.  Host images
-    are copied line by line into a pinned staging buffer, each line's DMA issued right behind its memcpy (the copy of line i+1
-    runs under the transfer of line i); the buffer is reused by the next call only after this call's last transfer finished."""
-    if all(isinstance(im, torch.Tensor) for im in imgs):
-        return torch.stack([im.to(dev) for im in imgs]).contiguous()
+def _upload_lines(imgs, dev, stream=None):
+    """HWC uint8 images of ONE geometry (numpy, or uint8 tensors already on ``dev``) -> ([L,H,W,3] device tensor, event).  Host
+    images go to the device by the runtime's own pageable copy, line by line (round 6, tools/host_register_probe.py: 48.9 GB/s
+    against 55.7 GB/s from pinned memory — the pageable -> pinned memcpy of the round-3..5 staging chain alone cost more than that
+    difference).  ``stream``: issue the copies on this side stream (run_effocr's prefetch of the NEXT chunk of lines, from a helper
+    thread: the copy blocks its caller with the GIL released); the returned event marks the last copy — consumers on another
+    stream wait for it."""
+    if all(isinstance(im, torch.Tensor) and im.device == dev for im in imgs):
+        return torch.stack(list(imgs)).contiguous(), None
     L, shape = len(imgs), tuple(imgs[0].shape)
-    n = int(np.prod(shape))
-    key = (str(dev), 1 << max(20, (L * n - 1).bit_length()))
-    with _PINNED_GUARD:
-        ent = _PINNED.get(key)
-        if ent is None:
-            ent = _PINNED[key] = [torch.empty(key[1], dtype=torch.uint8).pin_memory(), None, threading.Lock()]
-    out = torch.empty((L,) + shape, dtype=torch.uint8, device=dev)
-    # One caller at a time per staging buffer, from the wait for the previous call's transfers until THIS call's last DMA is enqueued
-    # and its event recorded: the engines are shareable across threads (a-8), and two run_effocr calls on one device must not memcpy
-    # into the buffer while the other's DMAs are still reading it.
-    with ent[2]:
-        if ent[1] is not None:
-            ent[1].synchronize()                                              # previous call's transfers (normally long done)
-        stage = ent[0][: L * n].view((L,) + shape)
-        stage_np = stage.numpy()
-        # the pageable -> pinned memcpy is the slow leg (3 MB per 4096 x 256 line at one core's rate): four helper threads copy lines
-        # side by side (numpy releases the GIL for large copies), the DMA of line j goes out as soon as ITS copy has landed, in order
-        futs = [_copiers().submit(np.copyto, stage_np[j], im.cpu().numpy() if isinstance(im, torch.Tensor) else im) for j, im in enumerate(imgs)]
-        for j, f in enumerate(futs):
-            f.result()
-            out[j].copy_(stage[j], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        ent[1] = ev
-    return out
+    with torch.cuda.device(dev), torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(dev)):
+        out = torch.empty((L,) + shape, dtype=torch.uint8, device=dev)
+        for j, im in enumerate(imgs):
+            out[j].copy_(im if isinstance(im, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(im)))
+        ev = None
+        if stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+    return out, ev
+
+
+def _char_boxes_torch(rows, counts, max_det, H, W, axis, vertical):
+    """The same box stage as ~25 ATen launches (rounds 3-5): the fall-back for max_det > 4096 and what tests compare the kernel with."""
+    dev, L = rows.device, int(rows.shape[0])
+    valid = torch.arange(max_det, device=dev)[None, :] < counts[:, None]
+    is_char = valid & (rows[..., 5] == 0)
+    key = torch.where(is_char, rows[..., axis], torch.full_like(rows[..., axis], float("inf")))
+    order = torch.sort(key, dim=1, stable=True).indices                  # sorted(bboxes_char, key=x[0] | x[1]) (:72,134): stable
+    boxes = torch.gather(rows[..., :4], 1, order[..., None].expand(-1, -1, 4))     # [L,max_det,4], the first n_chars rows are characters
+    n_chars = is_char.sum(1)
+    r = torch.round(boxes).double()                                      # torch.round(bbox) (:313)
+    sel = torch.arange(max_det, device=dev)[None, :] < n_chars[:, None]
+    line_idx = torch.arange(L, device=dev, dtype=torch.int64)[:, None].expand(-1, max_det)
+    if vertical:                                                         # (:315-316)
+        lo = torch.round(r[..., 1] * H / 640).to(torch.int64)
+        hi = torch.round(r[..., 3] * H / 640).to(torch.int64)
+        y0, y1 = _resolve_slice(lo, H), _resolve_slice(hi, H)
+        x0, x1 = torch.zeros_like(y0), torch.full_like(y0, W)
+    else:                                                                # (:317-318)
+        lo = torch.round(r[..., 0] * W / 640).to(torch.int64)
+        hi = torch.round(r[..., 2] * W / 640).to(torch.int64)
+        x0, x1 = _resolve_slice(lo, W), _resolve_slice(hi, W)
+        y0, y1 = torch.zeros_like(x0), torch.full_like(x0, H)
+    boxes5 = torch.stack((x0, y0, x1, y1, line_idx), dim=-1)[sel].to(torch.int32)      # [total,5]; boolean indexing = a host sync
+    return boxes, n_chars.to(torch.int32), boxes5
+
+
+def _char_boxes(rows, counts, max_det, H, W, axis, vertical):
+    """Box stage of run_effocr on the device (csrc/boxes.hip, effocr_parse_char_boxes): NMS rows [L, max_det, 6] + counts [L] ->
+    (boxes [L, max_det, 4] with the characters first, stably sorted along the reading axis; n_chars [L] int32; boxes5 [total, 5] int32 =
+    the crop slice of every character, compact over the lines).  One host read (the total): the crop tensor is allocated from it."""
+    from . import _lib
+    if max_det > 4096:
+        return _char_boxes_torch(rows, counts, max_det, H, W, axis, vertical)
+    L = int(rows.shape[0])
+    dev = rows.device
+    Lh = _lib.lib()
+    rows = rows.contiguous()
+    counts = counts.to(torch.int32).contiguous()
+    boxes = torch.empty((L, max_det, 4), dtype=torch.float32, device=dev)
+    n_chars = torch.empty(L, dtype=torch.int32, device=dev)
+    b5 = torch.empty((L * max_det, 5), dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(Lh.effocr_parse_char_boxes(_lib.ptr(rows), _lib.ptr(counts), L, int(max_det), int(H), int(W), int(axis), 1 if vertical else 0,
+                                              _lib.ptr(boxes), _lib.ptr(n_chars), _lib.ptr(b5), _lib.ptr(total), _lib.current_stream(dev)),
+                   "effocr_parse_char_boxes", Lh)
+    return boxes, n_chars, b5[: int(total.item())]
 
 
 def _load_rgb(p):
@@ -299,7 +331,7 @@ def _resolve_slice(v, size):
 
 
 def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform, lang, num_streams=4, vertical=False,
-               localizer_output=None, conf_thres=0.5, *, knn_func, candidate_chars, anchor_margin=None, max_det=1000):
+               localizer_output=None, conf_thres=0.5, *, knn_func, candidate_chars, anchor_margin=None, max_det=1000, lines_per_chunk=16):
     """``run_effocr`` of infer_effocr_onnx_multi.py:227-397: text-line images -> {image key: transcription}.
 
     Same stages, same arithmetic, but the arrays never leave the GPU between them:
@@ -324,7 +356,9 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     detectron2 / mmdetection branches); ``localizer_output`` (debug drawings) raises NotImplementedError.  Results are keyed by
     the path (or by position for in-memory arrays) in INPUT order — the reference's order is thread-completion order.
     Images of different sizes are processed in groups of one geometry; HWC uint8 tensors already on the engines' device are
-    taken as they are (no upload)."""
+    taken as they are (no upload).  The reference hands over ALL line images of a job at once (:227, one list); here a group is
+    processed in chunks of ``lines_per_chunk`` lines (bounded activation memory: ~70 crops per line) and the upload of chunk i+1
+    runs on a side stream, from a helper thread, under the kernels of chunk i (round 6)."""
     import copy
     from .postprocess import LinePostprocessor
     if lang not in ("en", "jp"):
@@ -348,31 +382,25 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     # en_preprocess is called WITHOUT the vertical flag (:277: always sorts by x0); jp_preprocess gets it (:288)
     axis = 1 if (vertical and lang == "jp") else 0
     per_line = {}                                                            # line index -> (ids, sorted char boxes, word boxes)
-    for (H, W), members in groups.items():
-        stack = _upload_lines([images[i] for i in members], dev)           # [L,H,W,3] uint8: the one upload (pinned staging, overlapped)
+    lpc = max(1, int(lines_per_chunk)) if lines_per_chunk else (1 << 30)
+    chunks = [(hw, mem[c0:c0 + lpc]) for hw, mem in groups.items() for c0 in range(0, len(mem), lpc)]
+    side = torch.cuda.Stream(device=dev) if len(chunks) > 1 else None
+    pending = None                                                           # upload of the NEXT chunk (future -> (stack, event))
+    for ci, ((H, W), members) in enumerate(chunks):
+        if pending is None:
+            stack, ev = _upload_lines([images[i] for i in members], dev)     # [L,H,W,3] uint8: the one upload of these lines
+        else:
+            stack, ev = pending.result()
+            pending = None
+        if ev is not None:
+            torch.cuda.current_stream(dev).wait_event(ev)
+            stack.record_stream(torch.cuda.current_stream(dev))
+        if ci + 1 < len(chunks):
+            nxt = [images[i] for i in chunks[ci + 1][1]]
+            pending = _prefetcher().submit(_upload_lines, nxt, dev, side)
         L = len(members)
         rows, counts = localizer_engine.run_device([stack[j] for j in range(L)], max_det=max_det)
-        valid = torch.arange(max_det, device=dev)[None, :] < counts[:, None]
-        labels = rows[..., 5]
-        is_char = valid & (labels == 0)
-        key = torch.where(is_char, rows[..., axis], torch.full_like(rows[..., axis], float("inf")))
-        order = torch.sort(key, dim=1, stable=True).indices                  # sorted(bboxes_char, key=x[0] | x[1]) (:72,134): stable
-        boxes = torch.gather(rows[..., :4], 1, order[..., None].expand(-1, -1, 4))     # [L,max_det,4], the first n_chars rows are characters
-        n_chars = is_char.sum(1)
-        r = torch.round(boxes).double()                                      # torch.round(bbox) (:313)
-        sel = torch.arange(max_det, device=dev)[None, :] < n_chars[:, None]
-        line_idx = torch.arange(L, device=dev, dtype=torch.int64)[:, None].expand(-1, max_det)
-        if vertical:                                                         # (:315-316)
-            lo = torch.round(r[..., 1] * H / 640).to(torch.int64)
-            hi = torch.round(r[..., 3] * H / 640).to(torch.int64)
-            y0, y1 = _resolve_slice(lo, H), _resolve_slice(hi, H)
-            x0, x1 = torch.zeros_like(y0), torch.full_like(y0, W)
-        else:                                                                # (:317-318)
-            lo = torch.round(r[..., 0] * W / 640).to(torch.int64)
-            hi = torch.round(r[..., 2] * W / 640).to(torch.int64)
-            x0, x1 = _resolve_slice(lo, W), _resolve_slice(hi, W)
-            y0, y1 = torch.zeros_like(x0), torch.full_like(x0, H)
-        boxes5 = torch.stack((x0, y0, x1, y1, line_idx), dim=-1)[sel].to(torch.int32)      # [total,5]; boolean indexing = sync 1
+        boxes, n_chars, boxes5 = _char_boxes(rows, counts, max_det, H, W, axis, vertical)     # two launches; one host read (sync 1)
         if boxes5.shape[0]:
             # 16-bit hand-off (SURVEY f-2): the crops are written in the encoder's operand type — same embeddings bit for bit
             crops = char_transform.boxes_batch(stack, boxes5, dtype=getattr(recognizer_engine, "crop_dtype", torch.float32))
@@ -381,10 +409,13 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
         else:
             ids = torch.empty(0, dtype=torch.int64, device=dev)
         # sync 2: everything the string stage needs, in one go
-        is_word = valid & (labels == 1)
         ids_h, boxes_h, n_h = ids.cpu().tolist(), boxes.cpu(), n_chars.cpu().tolist()
         check_encoder_status(recognizer_engine)
-        rows_h, word_h = (rows.cpu(), is_word.cpu()) if lang == "en" else (None, None)
+        if lang == "en":                                                     # word boxes = valid rows of class 1, in NMS order (:254-256)
+            rows_h, counts_h = rows.cpu(), counts.cpu()
+            word_h = (torch.arange(max_det)[None, :] < counts_h[:, None]) & (rows_h[..., 5] == 1)
+        else:
+            rows_h, word_h = None, None
         off = 0
         for j, li in enumerate(members):
             n = n_h[j]

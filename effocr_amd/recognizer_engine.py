@@ -42,7 +42,7 @@ class _Lane:
 class EffRecognizer:
 
     def __init__(self, model, num_cores=None, providers=None, arch=None, precision=DEFAULT_PRECISION, img_size=224,
-                 device=None, lanes=2):
+                 device=None, lanes=4, copiers=4, slices=8, staging="direct"):
         # num_cores / providers are ORT knobs (recognizer_engine.py:10-15): accepted and ignored.
         self.num_cores, self.providers = num_cores, providers
         if isinstance(model, dict):
@@ -55,13 +55,17 @@ class EffRecognizer:
         # `lanes` calls can be in flight at once; further callers wait for a free lane.  ctypes releases the GIL during
         # the enqueue and torch releases it during copies / synchronisation, so the threads really overlap:
         # H2D of call i+1 (pinned, async, own stream) runs under the kernels of call i.
-        self._lanes = queue.SimpleQueue()
+        self._lanes = queue.LifoQueue()                    # LIFO: a single caller keeps re-using ONE lane (warm pinned buffers / workspace); N callers spread over N lanes
         for _ in range(max(1, int(lanes))):
             self._lanes.put(_Lane(self._eng_net.device))
         # the pageable -> pinned staging copy is the slowest leg of a call (38.5 MB per 64 crops at one core's memcpy rate): a few
         # persistent helper threads copy slices side by side (numpy releases the GIL for large copies; torch's own intra-op pool is
         # far too large on these hosts — see run())
-        self._copiers = ThreadPoolExecutor(max_workers=4, thread_name_prefix="effocr-stage")
+        self._copiers = ThreadPoolExecutor(max_workers=max(1, int(copiers)), thread_name_prefix="effocr-stage") if staging == "pinned" else None
+        self._slices = max(1, int(slices))
+        if staging not in ("direct", "pinned"):
+            raise ValueError("staging must be 'direct' or 'pinned'")
+        self._staging = staging
 
     def __call__(self, imgs):
         return self.run(imgs)
@@ -110,16 +114,26 @@ class EffRecognizer:
             return [np.empty((0, D), dtype=np.float32)]
         lane = self._lanes.get()                             # blocks while every lane is busy
         try:
-            h_in, h_out = lane.staging(imgs.size, B * D)
+            direct = self._staging == "direct"
+            h_in, h_out = lane.staging(0 if direct else imgs.size, B * D)
             imgs = np.ascontiguousarray(imgs)
-            stage = h_in.view(imgs.shape)
-            stage_np = stage.numpy()
+            if not direct:
+                stage = h_in.view(imgs.shape)
+                stage_np = stage.numpy()
             with torch.cuda.device(eng.device), torch.cuda.stream(lane.stream):
                 # pageable -> pinned -> device in a few slices: the host memcpy of slice i+1 runs under the DMA of slice i.
                 # (np.copyto, not Tensor.copy_: torch spreads a 38 MB copy over its whole intra-op pool — 128 threads on this
                 # host — and the pool's wake-up costs 80-90 ms every few calls: 2.5 ms median but 23 ms mean per 64 crops.)
                 x = torch.empty(imgs.shape, dtype=torch.float32, device=eng.device)
-                nsl = max(1, min(8, B // 8))
+                if direct:
+                    # round 6 (tools/host_register_probe.py): the runtime's own pageable -> device copy moves a 38.5 MB batch in 0.79 ms
+                    # (48.9 GB/s; pinned -> device 0.69 ms) — the hand-made pageable -> pinned -> device chain below costs 1.5 ms on one
+                    # core and 2.1-2.7 ms per call with its helper threads.  The copy blocks this caller (GIL released) on the lane's
+                    # stream; other callers' kernels run meanwhile on theirs.
+                    x.copy_(torch.from_numpy(imgs))
+                    nsl = 0
+                else:
+                    nsl = max(1, min(self._slices, B // 8))
                 bounds = [(B * i // nsl, B * (i + 1) // nsl) for i in range(nsl)]
                 futs = [self._copiers.submit(np.copyto, stage_np[a:b], imgs[a:b]) for a, b in bounds]
                 for (a, b), f in zip(bounds, futs):             # DMA of slice i as soon as its memcpy is done, in order

@@ -29,7 +29,7 @@ extern "C" {
 /* bumped whenever an exported signature or the meaning of an argument changes (round 1: 1; round 2 added
  * arguments to effocr_op_mlp_blocked without a bump — callers must treat 1 as "unknown layout"); a caller built
  * against another value must refuse to call into the library (effocr_amd/_lib.py does) */
-#define EFFOCR_ABI_VERSION 7
+#define EFFOCR_ABI_VERSION 8
 
 enum effocr_status {
   EFFOCR_OK = 0,
@@ -310,6 +310,18 @@ int effocr_nms(const float* pred_dev, int n, int num_classes, float conf_thres, 
 size_t effocr_nms_batch_workspace_bytes(int n, int max_det, int max_nms);
 int effocr_nms_batch(const float* pred_dev, int batch, int n, int num_classes, float conf_thres, float iou_thres, int max_det, int max_nms,
                      float max_wh, int agnostic, float* out_dev, int* count_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ABI 8 — box stage of run_effocr (infer_effocr_onnx_multi.py:252-256,275-288,313-320; the stable sorted(..., key=x[axis]) of
+ * en_preprocess / jp_preprocess :70-73,133-135) for all `lines` of one localizer call, two launches:
+ * rows_dev [lines, max_det, 6] = (x0, y0, x1, y1, conf, label) as effocr_nms_batch wrote them, counts_dev [lines]; characters = label 0.
+ *   sorted_dev  [lines, max_det, 4]  the boxes with the characters first, STABLY sorted by x0 (axis 0) or y0 (axis 1), the rest behind in row order
+ *   n_chars_dev [lines]              characters per line
+ *   boxes5_dev  [lines * max_det, 5] int32 (x0, y0, x1, y1, line): the crop slice of every character, compact, in line order — torch.round (half
+ *                                    to even), x size / 640 in float64, Python round(), numpy slice resolution, full height (width if `vertical`)
+ *   total_dev   [1]                  number of rows written to boxes5_dev
+ * max_det <= 4096.  Bit-identical to the torch expression it replaces (tests/test_gpu_pipeline.py). */
+int effocr_parse_char_boxes(const float* rows_dev, const int* counts_dev, int lines, int max_det, int height, int width, int axis, int vertical,
+                            float* sorted_dev, int* n_chars_dev, int* boxes5_dev, int* total_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Individual encoder operators (exported so that each kernel is parity-tested on its own).

@@ -13,13 +13,15 @@ from effocr_amd.weights import init_state_dict
 pytestmark = pytest.mark.gpu
 
 
-def test_effrecognizer_shared_by_threads(dev):
+@pytest.mark.parametrize("staging,lanes", [("direct", 4), ("direct", 2), ("pinned", 2)])
+def test_effrecognizer_shared_by_threads(dev, staging, lanes):
     """infer_effocr_onnx_multi.py:207-223,350-364: N Python threads call ``run`` on ONE engine instance.  Results must be
-    bit-identical to serial calls (per-call streams, pinned staging, one workspace per stream)."""
+    bit-identical to serial calls (per-call streams, one workspace per stream; the host batch reaches the device by the runtime's
+    pageable copy — the default — or through the pinned staging slices)."""
     from effocr_amd.recognizer_engine import EffRecognizer
     arch = "vit_tiny_test"
     sd = init_state_dict(arch, seed=4, img_size=64)
-    eng = EffRecognizer(sd, arch=arch, precision="bf16", img_size=64, device=dev, lanes=2)
+    eng = EffRecognizer(sd, arch=arch, precision="bf16", img_size=64, device=dev, lanes=lanes, staging=staging)
     rng = np.random.default_rng(1)
     batches = [rng.standard_normal((b, 3, 64, 64), dtype=np.float32) for b in (64, 64, 7, 64, 33, 64, 1, 64)]
     serial = [eng.run(b)[0] for b in batches]

@@ -271,3 +271,35 @@ def test_line_recognizer_reproduces_the_references_infer(dev, suffix):
             else:
                 assert got[:1] == want[:1]
     assert full >= 20
+
+
+@pytest.mark.parametrize("vertical,axis", [(False, 0), (True, 1), (True, 0)])
+def test_box_stage_kernel_equals_the_torch_expression(dev, vertical, axis):
+    """csrc/boxes.hip (two launches) against the ~25 ATen launches it replaces (infer_effocr_onnx_multi.py:252-256,275-288,313-320):
+    identical sorted boxes, character counts and crop slices — ties in the sort key (stable: NMS order), boxes whose scaled bounds are
+    negative / beyond the line, half-way values for both roundings, lines with no characters, no rows at all, and every row a character."""
+    from effocr_amd.pipeline import _char_boxes, _char_boxes_torch
+    g = torch.Generator().manual_seed(5)
+    L, max_det, H, W = 7, 1000, 256, 4096
+    rows = torch.zeros(L, max_det, 6)
+    rows[..., 0] = (torch.rand(L, max_det, generator=g) * 700 - 30)
+    rows[..., 1] = (torch.rand(L, max_det, generator=g) * 700 - 30)
+    rows[..., 2] = rows[..., 0] + torch.rand(L, max_det, generator=g) * 80
+    rows[..., 3] = rows[..., 1] + torch.rand(L, max_det, generator=g) * 80
+    rows[..., 4] = torch.rand(L, max_det, generator=g)
+    rows[..., 5] = torch.randint(0, 2, (L, max_det), generator=g).float()
+    rows[0, :300, 0] = torch.randint(0, 20, (300,), generator=g).float()            # many equal sort keys: stability
+    rows[0, :300, 1] = torch.randint(0, 20, (300,), generator=g).float()
+    rows[1, :200, :4] = torch.round(rows[1, :200, :4]) + 0.5                         # x.5: round half to even
+    rows[2, :100, 0] = torch.arange(100).float() * 6.4 + 3.2                         # scaled values landing on .5 at W = 4096 (x 6.4)
+    rows[3, :, 5] = 1                                                                # a line without characters
+    rows[5, :, 5] = 0                                                                # every row a character
+    counts = torch.tensor([300, 1000, 640, 50, 0, 1000, 17], dtype=torch.int32)
+    rows, counts = rows.to(dev), counts.to(dev)
+    b0, n0, x0 = _char_boxes_torch(rows, counts, max_det, H, W, axis, vertical)
+    b1, n1, x1 = _char_boxes(rows, counts, max_det, H, W, axis, vertical)
+    assert torch.equal(n0.cpu(), n1.cpu()) and n1.tolist()[3:5] == [0, 0] and n1.tolist()[5] == 1000
+    assert torch.equal(x0.cpu(), x1.cpu()) and x1.dtype == torch.int32
+    assert torch.equal(b0.cpu(), b1.cpu())
+    e = _char_boxes(rows[:0], counts[:0], max_det, H, W, axis, vertical)
+    assert e[2].shape == (0, 5)
