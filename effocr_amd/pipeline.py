@@ -287,13 +287,15 @@ def _char_boxes_torch(rows, counts, max_det, H, W, axis, vertical):
     return boxes, n_chars.to(torch.int32), boxes5
 
 
-def _char_boxes(rows, counts, max_det, H, W, axis, vertical):
+def _char_boxes(rows, counts, max_det, H, W, axis, vertical, defer_total=False):
     """Box stage of run_effocr on the device (csrc/boxes.hip, effocr_parse_char_boxes): NMS rows [L, max_det, 6] + counts [L] ->
     (boxes [L, max_det, 4] with the characters first, stably sorted along the reading axis; n_chars [L] int32; boxes5 [total, 5] int32 =
-    the crop slice of every character, compact over the lines).  One host read (the total): the crop tensor is allocated from it."""
+    the crop slice of every character, compact over the lines).  One host read (the total): the crop tensor is allocated from it.
+    ``defer_total``: return (boxes, n_chars, the un-cut [L * max_det, 5] buffer, the device total) without reading anything."""
     from . import _lib
     if max_det > 4096:
-        return _char_boxes_torch(rows, counts, max_det, H, W, axis, vertical)
+        out = _char_boxes_torch(rows, counts, max_det, H, W, axis, vertical)
+        return out + (None,) if defer_total else out
     L = int(rows.shape[0])
     dev = rows.device
     Lh = _lib.lib()
@@ -307,6 +309,8 @@ def _char_boxes(rows, counts, max_det, H, W, axis, vertical):
         _lib.check(Lh.effocr_parse_char_boxes(_lib.ptr(rows), _lib.ptr(counts), L, int(max_det), int(H), int(W), int(axis), 1 if vertical else 0,
                                               _lib.ptr(boxes), _lib.ptr(n_chars), _lib.ptr(b5), _lib.ptr(total), _lib.current_stream(dev)),
                    "effocr_parse_char_boxes", Lh)
+    if defer_total:                                      # (run_effocr reads the total later: the next launches go out first)
+        return boxes, n_chars, b5, total
     return boxes, n_chars, b5[: int(total.item())]
 
 
@@ -348,7 +352,8 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
                   last batch of 64 produces rows nobody reads and is skipped);
       post        per line: characters joined (:384-385) and, for ``lang == "en"``, ``en_postprocess`` with the heights /
                   bottoms of the 640-space boxes (:323-325,387-392).
-    Two host synchronisations per call (character counts; ids + boxes), whatever the number of lines.
+    Two host reads per chunk of lines (the number of crops; ids + boxes), the second one on an event of its own chunk: the next chunk's
+    localizer is enqueued before the host looks at this chunk's results, so the device does not wait for Python between chunks.
 
     Differences from the reference signature: ``knn_func`` / ``candidate_chars`` are module globals there (:372,375) and
     keyword arguments here; ``anchor_margin`` is exposed (the reference call leaves ``en_postprocess``'s default None);
@@ -385,43 +390,74 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     lpc = max(1, int(lines_per_chunk)) if lines_per_chunk else (1 << 30)
     chunks = [(hw, mem[c0:c0 + lpc]) for hw, mem in groups.items() for c0 in range(0, len(mem), lpc)]
     side = torch.cuda.Stream(device=dev) if len(chunks) > 1 else None
-    pending = None                                                           # upload of the NEXT chunk (future -> (stack, event))
-    for ci, ((H, W), members) in enumerate(chunks):
-        if pending is None:
-            stack, ev = _upload_lines([images[i] for i in members], dev)     # [L,H,W,3] uint8: the one upload of these lines
-        else:
-            stack, ev = pending.result()
-            pending = None
+    cur = torch.cuda.current_stream(dev)
+    uploads = {}                                                             # chunk index -> future of (stack, event) / the pair itself
+
+    def start_upload(ci, prefetch):
+        if ci >= len(chunks) or ci in uploads:
+            return
+        imgs = [images[i] for i in chunks[ci][1]]
+        uploads[ci] = _prefetcher().submit(_upload_lines, imgs, dev, side) if prefetch else _upload_lines(imgs, dev)
+
+    def front(ci):
+        """Upload (waited for), localizer + NMS, box stage: everything of chunk ``ci`` that does not need the host.  Enqueued BEHIND
+        the recognizer kernels of chunk ci-1 and BEFORE the host reads that chunk's results, so the device never waits for Python."""
+        (H, W), members = chunks[ci]
+        up = uploads.pop(ci)
+        stack, ev = up.result() if hasattr(up, "result") else up
         if ev is not None:
-            torch.cuda.current_stream(dev).wait_event(ev)
-            stack.record_stream(torch.cuda.current_stream(dev))
-        if ci + 1 < len(chunks):
-            nxt = [images[i] for i in chunks[ci + 1][1]]
-            pending = _prefetcher().submit(_upload_lines, nxt, dev, side)
+            cur.wait_event(ev)
+            stack.record_stream(cur)
+        start_upload(ci + 1, prefetch=True)                                  # the NEXT chunk's lines travel under this chunk's kernels
         L = len(members)
         rows, counts = localizer_engine.run_device([stack[j] for j in range(L)], max_det=max_det)
-        boxes, n_chars, boxes5 = _char_boxes(rows, counts, max_det, H, W, axis, vertical)     # two launches; one host read (sync 1)
+        boxes, n_chars, b5, total = _char_boxes(rows, counts, max_det, H, W, axis, vertical, defer_total=True)   # two launches
+        return dict(H=H, W=W, members=members, stack=stack, rows=rows, counts=counts, boxes=boxes, n_chars=n_chars, b5=b5, total=total)
+
+    def back(st):
+        """Crops -> encoder -> k-NN of a chunk (one host read: the number of crops), results on their way to pinned host memory."""
+        if isinstance(st["total"], torch.Tensor):
+            boxes5 = st["b5"][: int(st["total"].item())]                    # sync 1: the crop tensor is allocated from it
+        else:
+            boxes5 = st["b5"]
         if boxes5.shape[0]:
             # 16-bit hand-off (SURVEY f-2): the crops are written in the encoder's operand type — same embeddings bit for bit
-            crops = char_transform.boxes_batch(stack, boxes5, dtype=getattr(recognizer_engine, "crop_dtype", torch.float32))
+            crops = char_transform.boxes_batch(st["stack"], boxes5, dtype=getattr(recognizer_engine, "crop_dtype", torch.float32))
             emb = recognizer_engine.encode_device(crops, normalize=True)
             ids = knn_func(emb, k=1)[1][:, 0]
         else:
             ids = torch.empty(0, dtype=torch.int64, device=dev)
-        # sync 2: everything the string stage needs, in one go
-        ids_h, boxes_h, n_h = ids.cpu().tolist(), boxes.cpu(), n_chars.cpu().tolist()
+        want = [ids, st["boxes"], st["n_chars"]] + ([st["rows"], st["counts"]] if lang == "en" else [])
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in want]   # (torch's caching pinned allocator)
+        for h, t in zip(host, want):
+            h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        st["host"], st["done"] = host, ev
+        st["stack"] = None                                                   # (the line images are not needed any more)
+
+    def finish(st):
+        """Sync 2 — on THIS chunk's event only (the next chunk's localizer is already running) — and the string stage's inputs."""
+        st["done"].synchronize()
         check_encoder_status(recognizer_engine)
+        ids_h, boxes_h, n_h = st["host"][0].tolist(), st["host"][1], st["host"][2].tolist()
         if lang == "en":                                                     # word boxes = valid rows of class 1, in NMS order (:254-256)
-            rows_h, counts_h = rows.cpu(), counts.cpu()
+            rows_h, counts_h = st["host"][3], st["host"][4].to(torch.int64)
             word_h = (torch.arange(max_det)[None, :] < counts_h[:, None]) & (rows_h[..., 5] == 1)
-        else:
-            rows_h, word_h = None, None
         off = 0
-        for j, li in enumerate(members):
+        for j, li in enumerate(st["members"]):
             n = n_h[j]
-            wb = rows_h[j][word_h[j]][:, :4] if lang == "en" else None
-            per_line[li] = (ids_h[off:off + n], boxes_h[j, :n], wb)
+            wb = rows_h[j][word_h[j]][:, :4].clone() if lang == "en" else None
+            per_line[li] = (ids_h[off:off + n], boxes_h[j, :n].clone(), wb)
             off += n
+
+    start_upload(0, prefetch=False)
+    st = front(0)
+    for ci in range(len(chunks)):
+        back(st)
+        nxt = front(ci + 1) if ci + 1 < len(chunks) else None
+        finish(st)
+        st = nxt
     for li, key_ in enumerate(keys):
         ids_l, cb, wb = per_line[li]
         out = "".join(candidate_chars[i][0] for i in ids_l).strip()           # "".join(x[0] for x in textline).strip() (:385), k = 1

@@ -58,10 +58,11 @@ knn.train(torch.nn.functional.normalize(torch.randn(10000, 384, generator=torch.
 chars = [chr(0x4E00 + i) for i in range(10000)]
 tf = PairedTransform(size=224, device=dev)
 rng = np.random.default_rng(0)
-lines = [(rng.integers(0, 256, (256, 4096, 3)) // 32 * 32).astype(np.uint8) for _ in range(16)]
+NL = int(sys.argv[sys.argv.index('--lines') + 1]) if '--lines' in sys.argv else 16
+lines = [(rng.integers(0, 256, (256, 4096, 3)) // 32 * 32).astype(np.uint8) for _ in range(NL)]
 inp = lines if "--host" in sys.argv else [torch.from_numpy(im).to(dev) for im in lines]
 for i in range(5):
     torch.cuda.synchronize(); time.sleep(0.05)
     t0 = time.perf_counter()
-    res, _ = run_effocr(inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=64)
+    res, _ = run_effocr(inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=1000 if '--lines' in sys.argv else 64)
     print(f"call {i}: {1e3 * (time.perf_counter() - t0):.2f} ms, {sum(len(v) for v in res.values())} chars", flush=True)
