@@ -57,6 +57,11 @@ class HipEncoder:
             self._wblob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self._L.effocr_encoder_upload(self._h, _lib.ptr(self._wblob), nbytes), "effocr_encoder_upload", self._L)
         self._ws = {}
+        # calls of 192..640 crops run as 2-4 concurrent sub-batches of ~128 crops on side streams (ViT-S, 16-bit modes; forward_split below)
+        self.split_streams = True
+        self._side = None                    # (streams, thread pool) of the split, created on first use
+        self._side_used = set()              # side streams whose workspaces may hold an unchecked status word
+        self._profiling = False
 
     def __del__(self):
         try:
@@ -103,22 +108,84 @@ class HipEncoder:
         emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
         if B == 0:
             return emb
+        parts = self._split_plan(B)
+        if parts > 1:
+            return self._forward_split(x, emb, normalize, parts)
+        self._forward_into(x, emb, normalize)
+        return emb
+
+    # Measured (tools/split_streams.py, tools/split_sweep.py, round 6, same box, encoder + k-NN): a 256-crop call 78.9 k crops/s as ONE call
+    # against 87.1 / 89.5 k as two / three concurrent sub-batches (0.83 -> 0.94 of the 1024-crop rate), 192 crops 66.4 -> 87.3 k as two,
+    # 384 crops 83.5 -> 91.3 k as three, 512 crops 90.9 -> 93.5 k; 160 crops and below lose (72.3 -> 59.4 k), 640 and above do not gain.  Why: 256 crops = 394 fused-MLP
+    # panels = 1.54 rounds of 256 CUs — the second round runs on 54 % of the chip — while two 128-crop sub-batches out of phase fill each
+    # other's idle CUs (one's 197-panel MLP beside the other's per-image kernel).
+    SPLIT_MIN, SPLIT_MAX = 176, 576
+
+    def _split_plan(self, B):
+        if not (self.split_streams and self.arch == "vit_small_patch16_224" and self.precision in _CROP_DTYPE) or self._profiling:
+            return 1
+        if isinstance(self.split_streams, int) and not isinstance(self.split_streams, bool):
+            return max(1, min(4, self.split_streams)) if B >= 8 else 1        # (forced part count: tools/split_sweep.py)
+        if not (self.SPLIT_MIN <= B < self.SPLIT_MAX):
+            return 1
+        return 2 if B < 240 else 3                                            # tools/split_sweep.py (profiles/r06_split_sweep.txt)
+
+    def _forward_into(self, x, emb, normalize):
+        """Enqueue one forward on torch's current stream of THIS thread.  The lock covers the workspace table only: the library's
+        forward is re-entrant while its profiler is not armed (it reads the handle, writes only the caller's buffers), and N caller
+        threads / the split's helper threads enqueue side by side (ctypes releases the GIL); an armed profiler serialises them."""
+        B = x.shape[0]
         need = self.workspace_bytes(B)
-        with self._lock, torch.cuda.device(self.device):
-            key = torch.cuda.current_stream(self.device).cuda_stream
-            ws = self._ws.get(key)
-            if ws is None or ws.numel() < need:
-                old = self._ws.pop(key, None)
-                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                if old is None:
-                    ws[:256].zero_()                            # the sticky status word starts clean (effocr_encoder_check_status)
-                else:
-                    ws[:256].copy_(old[:256])                   # ... and SURVIVES a larger workspace: an overflow recorded by an earlier, not yet
-                self._ws[key] = ws                              # checked forward on this stream must still be reported by the next check
-            x_dtype = _lib.PREC["fp32"] if x.dtype == torch.float32 else _lib.PREC[self.precision]
-            _lib.check(self._L.effocr_encoder_forward_ex(self._h, _lib.ptr(x), x_dtype, B, _lib.ptr(emb), 1 if normalize else 0,
-                                                         _lib.ptr(ws), ws.numel(),
-                                                         _lib.current_stream(self.device)), "effocr_encoder_forward", self._L)
+        with torch.cuda.device(self.device):
+            with self._lock:
+                key = torch.cuda.current_stream(self.device).cuda_stream
+                ws = self._ws.get(key)
+                if ws is None or ws.numel() < need:
+                    old = self._ws.pop(key, None)
+                    ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                    if old is None:
+                        ws[:256].zero_()                            # the sticky status word starts clean (effocr_encoder_check_status)
+                    else:
+                        ws[:256].copy_(old[:256])                   # ... and SURVIVES a larger workspace: an overflow recorded by an earlier, not yet
+                    self._ws[key] = ws                              # checked forward on this stream must still be reported by the next check
+                serial = self._profiling
+                if serial:
+                    self._enqueue(x, emb, normalize, ws)
+            if not serial:
+                self._enqueue(x, emb, normalize, ws)
+
+    def _enqueue(self, x, emb, normalize, ws):
+        x_dtype = _lib.PREC["fp32"] if x.dtype == torch.float32 else _lib.PREC[self.precision]
+        _lib.check(self._L.effocr_encoder_forward_ex(self._h, _lib.ptr(x), x_dtype, x.shape[0], _lib.ptr(emb), 1 if normalize else 0,
+                                                     _lib.ptr(ws), ws.numel(),
+                                                     _lib.current_stream(self.device)), "effocr_encoder_forward", self._L)
+
+    def _forward_split(self, x, emb, normalize, parts):
+        from concurrent.futures import ThreadPoolExecutor
+        with self._lock:
+            if self._side is None:
+                self._side = ([torch.cuda.Stream(device=self.device) for _ in range(4)],
+                              ThreadPoolExecutor(max_workers=4, thread_name_prefix="effocr-split"))
+        streams, pool = self._side
+        cur = torch.cuda.current_stream(self.device)
+        B = x.shape[0]
+        ready = torch.cuda.Event()
+        ready.record(cur)                                      # the crops (and everything queued before them) are on `cur`
+        bounds = [(B * i // parts, B * (i + 1) // parts) for i in range(parts)]
+
+        def sub(i):
+            a, b = bounds[i]
+            with torch.cuda.device(self.device), torch.cuda.stream(streams[i]):
+                streams[i].wait_event(ready)
+                self._forward_into(x[a:b], emb[a:b], normalize)
+                done = torch.cuda.Event()
+                done.record(streams[i])
+            return done
+
+        futs = [pool.submit(sub, i) for i in range(parts)]
+        for i, f in enumerate(futs):
+            cur.wait_event(f.result())                         # join: `cur` continues (k-NN, the caller's reads) behind every sub-batch
+            self._side_used.add(streams[i].cuda_stream)
         return emb
 
     def check_status(self):
@@ -129,6 +196,12 @@ class HipEncoder:
         calls it when it wants to know, and a non-finite query can never come back from the k-NN with a plausible id in the meantime
         (knn.hip ranks a NaN score below every real one: ids -1)."""
         with self._lock, torch.cuda.device(self.device):
+            side, self._side_used = self._side_used, set()
+            for key in side:                                   # sub-batches of split calls: their status words live in the side streams' workspaces
+                ws = self._ws.get(key)
+                if ws is not None:
+                    _lib.check(self._L.effocr_encoder_check_status(self._h, _lib.ptr(ws), ctypes.c_void_p(key)),
+                               "effocr_encoder_check_status", self._L)
             ws = self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
             if ws is None:
                 return
@@ -140,6 +213,7 @@ class HipEncoder:
     # -- HIP-event profiler (bench.py roofline) --------------------------------------------------
     def profile_begin(self, only=None):
         """Arm the in-library profiler: every kernel class, or only the class named ``only``."""
+        self._profiling = True                                 # (armed profiler: enqueues serialised, no stream split)
         _lib.check(self._L.effocr_encoder_profile_begin(self._h, 2 if only else 1, only.encode() if only else None),
                    "effocr_encoder_profile_begin", self._L)
 
@@ -147,6 +221,7 @@ class HipEncoder:
         """-> {class: {"ms": total, "launches": n, "flops": total algorithmic FLOPs, "shader_ghz": clock the class ran at (full
         breakdowns only, else 0)}} (synchronises)."""
         n = self._L.effocr_encoder_profile_collect(self._h)
+        self._profiling = False
         if n < 0:
             _lib.check(n, "effocr_encoder_profile_collect")
         out = {}

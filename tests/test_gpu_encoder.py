@@ -329,6 +329,44 @@ def test_embedding_does_not_depend_on_the_call_size(dev, prec):
         assert torch.equal(planted.search_device(emb, 1)[1][:, 0], want)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("B", [176, 239, 256, 575])
+def test_stream_split_calls_equal_their_sub_batches(dev, prec, B):
+    """Round 6: calls of 176..575 crops run as 2 / 3 concurrent sub-batches on side streams (HipEncoder._forward_split; 16-bit ViT-S).
+    The split call must be BIT-identical to the sub-batches run as calls of their own (same kernels at the same call sizes), agree with
+    the unsplit call of the same crops within the mode's call-size bound, join back onto the caller's stream (the result is readable right
+    away), and report a non-finite sub-batch through check_status (the status words live in the side streams' workspaces)."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    sd = init_state_dict(arch, seed=3, img_size=224)
+    enc = HipEncoder(arch, sd, precision=prec, device=dev)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(B), device=dev)
+    parts = enc._split_plan(B)
+    assert parts == (1 if prec == "fp32" else (2 if B < 240 else 3))
+    got = enc.forward(x, normalize=True)
+    first = got.clone()                                                  # readable on the caller's stream without a synchronise
+    enc.split_streams = False
+    whole = enc.forward(x, normalize=True)
+    bounds = [(B * i // parts, B * (i + 1) // parts) for i in range(parts)]
+    subs = torch.cat([enc.forward(x[a:b].contiguous(), normalize=True) for a, b in bounds])
+    torch.cuda.synchronize()
+    assert torch.equal(first, got) and torch.equal(got, subs)
+    bound = {"fp32": 2e-6, "fp16": REL["fp16"], "bf16": REL["bf16"]}[prec]
+    e = rel_err(got.cpu(), whole.cpu())
+    print(f"{arch} {prec} {B} crops: {parts} concurrent sub-batches vs one call {e:.2e}")
+    assert e <= bound
+    if prec != "fp32":
+        enc.split_streams = True
+        enc.check_status()                                               # clean so far
+        bad = x.clone()
+        bad[B - 1, 0, 0, 0] = float("nan")                               # lands in the LAST sub-batch
+        enc.forward(bad, normalize=True)
+        from effocr_amd._lib import EffOCRHipError
+        with pytest.raises(EffOCRHipError):
+            enc.check_status()
+        enc.check_status()                                               # sticky word cleared by the failing check
+
+
 def test_resnet_and_localizer_do_not_depend_on_the_call_size(dev):
     """resnet18 (split-K convolutions for launches of few tiles) and the YOLOv5s localizer at 1 vs 16 images per call: exact-fp32
     MFMA operands either way, only the order of the split partial sums moves: <= 2e-6 relative."""
