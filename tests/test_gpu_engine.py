@@ -333,3 +333,40 @@ def test_top1_safety_margin_per_precision(dev):
         assert torch.equal(I, 2 * torch.arange(48)), prec
     assert report["fp16"] < report["bf16"]
     print("top-1 safe cosine margins:", {k: f"{v:.2e}" for k, v in report.items()})
+
+
+def test_stream_split_forward_from_several_caller_threads(dev):
+    """Round 6: 256-crop calls run as concurrent sub-batches on the encoder's side streams.  Three caller threads, each on a stream of
+    its own, share ONE HipEncoder (the reference's N-threads-one-engine use, infer_effocr_onnx_multi.py:207-223): the side streams and
+    their workspaces are shared too, so the sub-batches of different callers queue behind each other — results must stay bit-identical
+    to the same calls made one after the other."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    enc = HipEncoder(arch, init_state_dict(arch, seed=2, img_size=224), precision="fp16", device=dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    xs = [torch.randn(b, 3, 224, 224, generator=g, device=dev) for b in (256, 200, 300)]
+    assert all(enc._split_plan(x.shape[0]) > 1 for x in xs)
+    serial = [enc.forward(x, normalize=True).clone() for x in xs]
+    torch.cuda.synchronize()
+    out, errors = [None] * 3, []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(4):
+                    r = enc.forward(xs[i], normalize=True)
+                st.synchronize()
+            out[i] = r
+        except Exception as e:                 # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for i in range(3):
+        assert torch.equal(out[i], serial[i]), i
+    enc.check_status()
