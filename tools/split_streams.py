@@ -10,9 +10,13 @@ from effocr_amd.weights import init_state_dict
 dev = torch.device("cuda:0")
 arch = "vit_small_patch16_224"
 enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=224), precision="bf16", device=dev)
+enc.split_streams = False
+for o in sys.argv[1:]:
+    if "=" in o:
+        k, v = o.split("="); enc.set_option(k, int(v)); print("option", k, v)
 idx = IndexFlatIP(384, device=dev)
 idx.add(torch.nn.functional.normalize(torch.randn(10000, 384, generator=torch.Generator().manual_seed(0)), dim=1))
-for T in (64, 128, 256, 512, 1024):
+for T in (64, 128, 192, 256):
     row = []
     for S in (1, 2, 4):
         if T // S < 32: row.append("   -   "); continue
