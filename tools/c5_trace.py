@@ -64,5 +64,5 @@ inp = lines if "--host" in sys.argv else [torch.from_numpy(im).to(dev) for im in
 for i in range(5):
     torch.cuda.synchronize(); time.sleep(0.05)
     t0 = time.perf_counter()
-    res, _ = run_effocr(inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=1000 if '--lines' in sys.argv else 64)
+    res, _ = run_effocr(inp, loc, rec, tf, "jp", knn_func=knn, candidate_chars=chars, max_det=1000 if '--lines' in sys.argv else 64, overlap_localizer='--serial' not in sys.argv)
     print(f"call {i}: {1e3 * (time.perf_counter() - t0):.2f} ms, {sum(len(v) for v in res.values())} chars", flush=True)
