@@ -7,6 +7,7 @@ Restated reference logic (file:line into the reference tree):
   kNN branch of EffOCR.infer      infer_effocr.py:310-319,337-338
   ONNX-driver recognizer phase    infer_effocr_onnx_multi.py:350-375
 """
+import os
 import queue
 import threading
 
@@ -314,6 +315,28 @@ def _char_boxes(rows, counts, max_det, H, W, axis, vertical, defer_total=False):
     return boxes, n_chars, b5[: int(total.item())]
 
 
+def _draw_localizer_boxes(out_dir, coco_images, images, per_line, vertical):
+    """``localizer_output`` of the ONNX driver (infer_effocr_onnx_multi.py:292-305): every line image saved under its base name with the
+    character crop regions outlined in red — torch.round(bbox), scaled by size / 640 with Python's round(), full line height (width when
+    vertical), NOT clipped (PIL clips what it draws).  In-memory images have no name: "<position>.png".  Debug output, host side."""
+    from PIL import Image, ImageDraw
+    for li, src in enumerate(coco_images):
+        im = images[li]
+        if isinstance(im, torch.Tensor):
+            im = im.cpu().numpy()
+        img = Image.fromarray(np.ascontiguousarray(im)).convert("RGB")
+        W, H = img.size
+        draw = ImageDraw.Draw(img)
+        for bb in per_line[li][1]:
+            x0, y0, x1, y1 = (float(torch.round(v)) for v in bb)
+            if vertical:
+                rect = (0, int(round(y0 * H / 640)), W, int(round(y1 * H / 640)))
+            else:
+                rect = (int(round(x0 * W / 640)), 0, int(round(x1 * W / 640)), H)
+            draw.rectangle(rect, outline="red")
+        img.save(os.path.join(out_dir, os.path.basename(src) if isinstance(src, str) else f"{li}.png"))
+
+
 def _load_rgb(p):
     if isinstance(p, torch.Tensor):
         if p.dim() != 3 or p.shape[2] != 3 or p.dtype != torch.uint8:
@@ -358,7 +381,7 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     Differences from the reference signature: ``knn_func`` / ``candidate_chars`` are module globals there (:372,375) and
     keyword arguments here; ``anchor_margin`` is exposed (the reference call leaves ``en_postprocess``'s default None);
     ``num_streams`` / ``conf_thres`` are accepted and unused (HIP streams are ordered by the device; ``conf_thres`` only feeds the
-    detectron2 / mmdetection branches); ``localizer_output`` (debug drawings) raises NotImplementedError.  Results are keyed by
+    detectron2 / mmdetection branches); ``localizer_output``: a directory that receives the debug drawings of :292-305.  Results are keyed by
     the path (or by position for in-memory arrays) in INPUT order — the reference's order is thread-completion order.
     Images of different sizes are processed in groups of one geometry; HWC uint8 tensors already on the engines' device are
     taken as they are (no upload).  The reference hands over ALL line images of a job at once (:227, one list); here a group is
@@ -370,8 +393,6 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     from .postprocess import LinePostprocessor
     if lang not in ("en", "jp"):
         raise ValueError("lang must be 'en' or 'jp'")
-    if localizer_output:
-        raise NotImplementedError("localizer_output (debug drawings of the localizer boxes) is not part of the hot path")
     if getattr(localizer_engine, "_model_backend", "yolo") != "yolo":
         raise NotImplementedError("only the yolo localizer backend exists")
     keys = [p if isinstance(p, str) else i for i, p in enumerate(coco_images)]
@@ -472,6 +493,8 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
         nxt = front(ci + 1) if ci + 1 < len(chunks) else None
         finish(st)
         st = nxt
+    if localizer_output:
+        _draw_localizer_boxes(localizer_output, coco_images, images, per_line, vertical)
     for li, key_ in enumerate(keys):
         ids_l, cb, wb = per_line[li]
         out = "".join(candidate_chars[i][0] for i in ids_l).strip()           # "".join(x[0] for x in textline).strip() (:385), k = 1

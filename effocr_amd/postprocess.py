@@ -14,8 +14,8 @@ Reference: `infer_effocr.py`
                                  "-" sitting on the baseline become ".".  Quirk kept: returns None when ANY input
                                  (including `word_end_idx`) is empty
   * `infer` (:255-343)           glue: boxes -> crops -> recognizer -> strings
-The optional homoglyph spell checker (`utils/spell_check_utils.py`, needs external dictionaries) is out of scope:
-`spell_check=True` raises NotImplementedError.
+The optional homoglyph spell checker (`spell_check=True`, infer_effocr.py:401-402) lives in `effocr_amd/spell_check.py`; it needs a
+word-frequency dictionary (`worddict=`, or symspellpy's packaged file when that package is installed).
 """
 import numpy as np
 
@@ -26,11 +26,16 @@ LARGE_NUM = 1_000_000                # infer_effocr.py:239
 
 class LinePostprocessor:
     def __init__(self, lang="jp", vertical=False, score_thresh=0.5, score_thresh_word=0.5, anchor_margin=None,
-                 anchor_multiplier=4, spell_check=False):
+                 anchor_multiplier=4, spell_check=False, worddict=None, simdict=None, abbrevset=None):
         if lang not in ("jp", "en"):
             raise ValueError("lang must be 'jp' or 'en'")
-        if spell_check:
-            raise NotImplementedError("the homoglyph spell checker needs the reference's external dictionaries")
+        self.spell_check = bool(spell_check)
+        if self.spell_check:
+            # WORDDICT / SIMDICT / ABBREVSET are module globals of the reference's driver (infer_effocr.py:471-473); keyword arguments here
+            from . import spell_check as SC
+            self.worddict = SC.create_worddict() if worddict is None else worddict
+            self.simdict = SC.create_homoglyph_dict() if simdict is None else simdict
+            self.abbrevset = SC.create_common_abbrev() if abbrevset is None else abbrevset
         self.lang, self.vertical = lang, bool(vertical)
         self.score_thresh, self.score_thresh_word = score_thresh, score_thresh_word
         self.anchor_margin, self.anchor_multiplier = anchor_margin, anchor_multiplier
@@ -82,22 +87,30 @@ class LinePostprocessor:
         if len(heights) != len(line):
             raise AssertionError(f"charheights_w_spaces = {len(heights)}; output = {len(line)}; {line}")
         anchors = [i for i, c in enumerate(line) if c in DISTINCT_LOWERCASE]
-        if not anchors or self.anchor_margin is None:
+        repair = bool(anchors) and self.anchor_margin is not None
+        if repair:
+            # index lists over the line AS RECOGNISED (:388-399) ...
+            h = np.asarray(heights, dtype=np.float64)
+            b = np.asarray(bottoms, dtype=np.float64)
+            mean_h = sum(heights[i] for i in anchors) / len(anchors)
+            mean_b = sum(bottoms[i] for i in anchors) / len(anchors)
+            lower = set(np.nonzero(np.abs(h - mean_h) < self.anchor_margin * mean_h)[0].tolist())
+            upper = set(np.nonzero((h - mean_h) > self.anchor_margin * self.anchor_multiplier * mean_h)[0].tolist())
+            period = {i for i in np.nonzero(np.abs(b - mean_b) < self.anchor_margin * mean_h)[0].tolist() if line[i] == "-"}
+        if self.spell_check:
+            # ... the spell checker rewrites the line in between (:401-402) — quirk kept: a correction that changes the length (H -> ll)
+            # shifts the characters under the index lists computed above
+            from .spell_check import visual_spell_checker
+            line = visual_spell_checker(line, self.worddict, self.simdict, self.abbrevset)
+        if not repair:
             return line
-        h = np.asarray(heights, dtype=np.float64)
-        b = np.asarray(bottoms, dtype=np.float64)
-        mean_h = sum(heights[i] for i in anchors) / len(anchors)
-        mean_b = sum(bottoms[i] for i in anchors) / len(anchors)
-        lower = np.abs(h - mean_h) < self.anchor_margin * mean_h
-        upper = (h - mean_h) > self.anchor_margin * self.anchor_multiplier * mean_h
-        period = np.abs(b - mean_b) < self.anchor_margin * mean_h
         out = []
-        for i, c in enumerate(line):
-            if lower[i]:
+        for i, c in enumerate(line):                                          # ... and are applied to the corrected line (:404-408)
+            if i in lower:
                 c = c.lower()
-            if upper[i] and c in NONDISTINCT_LOWERCASE:
+            if i in upper and c in NONDISTINCT_LOWERCASE:
                 c = c.upper()
-            if line[i] == "-" and period[i]:
+            if i in period:
                 c = "."
             out.append(c)
         return "".join(out)

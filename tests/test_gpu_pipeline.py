@@ -174,8 +174,15 @@ def test_run_effocr_edge_cases(dev, tmp_path):
     assert run_effocr([], loc, rec, tf, "en", knn_func=knn, candidate_chars=CHARS)[0] == {}
     with pytest.raises(ValueError):
         run_effocr(lines[:1], loc, rec, tf, "fr", knn_func=knn, candidate_chars=CHARS)
-    with pytest.raises(NotImplementedError):
-        run_effocr(lines[:1], loc, rec, tf, "en", localizer_output=str(tmp_path), knn_func=knn, candidate_chars=CHARS)
+    # localizer_output: the debug drawings of infer_effocr_onnx_multi.py:292-305 — one image per line, character regions outlined in red
+    from PIL import Image
+    gd, _ = run_effocr(lines[:2], loc, rec, tf, "en", localizer_output=str(tmp_path), knn_func=knn, candidate_chars=CHARS)
+    assert gd == run_effocr(lines[:2], loc, rec, tf, "en", knn_func=knn, candidate_chars=CHARS)[0]      # drawing changes no result
+    for j in (0, 1):
+        drawn = np.array(Image.open(tmp_path / f"{j}.png").convert("RGB"))
+        assert drawn.shape == lines[j].shape
+        changed = (drawn != lines[j]).any(axis=2)
+        assert changed.any() and (drawn[changed] == np.array([255, 0, 0])).all()            # only red outline pixels differ
 
 
 def test_word_end_indices_keeps_the_reference_quirks():

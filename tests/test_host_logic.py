@@ -208,8 +208,9 @@ def test_en_postprocess_spaces_case_and_period():
     assert R.en_postprocess("abc", [], [1, 1, 1], [1, 1, 1]) is None
     with pytest.raises(AssertionError):
         LinePostprocessor(lang="en").en_postprocess("abc", [0], [1, 1], [1, 1, 1])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                      # spell_check=True needs a word-frequency dictionary (symspellpy absent here)
         LinePostprocessor(lang="en", spell_check=True)
+    assert LinePostprocessor(lang="en", spell_check=True, worddict={"hello": 5}).en_postprocess("he11o", [0], [9.0] * 5, [1.0] * 5) == "hello"
 
 
 def test_postprocess_matches_restatement_on_random_lines():

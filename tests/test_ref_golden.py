@@ -239,3 +239,61 @@ def test_reference_infer_replayed_through_the_oracle():
         assert (cb is None and c["char_bboxes"] is None) or _floats(cb) == c["char_bboxes"]
         seen += len(nns or [])
     assert seen > 35
+
+
+# ---- the optional homoglyph spell checker (infer_effocr.py:401-402, utils/spell_check_utils.py), recorded by make_ref_spellcheck.py ----
+@pytest.fixture(scope="module")
+def sx():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_spellcheck.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_spell_check_tables_and_helpers_equal_the_reference(sx):
+    from effocr_amd import spell_check as S
+    assert S.create_homoglyph_dict() == sx["homoglyphs"]
+    assert sorted(S.create_common_abbrev()) == sx["abbrevs"]
+    words, abbr = sx["words"], set(sx["abbrevs"])
+    for c in sx["helpers"]:
+        s = c["s"]
+        got = {"s": s, "depunctuate": S.depunctuate(s), "is_number": S.is_number(s), "is_word": S.is_word(s, words),
+               "is_initial": S.is_initial(s), "all_caps": S.all_caps(s), "is_abbrev": S.is_abbrev(s, abbr)}
+        assert got == c
+    for c in sx["majority"]:
+        if "raises" in c:
+            with pytest.raises(IndexError):
+                S.majority_normalize(c["s"], sx["homoglyphs"])
+        else:
+            assert S.majority_normalize(c["s"], sx["homoglyphs"]) == c["out"], c
+
+
+def test_visual_spell_checker_equals_the_reference(sx):
+    """192 recorded calls of the reference's visual_spell_checker over a synthetic dictionary: dictionary hits by frequency, abbreviations,
+    initials, numbers, splitters (incl. the double-quote quirk), the H -> ll index shift, a beam of 3, majority normalisation on / off."""
+    from effocr_amd import spell_check as S
+    words, sim, abbr = sx["words"], sx["homoglyphs"], set(sx["abbrevs"])
+    changed = 0
+    for c in sx["checker"]:
+        assert "raises" not in c
+        got = S.visual_spell_checker(c["line"], words, sim, abbr, beam=c["beam"], majority_norm=c["majority_norm"])
+        assert got == c["out"], c
+        changed += got != c["line"]
+    assert changed > 60
+
+
+def test_en_postprocess_with_spell_check_equals_the_reference(sx):
+    """EffOCR.en_postprocess(spell_check=True): the case-repair index lists are computed before the correction and applied after it."""
+    from effocr_amd.postprocess import LinePostprocessor
+    words, sim, abbr = sx["words"], sx["homoglyphs"], set(sx["abbrevs"])
+    for c in sx["postprocess"]:
+        post = LinePostprocessor(lang="en", anchor_margin=c["anchor_margin"], spell_check=True, worddict=words, simdict=sim, abbrevset=abbr)
+        _check_post(lambda: post.en_postprocess(c["line"], c["word_end_idx"], c["heights"], c["bottoms"]), c)
+
+
+def test_load_worddict_reads_the_symspellpy_format(tmp_path):
+    from effocr_amd import spell_check as S
+    p = tmp_path / "freq.txt"
+    p.write_text("the 23135851162\nhello 32960381\nmr 5000\nbroken line here\n\nworld 1\n", encoding="utf-8")
+    d = S.load_worddict(str(p))
+    assert d == {"the": 23135851162, "hello": 32960381, "world": 1}          # "mr" removed: a de-punctuated common abbreviation
+    assert S.create_worddict(str(p)) == d
