@@ -82,6 +82,7 @@ struct effocr_encoder {
   int use_gemm3 = 1;                // 128-row wave-tile GEMM (gemm3.hip) where the blocked layout allows (0: A/B switch)
   int use_lnfold = 1;               // gemm3 path (ViT-B): LayerNorm folded into the residual producers' / qkv, fc1 consumers' epilogues (0: LayerNorm launches, A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
+  int split6 = 1;                   // fused MLP: 6-way hidden split for calls of <= 27 crops (0: A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
   int panel_rows = 128;             // row-panel height: 128 (1 workgroup/CU) or 64 (2 workgroups/CU)
@@ -427,7 +428,7 @@ VitWs vit_ws(const effocr_encoder* e, int B) {
     // SMALLER than the 4-way partials (M x 1536 x 2 bytes against 4 x M x 384 x 4): the launcher then silently ran whole panels on a
     // tenth of the chip (16 crops: 73 us per block on 25 CUs; round 6).  Size for the split the launcher will choose.
     const size_t cus = (size_t)device_cus(), np = M / 128, tail = np % cus;
-    const size_t split = (tail && tail * 4 <= cus) ? 4 : (tail && tail * 2 <= cus) ? 2 : 0;
+    const size_t split = (tail && tail * 6 <= cus) ? 6 : (tail && tail * 4 <= cus) ? 4 : (tail && tail * 2 <= cus) ? 2 : 0;
     const size_t need = split * tail * 128 * D * 4;
     if (need > w.hbytes) w.hbytes = need;
   }
@@ -515,7 +516,7 @@ int vit_forward(effocr_encoder* e, const void* x, int x16, int B, float* emb, in
         MlpArgs m{};
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
         m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
-        m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split; m.stagger = e->mlp_stagger; m.stagger_min_rounds = e->mlp_stagger_min_rounds;   // the hidden buffer is free on this path
+        m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split; m.no_split6 = !e->split6; m.stagger = e->mlp_stagger; m.stagger_min_rounds = e->mlp_stagger_min_rounds;   // the hidden buffer is free on this path
         if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
           m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p);
           if (i + 1 == e->vit.depth && e->cls_only_last) {
@@ -806,6 +807,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "use_gemm2") { enc->use_gemm2 = value; return EFFOCR_OK; }
   if (n == "use_blocked") { enc->use_blocked = value; return EFFOCR_OK; }
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
+  if (n == "split6") { enc->split6 = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_lnfold") { enc->use_lnfold = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }

@@ -54,6 +54,7 @@ struct MlpArgs {
   int rows_alloc;                   // rows addressable in x (multiple of 32, >= M)
   float* partial; size_t partial_bytes;   // optional scratch for the tail split (>= 4 * 64 * 128 * D * 4 bytes covers every case)
   int no_tail_split;                // 1: single launch (A/B switch)
+  int no_split6;                    // 1: never the 6-way split of calls of <= 27 crops (A/B switch)
   int panel0, tail_rb, stagger_wgs, main_wgs; // set by the launcher
   int stagger;                      // > 0: the first round of workgroups starts spread over 32 x stagger clock ticks (see mlp_kernel.hpp)
   int stagger_min_rounds;           // ... when the launch has at least this many rounds of CUs (0 = 4)

@@ -740,7 +740,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // Schedule (ring stream order A(0) | A(1) | B(0) | A(2) | B(1) | ...).  ONE hand-over set: parked after A(c) — once B(c-1)
   // has consumed the previous contents — activated in place under A(c+1), consumed by B(c):
   //   A(0) park | {A(c)+gelu(c-1) | B(c-1) | park(c)} c=1..NC-1 | gelu(NC-1) | B(NC-1)
-  static_assert(NC >= 3, "mlp: at least three hidden chunks");
+  static_assert(NC >= 3 || (NC == 2 && MLP_GELU_BURST == 2), "mlp: at least three hidden chunks (two: fused-burst hand-over only)");
   typedef std::integral_constant<int, FAR> Far;
   // Schedule, same ring stream order.  TWO hand-over sets (chunk c uses set c & 1): while B(c-1) consumes one, the ops of chunk c
   // fill the other — its park ops and the first part of its GELU behind B(c-1)'s MFMAs, the rest behind A(c+1)'s:
@@ -751,6 +751,18 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   typedef std::integral_constant<int, KB> KB_; typedef std::integral_constant<int, CO::N> KN_;
   HSet S2[2];
   const int cb0 = c0 * 128;
+  if constexpr (NC == 2) {
+    // Two chunks per workgroup (round 6: the 6-way split of calls of <= 27 crops — 12 chunks over six workgroups per panel):
+    //   A(0) | hand-over(0) | A(1) | B(0) + hand-over(1) | B(1)        (ring stream A(0) | A(1) | B(0) | B(1), as stage_src deals it)
+    phase_a_h(Far{}, nullptr, 0, K0_{}, K0_{});                             // A(0): 3 phases = 18 stages follow
+    if constexpr (!(MLP_DIAG & 1)) {
+      bias_octet(cb0, std::integral_constant<int, 0>{});
+      sfor<0, 8>([&](auto O_) { fused_burst(S2[0], cb0, O_); });
+    }
+    phase_a_h(std::integral_constant<int, 2 * SB>{}, nullptr, 0, K0_{}, K0_{});                                   // A(1)
+    phase_b_h(std::integral_constant<int, SB>{}, S2[0], &S2[1], cb0 + 128, K0_{}, KB_{});                        // B(0) + hand-over(1)
+    phase_b_h(std::integral_constant<int, 0>{}, S2[1], nullptr, 0, K0_{}, K0_{});                                 // B(1)
+  } else {
   phase_a_h(Far{}, nullptr, 0, K0_{}, K0_{});                               // A(0)
   if constexpr (MLP_GELU_BURST == 2) {
     if constexpr (!(MLP_DIAG & 1)) {
@@ -784,6 +796,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   else if constexpr (!(MLP_DIAG & 1))
   sfor<KB, CO::N>([&](auto K_) { gop(S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K_); });
   phase_b_h(std::integral_constant<int, 0>{}, S2[(NC - 1) & 1], nullptr, 0, K0_{}, K0_{});                     // B(NC-1)
+  }
   MLP_STAMP_AT(8)
   // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row (W2's
   // rows are permuted per 32: api.hip rowperm32).  Whole panels: acc2 already holds x + bias2 + fc2 — nothing is re-read.
@@ -907,17 +920,18 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   const int slots = device_cus();
   const int tail = a.no_tail_split ? 0 : npanels % slots;
   int split = 1;
-  if (tail > 0 && tail * 4 <= slots) split = 4;
-  else if (tail > 0 && tail * 2 <= slots) split = 2;
-  const size_t need = (size_t)split * tail * MLP_PT * a.D * sizeof(float);
-  if (split > 1 && (!a.partial || a.partial_bytes < need)) split = 1;
+  for (const int cand : {6, 4, 2}) {                     // 6: calls of <= 27 crops — six two-chunk parts per panel (16 crops: 0.89 -> 0.8 ms)
+    if (cand == 6 && a.no_split6) continue;
+    if (tail > 0 && tail * cand <= slots && a.partial && a.partial_bytes >= (size_t)cand * tail * MLP_PT * a.D * sizeof(float)) { split = cand; break; }
+  }
   const int main_panels = split > 1 ? npanels - tail : npanels;
   a.panel0 = main_panels;                                // first split panel
   a.main_wgs = main_panels;
   a.tail_rb = tail * 4;
   a.stagger_wgs = main_panels >= (a.stagger_min_rounds > 0 ? a.stagger_min_rounds : 4) * slots ? slots : 0;  // (the spread costs ~0.4 panel times at the end of the launch; measured worth it from 2 rounds on: api.hip)
   const dim3 grid((unsigned)(main_panels + (split > 1 ? tail * split : 0)));
-  if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, PROJ>), grid, dim3(256), 0, s, a);
+  if (split == 6) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 2, PROJ>), grid, dim3(256), 0, s, a);
+  else if (split == 4) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 3, PROJ>), grid, dim3(256), 0, s, a);
   else if (split == 2) hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 6, PROJ>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((mlp_fused_kernel<E, 384, 1536, 0, PROJ>), grid, dim3(256), 0, s, a);
   int rc = check_launch("mlp_fused");
