@@ -183,9 +183,16 @@ class HipEncoder:
             return done
 
         futs = [pool.submit(sub, i) for i in range(parts)]
+        first_error = None
         for i, f in enumerate(futs):
-            cur.wait_event(f.result())                         # join: `cur` continues (k-NN, the caller's reads) behind every sub-batch
             self._side_used.add(streams[i].cuda_stream)
+            try:
+                cur.wait_event(f.result())                     # join: `cur` continues (k-NN, the caller's reads) behind every sub-batch
+            except Exception as e:                             # a failed enqueue: still join the others (they read x, write emb) before raising
+                cur.wait_stream(streams[i])
+                first_error = first_error or e
+        if first_error is not None:
+            raise first_error
         return emb
 
     def check_status(self):
