@@ -58,9 +58,9 @@ class EffRecognizer:
         self._lanes = queue.LifoQueue()                    # LIFO: a single caller keeps re-using ONE lane (warm pinned buffers / workspace); N callers spread over N lanes
         for _ in range(max(1, int(lanes))):
             self._lanes.put(_Lane(self._eng_net.device))
-        # the pageable -> pinned staging copy is the slowest leg of a call (38.5 MB per 64 crops at one core's memcpy rate): a few
-        # persistent helper threads copy slices side by side (numpy releases the GIL for large copies; torch's own intra-op pool is
-        # far too large on these hosts — see run())
+        # staging="pinned" (rounds 3-5, kept for A/B): the pageable -> pinned staging copy is the slowest leg of such a call (38.5 MB per
+        # 64 crops at one core's memcpy rate): a few persistent helper threads copy slices side by side (numpy releases the GIL for large
+        # copies; torch's own intra-op pool is far too large on these hosts — see run()).  The default, "direct", needs none of it.
         self._copiers = ThreadPoolExecutor(max_workers=max(1, int(copiers)), thread_name_prefix="effocr-stage") if staging == "pinned" else None
         self._slices = max(1, int(slices))
         if staging not in ("direct", "pinned"):
