@@ -61,6 +61,7 @@ class HipEncoder:
         self.split_streams = True
         self._side = None                    # (streams, thread pool) of the split, created on first use
         self._side_used = set()              # side streams whose workspaces may hold an unchecked status word
+        self._stream_locks = {}              # stream handle -> lock held while a forward is enqueued onto that stream
         self._profiling = False
 
     def __del__(self):
@@ -122,18 +123,24 @@ class HipEncoder:
     SPLIT_MIN, SPLIT_MAX = 176, 576
 
     def _split_plan(self, B):
-        if not (self.split_streams and self.arch == "vit_small_patch16_224" and self.precision in _CROP_DTYPE) or self._profiling:
+        if not (self.split_streams and self.arch in ("vit_small_patch16_224", "vit_base_patch16_224") and self.precision in _CROP_DTYPE) or self._profiling:
             return 1
         if isinstance(self.split_streams, int) and not isinstance(self.split_streams, bool):
             return max(1, min(4, self.split_streams)) if B >= 8 else 1        # (forced part count: tools/split_sweep.py)
+        if self.arch == "vit_base_patch16_224":
+            # tools/split_sweep_vitb.py, three interleaved rounds: 256 crops 24.6 -> 25.6 k crops/s as two concurrent sub-batches, 512 crops
+            # 26.1 -> 26.8 k, 1024 crops 26.85 -> 27.3 k (three parts lose): the HBM-bound attention / residual epilogues of one beside the
+            # matrix-bound linears of the other
+            return 2 if B >= 192 else 1
         if not (self.SPLIT_MIN <= B < self.SPLIT_MAX):
             return 1
         return 2 if B < 240 else 3                                            # tools/split_sweep.py (profiles/r06_split_sweep.txt)
 
     def _forward_into(self, x, emb, normalize):
-        """Enqueue one forward on torch's current stream of THIS thread.  The lock covers the workspace table only: the library's
+        """Enqueue one forward on torch's current stream of THIS thread.  The engine lock covers the workspace table only: the library's
         forward is re-entrant while its profiler is not armed (it reads the handle, writes only the caller's buffers), and N caller
-        threads / the split's helper threads enqueue side by side (ctypes releases the GIL); an armed profiler serialises them."""
+        threads / the split's helper threads enqueue side by side on DIFFERENT streams (ctypes releases the GIL); forwards onto the same
+        stream are serialised by that stream's lock, an armed profiler serialises everything."""
         B = x.shape[0]
         need = self.workspace_bytes(B)
         with torch.cuda.device(self.device):
@@ -148,11 +155,17 @@ class HipEncoder:
                     else:
                         ws[:256].copy_(old[:256])                   # ... and SURVIVES a larger workspace: an overflow recorded by an earlier, not yet
                     self._ws[key] = ws                              # checked forward on this stream must still be reported by the next check
+                slock = self._stream_locks.get(key)
+                if slock is None:
+                    slock = self._stream_locks[key] = threading.Lock()
                 serial = self._profiling
                 if serial:
                     self._enqueue(x, emb, normalize, ws)
             if not serial:
-                self._enqueue(x, emb, normalize, ws)
+                # one forward at a time PER STREAM: its kernels share that stream's workspace, and two threads enqueueing onto one stream
+                # (two callers' sub-batches on a shared side stream) would interleave their launch sequences over the same activations
+                with slock:
+                    self._enqueue(x, emb, normalize, ws)
 
     def _enqueue(self, x, emb, normalize, ws):
         x_dtype = _lib.PREC["fp32"] if x.dtype == torch.float32 else _lib.PREC[self.precision]

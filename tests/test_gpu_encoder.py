@@ -367,6 +367,24 @@ def test_stream_split_calls_equal_their_sub_batches(dev, prec, B):
         enc.check_status()                                               # sticky word cleared by the failing check
 
 
+def test_stream_split_vit_base(dev):
+    """ViT-B/16 calls of >= 192 crops run as two concurrent sub-batches (tools/split_sweep_vitb.py): bit-identical to the halves as calls of
+    their own, within the mode's bound of the unsplit call."""
+    from effocr_amd.encoders import HipEncoder
+    arch, B = "vit_base_patch16_224", 200
+    enc = HipEncoder(arch, init_state_dict(arch, seed=3, img_size=224), precision="fp16", device=dev)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
+    assert enc._split_plan(B) == 2 and enc._split_plan(191) == 1
+    got = enc.forward(x, normalize=True)
+    enc.split_streams = False
+    whole = enc.forward(x, normalize=True)
+    subs = torch.cat([enc.forward(x[:100].contiguous(), normalize=True), enc.forward(x[100:].contiguous(), normalize=True)])
+    torch.cuda.synchronize()
+    assert torch.equal(got, subs) and rel_err(got.cpu(), whole.cpu()) <= REL["fp16"]
+    enc.split_streams = True
+    enc.check_status()
+
+
 def test_resnet_and_localizer_do_not_depend_on_the_call_size(dev):
     """resnet18 (split-K convolutions for launches of few tiles) and the YOLOv5s localizer at 1 vs 16 images per call: exact-fp32
     MFMA operands either way, only the order of the split partial sums moves: <= 2e-6 relative."""

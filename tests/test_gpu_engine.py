@@ -354,7 +354,7 @@ def test_stream_split_forward_from_several_caller_threads(dev):
         try:
             st = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st):
-                for _ in range(4):
+                for _ in range(8):                         # (callers' sub-batches meet on the shared side streams: one forward at a time per stream)
                     r = enc.forward(xs[i], normalize=True)
                 st.synchronize()
             out[i] = r
