@@ -231,6 +231,17 @@ def word_end_indices(char_rights, word_lefts):
 
 
 _PREFETCH = None
+_AUX_STREAMS = {}     # (device, role) -> the ONE side stream of that role: the engines keep a workspace per stream they have seen, so
+                      # run_effocr must not hand them a fresh stream per call (torch deals streams from a pool of 32: 32 workspaces)
+
+
+def _aux_stream(dev, role):
+    key = (str(dev), role)
+    st = _AUX_STREAMS.get(key)
+    if st is None:
+        st = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
 
 
 def _prefetcher():
@@ -412,9 +423,9 @@ def run_effocr(coco_images, localizer_engine, recognizer_engine, char_transform,
     per_line = {}                                                            # line index -> (ids, sorted char boxes, word boxes)
     lpc = max(1, int(lines_per_chunk)) if lines_per_chunk else (1 << 30)
     chunks = [(hw, mem[c0:c0 + lpc]) for hw, mem in groups.items() for c0 in range(0, len(mem), lpc)]
-    side = torch.cuda.Stream(device=dev) if len(chunks) > 1 else None
+    side = _aux_stream(dev, "upload") if len(chunks) > 1 else None
     cur = torch.cuda.current_stream(dev)
-    fstream = torch.cuda.Stream(device=dev) if (len(chunks) > 1 and overlap_localizer) else None
+    fstream = _aux_stream(dev, "front") if (len(chunks) > 1 and overlap_localizer) else None
     uploads = {}                                                             # chunk index -> future of (stack, event) / the pair itself
 
     def start_upload(ci, prefetch):
