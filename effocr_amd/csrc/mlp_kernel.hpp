@@ -53,6 +53,9 @@
 #ifndef MLP_DIAG
 #define MLP_DIAG 0                                       // timing ablations, WRONG results, never shipped (tools/ab_build.sh): 1 no hand-over ops,
 #endif                                                   // 2 no W-fragment reads in the steady state, 4 no steady-state DMA, 8 no mid-stage barrier
+#ifndef MLP_PRE_STAGES
+#define MLP_PRE_STAGES 3                                 // ring stages requested in front of the prologue's wait (the rest behind its barrier)
+#endif
 #ifndef MLP_NT
 #define MLP_NT 15                                        // non-temporal: 1 row loads, 2 attention-fragment loads, 4 row stores, 8 second-output stores
 #endif
@@ -63,11 +66,14 @@ namespace {
 // -DMLP_STAMP (tools/ab_build.sh variant, never shipped): wave 0 of every whole-panel workgroup records s_memtime at the panel's
 // milestones + its hardware id; tools/mlp_timeline.py reads the last launch's table through effocr_debug_mlp_stamps.
 #ifdef MLP_STAMP
-constexpr int MLP_STAMP_WGS = 2048, MLP_STAMP_N = 16;
+constexpr int MLP_STAMP_WGS = 2048, MLP_STAMP_N = 20;   // 0-11 milestones, 12 / 13 wait sums, 15 hardware id, 14 / 16 the 100 MHz real-time counter at entry / exit
 __device__ unsigned long long mlp_stamps[MLP_STAMP_WGS * MLP_STAMP_N];
 // branch-free (a branch would split the kernel's scheduling regions): every lane of wave 0..3 stores, the last writer's value stays
+#ifndef MLP_STAMP_PART
+#define MLP_STAMP_PART false                             // true: the split parts stamp instead of the whole panels (small calls)
+#endif
 #define MLP_STAMP_AT(k)                                                                                          \
-  if constexpr (!PARTIAL) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + (k)] = __builtin_amdgcn_s_memtime();
+  if constexpr (PARTIAL == MLP_STAMP_PART) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define MLP_STAMP_AT(k)
 #endif
@@ -138,9 +144,16 @@ template <int D, int H> constexpr int mlp_smem_bytes() { return MLP_RING * MLP_S
 __shared__ __attribute__((aligned(16))) char mlp_smem[mlp_smem_bytes<384, 1536>()];
 
 // body of one workgroup: bid = its index among the workgroups of its kind (whole panels / split parts)
-template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ>
+// PAIR (round 6, calls of 33-83 crops: 64-token panels): the workgroup owns TWO 32-token tiles; the waves 2j, 2j+1 share tile j.  Both run
+// the projection and the LayerNorm of the tile (redundantly: no exchange), then wave p = w & 1 takes hidden tiles 2p, 2p+1 of every
+// chunk in phase A (row blocks 2p, 2p+1 of the ring stage), applies bias + GELU to those 64 hidden features, and multiplies them — k half
+// p of the chunk — into all D outputs in phase B, whose ring stages are re-dealt as [output tile 2g + (w & 1)][k half w >> 1] so that every
+// wave finds its two tiles in every stage: 8 MFMAs per wave and stage in both phases, the SAME weight stream as a 128-token panel (a
+// stage still feeds all four waves).  The two partial sums of a tile meet through LDS (the drained ring) at the end; wave 2j writes.
+template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ, bool PAIR = false>
 __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) {
   static_assert(mlp_smem_bytes<D, H>() <= (int)sizeof(mlp_smem), "mlp: LDS object too small");
+  static_assert(!PAIR || (PROJ && !PARTIAL && NCW == H / 128 && D % 128 == 0), "mlp: the pair form is the whole MLP with the projection in front");
   char* smem = mlp_smem;
   typedef typename Op16<E>::V8 V8;
   constexpr int KC = D / 8;                              // 16-B k chunks per xn row
@@ -168,7 +181,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // PROJ: the projection bias and bias2 are added by ONE extra MFMA per output tile instead of 16 x (read accumulator, add, write
   // back) per lane: A = [32 features x 16 k] with k0 = hi(bias), k1 = lo(bias) (two operand-type values: 16+ mantissa bits),
   // B = [16 k x 32 tokens] with rows k0 = k1 = 1.  ~1 000 of the 3 400 VALU instructions between the projection and phase A(0).
-  constexpr bool BIAS_MM = PROJ && !PARTIAL;
+  constexpr bool BIAS_MM = PROJ;                         // (the split parts too, round 6: 576 accumulator read / add / write instructions per part)
   auto hilo = [](float b) __attribute__((always_inline)) -> uint32_t {
     const E hi = (E)b;
     const E lo = (E)(b - (float)hi);
@@ -176,7 +189,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   };
   MLP_STAMP_AT(0)
 #ifdef MLP_STAMP
-  if (!PARTIAL) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+  if (PARTIAL == MLP_STAMP_PART) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 14] = __builtin_amdgcn_s_memrealtime();
+  if (PARTIAL == MLP_STAMP_PART) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
 #endif
   // First round of workgroups only: spread the start over `stagger` x 32 ticks.  All panels cost the same, so the
   // workgroups of a launch otherwise stay in lock step from the first to the last round: every CU requests its rows at the
@@ -189,24 +203,35 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
   const int panel = (PARTIAL ? a.panel0 : 0) + bid / SPLIT;
   const int c0 = (bid % SPLIT) * NCW;        // first hidden chunk of this workgroup
-  const int64_t rb = (int64_t)panel * 4 + w;             // this wave's 32-row block of x
+  const int pp = PAIR ? (w & 1) : 0;                     // PAIR: which half of a chunk's hidden features this wave carries
+  const int64_t rb = PAIR ? (int64_t)bid * 2 + (w >> 1) : (int64_t)panel * 4 + w;   // this wave's 32-row block of x
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
 
-  // ---- every request of the prologue is in flight before anything waits: parameters (registers, oldest in the in-order VM
-  // queue), the wave's rows, then the first R-1 ring stages; the parameters go to LDS while the rest is still landing.
-  constexpr int NB1 = H / 256, ND = (D + 255) / 256;
-  float pb1[NB1], pdv[7][ND];
-#pragma unroll
-  for (int i = 0; i < NB1; ++i) pb1[i] = a.b1[tid + 256 * i];
+  // ---- every request of the prologue is in flight before anything waits: parameters (oldest in the in-order VM queue), the wave's
+  // rows, then the first R-1 ring stages.  The parameters go STRAIGHT to LDS by LDS-DMA (round 6, second half): through registers the
+  // compiler put s_waitcnt vmcnt(0) in front of their ds_write (an LDS write behind a global_load_lds it knows about) — i.e. the
+  // workgroup sat until its rows, attention fragments and all seven ring stages (112 KB) had landed before the first barrier:
+  // 14-18 k ticks of every panel and every split part (tools/mlp_part_timeline.py).  Now 16-byte units u = 256 j + tid of the LDS
+  // parameter image [b1 | b2 | gamma | beta | bp | gamma_n | beta_n] come from their arrays (16-byte aligned: launch_mlp checks), a lane
+  // without a unit (past the end, absent array) is masked off; nothing of it is visible to the compiler, the wait is counted by hand.
+  constexpr int U1 = H / 4, UD = D / 4, NU = U1 + 6 * UD, NPI = (NU + 255) / 256;
   const bool second = !PARTIAL && a.xn_out != nullptr;
+  {
+    const unsigned sP_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + R * MLP_STAGE);
 #pragma unroll
-  for (int j = 0; j < ND; ++j) {
-    const int n = tid + 256 * j;
-    if (n < D) {
-      pdv[0][j] = a.b2[n]; pdv[1][j] = a.gamma[n]; pdv[2][j] = a.beta[n];
-      if constexpr (PROJ) pdv[3][j] = a.bp[n];
-      if (second) { pdv[4][j] = a.gamma_n[n]; pdv[5][j] = a.beta_n[n]; }
+    for (int j = 0; j < NPI; ++j) {
+      const int u = j * 256 + tid;
+      const int v = u - U1, arr = v / UD, o = v - arr * UD;
+      const float* base = u < U1 ? a.b1 : arr == 0 ? a.b2 : arr == 1 ? a.gamma : arr == 2 ? a.beta : arr == 3 ? (PROJ ? a.bp : nullptr)
+                                        : arr == 4 ? (second ? a.gamma_n : nullptr) : (second ? a.beta_n : nullptr);
+      const char* src = reinterpret_cast<const char*>(base) + (size_t)(u < U1 ? u : o) * 16;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sP_lds + (unsigned)(j * 256 + w * 64) * 16u));
+      if (u < NU && base != nullptr)
+        asm volatile("s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(dst) : "memory", "m0");
     }
   }
   asm volatile("" ::: "memory");
@@ -217,7 +242,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   V8 xf[NXF];                                            // B-operand fragments: attention output (PROJ), then LayerNorm(x)
   auto bias_mm = [&](const float* sb, auto T_) __attribute__((always_inline)) {   // acc2[t] += bias (as stored by the prologue)
     constexpr int t = decltype(T_)::value;
-    const uint32_t wd = reinterpret_cast<const uint32_t*>(sb)[t * 32 + r31];
+    const uint32_t wd = hilo(sb[t * 32 + r31]);            // (hi, lo) operand-type pair of the fp32 bias: 16+ mantissa bits
     const uint32_t one2 = GeluFit<E>::lo ? 0x3f803f80u : 0x3c003c00u;
     const u32x4 af = {half ? 0u : wd, 0u, 0u, 0u}, bf = {half ? 0u : one2, 0u, 0u, 0u};
     acc2[t] = Op16<E>::mfma(__builtin_bit_cast(V8, af), __builtin_bit_cast(V8, bf), acc2[t]);
@@ -283,6 +308,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       else { isA = false; c = NC - 1; }                  // trailing B(NC-1): r counts its stages
     }
     if (isA) return W1 + ((size_t)(4 * (c0 + c) + w) * KC + 8 * r) * 512;
+    if constexpr (PAIR) return W2 + ((size_t)(2 * r + (w & 1)) * (H / 8) + 16 * (c0 + c) + 8 * (w >> 1)) * 512;   // [tile 2r + (w & 1)][k half w >> 1]
     const int g = r >> 1, kh = r & 1;
     return W2 + ((size_t)(4 * g + w) * (H / 8) + 16 * (c0 + c) + 8 * kh) * 512;
   };
@@ -290,16 +316,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // instruction's immediate offset, which the hardware adds on both sides (7 address / M0 instructions per piece before: a
   // quarter of the loop's non-MFMA issue slots).
   const unsigned lane16 = (unsigned)lane * 16u;
-  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {                  // caller guarantees s < NS; i = 0..3 (constant after inlining)
-    const __attribute__((address_space(1))) void* src = (const __attribute__((address_space(1))) void*)(stage_src(s) + lane16);
-    __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(sW + (s & (R - 1)) * MLP_STAGE + w * 4096);
-    switch (i) {
-      case 0: __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0); break;
-      case 1: __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0); break;
-      case 2: __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0); break;
-      default: __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0); break;
-    }
-  };
   // Steady state: the wave's four pieces of a stage in ONE inline-asm statement.  hipcc models __builtin_amdgcn_global_load_lds as an
   // access to BOTH address spaces ("pending flat"): after every such instruction its next LDS wait is s_waitcnt lgkmcnt(0) instead
   // of a counted one, i.e. the W-fragment read issued a moment earlier is drained on the spot — 58 full LDS drains per 192 MFMAs
@@ -335,31 +351,32 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
                  : "=&s"(keep) : "v"(src), "s"(dst), "n"(i * 1024) : "memory");
 #endif
   };
-#pragma unroll
-  for (int s0 = 0; s0 < R - 1; ++s0)
-    if (s0 < NS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) issue_piece(s0, i);
-    }
+  // The ring's first PRE stages go out in front of the wait, the other R-1-PRE behind it.  Why not all of them in front: the compiler
+  // counts only the loads it knows (rows, attention fragments) — with asm DMAs in flight BEHIND those, its vmcnt(n) in front of a
+  // fragment's first use would drain the ring down to n pieces.  So its loads are all consumed ("touched") here, where nothing younger
+  // than stage PRE-1 is in flight, and one explicit wait covers parameters, rows, fragments and the first PRE stages: 16 + 160 + 16 PRE KB
+  // per workgroup instead of 288 KB (the compiler's own vmcnt(0) in front of the parameters' ds_write, rounds 3-6).
+  constexpr int PRE = (MLP_PRE_STAGES < NS ? MLP_PRE_STAGES : NS) < R - 1 ? (MLP_PRE_STAGES < NS ? MLP_PRE_STAGES : NS) : R - 1;
+  sfor<0, PRE>([&](auto S0_) {
+    sfor<0, 4>([&](auto I_) { issue_piece_asm(decltype(S0_)::value, I_); });
+  });
   asm volatile("" ::: "memory");
+  if constexpr (PROJ) {
 #pragma unroll
-  for (int i = 0; i < NB1; ++i) sB1[tid + 256 * i] = pb1[i];
+    for (int t = 0; t < ((MLP_ROWS_LATE && OG > 1) ? 4 : OT); ++t) asm volatile("" : "+a"(acc2[t]));
 #pragma unroll
-  for (int j = 0; j < ND; ++j) {
-    const int n = tid + 256 * j;
-    if (n < D) {
-      sG[n] = pdv[1][j]; sBt[n] = pdv[2][j];
-      if constexpr (BIAS_MM) {                             // biases that enter through an MFMA: (hi, lo) operand-type pair per feature
-        reinterpret_cast<uint32_t*>(sB2)[n] = hilo(pdv[0][j]);
-        reinterpret_cast<uint32_t*>(sBp)[n] = hilo(pdv[3][j]);
-      } else {
-        sB2[n] = pdv[0][j];
-        if constexpr (PROJ) sBp[n] = pdv[3][j];
-      }
-      if (second) { sGn[n] = pdv[4][j]; sBn[n] = pdv[5][j]; }
-    }
+    for (int t = 0; t < NXF; ++t) asm volatile("" : "+v"(xf[t]));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2 * NXF; ++i) asm volatile("" : "+v"(xv[i]));
   }
-  __syncthreads();                                       // parameters visible
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // everybody's parameters and stages 0 .. PRE-1
+  asm volatile("" ::: "memory");
+  sfor<PRE, (R - 1 < NS ? R - 1 : NS)>([&](auto S0_) {
+    sfor<0, 4>([&](auto I_) { issue_piece_asm(decltype(S0_)::value, I_); });
+  });
+  asm volatile("" ::: "memory");
   MLP_STAMP_AT(2)
 
   if constexpr (PARTIAL && !PROJ) {
@@ -439,6 +456,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   }
 
   const int wo = half * 512 + r31 * 16;                  // + (row block i * 8 + 2 * c4) * 512 inside a stage
+  const int wo2 = wo + pp * 8192;                        // PAIR: row blocks 2p, 2p+1 of a stage
   int s = 0;                                             // ring stage counter
   struct WF { V8 w[4]; };
   auto load_w = [&](WF& f, const char* st, int c4) __attribute__((always_inline)) {
@@ -471,10 +489,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #endif
   };
   WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");   // stage 0 (own pieces) ...
-  __builtin_amdgcn_s_barrier();                          // ... and everybody's
-  asm volatile("" ::: "memory");
-  load_w(wf, sW, 0);
+  load_w(wf, sW, 0);                                     // (stage 0 landed in front of the prologue's barrier)
   MLP_STAMP_AT(3)
 
   // ---- chunk hand-over registers: the set holds the 8 B-operand fragments (8 values each) of one chunk, first as
@@ -610,7 +625,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       const f32x2 r = bx[j] * bp[j];
       hs.u[o][j] = pack2<E>(r[0], r[1]);
     }
-    if constexpr (o < 7) bias_octet(cb, std::integral_constant<int, o + 1>{});
+    if constexpr (o < (PAIR ? 3 : 7)) bias_octet(cb, std::integral_constant<int, o + 1>{});
     else bias_octet(cb + 128, std::integral_constant<int, 0>{});        // next chunk's first octet (past the last chunk: a harmless read inside sB1 / sB2)
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -649,6 +664,29 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     ++s;
   };
   constexpr int FAR = 1 << 20;                           // "plenty of stages follow"
+  // PAIR: a stage is 8 MFMAs of this wave, n = (k16 step c4 = n >> 1, row block 2p + (n & 1)); the four fragment registers roll with a
+  // distance of four MFMAs as above (fragment n + 4: of this stage up to n = 3, of the next one behind the mid-stage barrier at n = 4).
+  auto load_w_pair = [&](WF& f, const char* st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) f.w[n] = *reinterpret_cast<const V8*>(st + wo2 + ((n & 1) * 8 + 2 * (n >> 1)) * 512);
+  };
+  auto ring_stage_pair = [&](auto REM, auto&& mfma1) __attribute__((always_inline)) {
+    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1;
+    int so = (s & (R - 1)) * MLP_STAGE, son = ((s + 1) & (R - 1)) * MLP_STAGE;
+    asm volatile("" : "+s"(so), "+s"(son));
+    const char* st = sW + so;
+    const char* stn = sW + son;
+    sfor<0, 8>([&](auto N_) {
+      constexpr int n = decltype(N_)::value, c4 = n >> 1, i = n & 1;
+      if constexpr (n == 4) stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
+      mfma1(std::integral_constant<int, c4>{}, std::integral_constant<int, i>{}, wf.w[n & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (n < 4) wf.w[n & 3] = *reinterpret_cast<const V8*>(st + wo2 + (i * 8 + 2 * (c4 + 2)) * 512);
+      else if constexpr (next) wf.w[n & 3] = *reinterpret_cast<const V8*>(stn + wo2 + (i * 8 + 2 * (c4 - 2)) * 512);
+      if constexpr (more && n >= 4) issue_piece_asm(s + R - 1, std::integral_constant<int, n - 4>{});   // behind the barrier: slot of stage s-1 is free
+    });
+    ++s;
+  };
 
   // ---- phase A of a chunk (SA stages x 4 k16 steps x 4 tiles) / phase B ((group g, k half kh) stages; B-operand = fragment 4 kh + c4 of `hs`),
   // each hosting ops [K0, K1) of the chunk with bias base cb on set hd in the issue slots behind its MFMAs
@@ -656,6 +694,15 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     sfor<0, SA>([&](auto KS) {
       constexpr int ks = decltype(KS)::value;
       constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SA - 1 - ks);
+      if constexpr (PAIR) {
+        ring_stage_pair(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+          constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+          if constexpr (ks == 0 && c4 == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc1[i] = Op16<E>::mfma(wfrag, xf[0], z);
+          } else acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
+        });
+      } else
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
         if constexpr (ks == 0 && c4 == 0) {
@@ -676,6 +723,16 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       constexpr int sb = decltype(SBI)::value;
       constexpr int g = sb >> 1, kh = sb & 1;
       constexpr int rem = decltype(AFTER)::value >= FAR ? FAR : decltype(AFTER)::value + (SB - 1 - sb);
+      if constexpr (PAIR) {                                // stage sb = output tiles 2 sb, 2 sb + 1 x this wave's k half (its own four fragments)
+        static_assert(!PAIR || MLP_GELU_BURST == 2, "mlp: the pair form hands over in fused bursts");
+        ring_stage_pair(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+          constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+          const V8 hb = __builtin_bit_cast(V8, hs.u[c4]);
+          acc2[2 * sb + i] = Op16<E>::mfma(wfrag, hb, acc2[2 * sb + i]);
+          constexpr int n = sb * 8 + c4 * 2 + i, per = SB * 8 / 4;
+          if constexpr (decltype(K1_)::value > decltype(K0_)::value && n % per == per / 2 && !(MLP_DIAG & 1)) fused_burst(*hd, cb, std::integral_constant<int, n / per>{});
+        });
+      } else
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
         const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
@@ -710,25 +767,17 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       });
     });
     MLP_STAMP_AT(4)
-    if constexpr (BIAS_MM) sfor<0, OT>([&](auto T_) { bias_mm(sBp, T_); });
-    else sfor<0, OT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sBp + t * 32 + 8 * q + 4 * half);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += bv[e];
-      }
-    });
+    sfor<0, OT>([&](auto T_) { bias_mm(sBp, T_); });
     layernorm_to_xf();
-    if constexpr (BIAS_MM) sfor<0, OT>([&](auto T_) { bias_mm(sB2, T_); });   // (after the statistics: the LayerNorm is of the row without bias2)
-    load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
+    if constexpr (!PARTIAL) sfor<0, OT>([&](auto T_) { bias_mm(sB2, T_); });   // (after the statistics: the LayerNorm is of the row without bias2; split parts: the reduction adds it)
+    if constexpr (PAIR) load_w_pair(wf, sW + (s & (R - 1)) * MLP_STAGE);
+    else load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)                          // (not before: the 64 registers are free for the compiler up to here)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
-    if constexpr (PARTIAL) {                             // straight-line (a branch over 192 accumulators makes the compiler spill them)
-      const float kf = c0 == 0 ? 1.f : 0.f;
+    if constexpr (PARTIAL || PAIR) {                     // straight-line (a branch over 192 accumulators makes the compiler spill them)
+      const float kf = (PAIR ? pp == 0 : c0 == 0) ? 1.f : 0.f;   // (PAIR: wave 2j keeps the row, wave 2j+1 starts its partial sums at zero)
 #pragma unroll
       for (int t = 0; t < OT; ++t)
 #pragma unroll
@@ -750,14 +799,15 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   typedef std::integral_constant<int, 0> K0_; typedef std::integral_constant<int, CO::NPARK> KP_;
   typedef std::integral_constant<int, KB> KB_; typedef std::integral_constant<int, CO::N> KN_;
   HSet S2[2];
-  const int cb0 = c0 * 128;
+  const int cb0 = c0 * 128 + (PAIR ? 64 * pp : 0);        // (PAIR: the wave's two hidden tiles of a chunk)
+  constexpr int NOCT = PAIR ? 4 : 8;                     // octets (B-operand fragments) per chunk and wave
   if constexpr (NC == 2) {
     // Two chunks per workgroup (round 6: the 6-way split of calls of <= 27 crops — 12 chunks over six workgroups per panel):
     //   A(0) | hand-over(0) | A(1) | B(0) + hand-over(1) | B(1)        (ring stream A(0) | A(1) | B(0) | B(1), as stage_src deals it)
     phase_a_h(Far{}, nullptr, 0, K0_{}, K0_{});                             // A(0): 3 phases = 18 stages follow
     if constexpr (!(MLP_DIAG & 1)) {
       bias_octet(cb0, std::integral_constant<int, 0>{});
-      sfor<0, 8>([&](auto O_) { fused_burst(S2[0], cb0, O_); });
+      sfor<0, NOCT>([&](auto O_) { fused_burst(S2[0], cb0, O_); });
     }
     phase_a_h(std::integral_constant<int, 2 * SB>{}, nullptr, 0, K0_{}, K0_{});                                   // A(1)
     phase_b_h(std::integral_constant<int, SB>{}, S2[0], &S2[1], cb0 + 128, K0_{}, KB_{});                        // B(0) + hand-over(1)
@@ -767,7 +817,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   if constexpr (MLP_GELU_BURST == 2) {
     if constexpr (!(MLP_DIAG & 1)) {
       bias_octet(cb0, std::integral_constant<int, 0>{});
-      sfor<0, 8>([&](auto O_) { fused_burst(S2[0], cb0, O_); });            // hand-over(0): the only one without MFMAs around it
+      sfor<0, NOCT>([&](auto O_) { fused_burst(S2[0], cb0, O_); });         // hand-over(0): the only one without MFMAs around it
     }
   } else if constexpr (!(MLP_DIAG & 1))
   sfor<0, CO::NPARK>([&](auto K_) { gop(S2[0], cb0, K_); });              // park(0)
@@ -803,6 +853,36 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   int hf = half;
   asm volatile("" : "+v"(hf));                           // opaque: else the LayerNorm's 48 chunk offsets are kept (spilled) across the main loop for this
   auto cq = [&](int t, int q) __attribute__((always_inline)) { return 8 * t + 4 * (q >> 1) + 2 * hf + (q & 1); };
+  if constexpr (PAIR) {
+    // The two partial sums of a token tile meet in LDS: the ring is drained (every stage consumed), wave 2j+1 parks its 16 OT values per
+    // lane as [tile][quad][lane] x 16 B (48 KB per pair at D = 384), everybody adds (wave 2j+1 its own copy: straight-line, its result is dropped).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // nobody still reads the last stages
+    asm volatile("" ::: "memory");
+    char* px = smem + (w >> 1) * (OT * 4 * 1024) + lane * 16;
+    if (pp == 1) {
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(px + (t * 4 + q) * 1024) = o;
+        }
+      });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(px + (t * 4 + q) * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += v[e];
+      }
+    });
+  }
   if constexpr (PARTIAL) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
     const int64_t rbl = rb - (int64_t)a.panel0 * 4;
@@ -815,7 +895,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
-  } else if (rb * 32 + r31 < a.M) {
+  } else if ((!PAIR || pp == 0) && rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
     float sm = 0.f;
     sfor<0, OT>([&](auto T_) {
@@ -864,10 +944,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   }
   MLP_STAMP_AT(10)
 #ifdef MLP_STAMP
-  if constexpr (!PARTIAL) { mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 12] = vm_wait; mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 13] = bar_wait; }
+  if constexpr (PARTIAL == MLP_STAMP_PART) { mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 12] = vm_wait; mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 13] = bar_wait; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   MLP_STAMP_AT(11)
+#ifdef MLP_STAMP
+  if (PARTIAL == MLP_STAMP_PART) mlp_stamps[(bid & (MLP_STAMP_WGS - 1)) * MLP_STAMP_N + 16] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // One launch for the whole panels (workgroups [0, main_wgs)) AND the split parts of the tail panels (TNCW hidden chunks each; TNCW = 0:
@@ -880,6 +963,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     if ((int)blockIdx.x < a.main_wgs) mlp_fused_body<E, D, H, H / 128, false, PROJ>(a, (int)blockIdx.x);
     else mlp_fused_body<E, D, H, TNCW, true, PROJ>(a, (int)blockIdx.x - a.main_wgs);
   }
+}
+
+// 64-token panels, wave pairs (PAIR above): one workgroup per two row blocks
+template <typename E, int D, int H>
+__global__ __launch_bounds__(256, 1) void mlp_pair_kernel(MlpArgs a) {
+  mlp_fused_body<E, D, H, H / 128, false, true, true>(a, (int)blockIdx.x);
 }
 
 // x[row block rb0 + i] = (add_x ? x : 0) + bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
@@ -908,6 +997,8 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* 
 template <typename E, bool PROJ>
 int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   MlpArgs a = a_in;
+  for (const void* q : {(const void*)a.b1, (const void*)a.b2, (const void*)a.gamma, (const void*)a.beta, (const void*)a.bp, (const void*)a.gamma_n, (const void*)a.beta_n})
+    if ((reinterpret_cast<uintptr_t>(q) & 15) != 0) return fail(EFFOCR_EINVAL, "mlp_fused: bias / LayerNorm parameter arrays must be 16-byte aligned (they reach LDS by 16-byte DMA)");
   const int npanels = (a.M + MLP_PT - 1) / MLP_PT;
   if (a.D == 128 && a.H == 512) {
     a.panel0 = 0; a.main_wgs = npanels; a.stagger_wgs = 0;
@@ -918,6 +1009,18 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   // One workgroup per CU: the panels of the last, partially filled round are cut along the hidden dimension into
   // 4 (or 2) workgroups each, which write partial outputs to the caller's scratch; a small kernel reduces them.
   const int slots = device_cus();
+  if constexpr (PROJ) {
+    // Calls of 34-83 crops (more 128-token panels than a fifth of the CUs, 64-token panels within one round): 64-token panels on wave
+    // pairs — no partial sums in HBM, no reduction launch.  tools/pair_sweep.py, same box: 40 / 48 / 64 / 80 crops 0.90 / 0.90 / 0.90 / 0.91 of the
+    // split parts' call time, 32 crops 0.99, 24 crops 1.03 (there the 4- / 6-way parts win: a sixth of the weight stream per CU).
+    const int np64 = (a.M + 63) / 64;
+    const bool fits = np64 <= slots && a.rows_alloc >= np64 * 64;
+    if (fits && (a.pair > 0 || (a.pair == 0 && !a.no_tail_split && npanels * 5 > slots))) {
+      a.panel0 = 0; a.main_wgs = np64; a.stagger_wgs = 0; a.tail_rb = 0;
+      hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536>), dim3((unsigned)np64), dim3(256), 0, s, a);
+      return check_launch("mlp_pair");
+    }
+  }
   const int tail = a.no_tail_split ? 0 : npanels % slots;
   int split = 1;
   for (const int cand : {6, 4, 2}) {                     // 6: calls of <= 27 crops — six two-chunk parts per panel (16 crops: 0.89 -> 0.8 ms)

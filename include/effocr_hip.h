@@ -132,6 +132,9 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *   "cls_only_last" [1] last transformer block: attn.proj + MLP only on the class-token row of every image — the only row that
  *                 reaches the embedding (global_pool = 'token'); proj / LayerNorm / MLP act per row, so the result is the same
  *                 (0: all tokens, A/B switch)
+ *   "split6"      [1] fused MLP: calls of <= 27 crops cut their panels 6-way over the hidden dimension (0: 4-way)
+ *   "mlp_pair"    [0] fused proj+MLP: 64-token panels whose wave pairs split a chunk's hidden features (no partial sums in HBM, no
+ *                 reduction launch): 0 = for calls of 34..83 crops, 1 = whenever the 64-token panels fit one round of CUs, -1 = never
  *   "mlp_stagger" [3500] fused MLP kernel: the first round of workgroups starts spread over 32 x this many clock ticks, so
  *                 that the CUs do not request / store their rows all at the same moment (0 = off)
  *   "mlp_stagger_min_rounds" [2] ... for launches of at least this many rounds of CUs (512-crop calls: +7.7 %; no effect below two)
@@ -361,7 +364,9 @@ int effocr_op_linear_blocked(int precision, int epilogue, const void* x_blk_dev,
  * position p holds source row 8*(2*(r>>3) + hh) + (r&7) with hh = (p>>2)&1, r = (p&3) + 4*(p>>3)  ("P32": with it the
  * MFMA accumulators of a lane are the very fp32 chunks its LayerNorm read, so the kernel starts fc2's accumulators at
  * x + bias and never re-reads the residual).  b2_perm: fc2 bias P32-permuted; b2: the same bias unpermuted (tail reduction).
- * (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m.
+ * (d, h) in {(384,1536), (128,512)}; rows_alloc % 32 == 0, >= m.  The fp32 parameter arrays (gamma, beta, b1, b2_perm and, in the
+ * variants below, gamma_next, beta_next, bp_perm) must be 16-byte aligned — they reach the workgroup's LDS by 16-byte DMA
+ * (EFFOCR_EINVAL otherwise).
  * scratch_dev (optional, may be NULL): device scratch of scratch_bytes; with >= 64 MiB the 128-row panels of the last,
  * partially filled round of CUs are split over the hidden dimension and reduced in a fixed order (same result
  * bit for bit run to run; differs from the unsplit path only by fp32 summation order). */

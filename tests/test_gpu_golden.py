@@ -13,7 +13,10 @@ from oracle.encoders_ref import encoder_forward, l2_normalize
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
-REL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 8e-3}   # default dispatch, measured 4.7 ... 7.6e-3 (bf16)
+REL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 8.5e-3}   # default dispatch, max norm over the fixture's 4 crops.  bf16: 6.5e-3 (whole panels) ... 7.9e-3 (6-way
+# parts, round-6 first half) ... 8.0e-3 (parts with the projection bias through the MFMA, second half) — kernel selections that differ only in the
+# order of fp32 partial sums; the per-row relative L2 error is the stable statement: 5.66-5.90e-3 for all of them (tools/_goldchk.py), asserted below
+ROW_L2 = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 6.5e-3}
 
 
 def load(name):
@@ -30,6 +33,8 @@ def test_encoder_matches_golden(dev, arch, prec):
     emb = enc.forward(torch.from_numpy(g["x"].astype(np.float32)).to(dev)).cpu().numpy()
     tol = 1e-5 if arch == "resnet18" else REL[prec]          # resnet18 runs exact fp32 MFMA in every mode
     assert np.abs(emb - g["emb"]).max() <= tol * np.abs(g["emb"]).max()
+    if arch != "resnet18":
+        assert (np.linalg.norm(emb - g["emb"], axis=1) / np.linalg.norm(g["emb"], axis=1)).max() <= ROW_L2[prec]
 
 
 @pytest.mark.parametrize("arch", ["vit_small_patch16_224", "vit_base_patch16_224"])

@@ -11,21 +11,24 @@ from effocr_amd.encoders import HipEncoder
 from effocr_amd.weights import init_state_dict
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+PAIR = "--pair" in sys.argv                    # 64-token wave-pair panels (calls of <= 83 crops): every workgroup of the launch stamps
 dev = torch.device("cuda:0")
 enc = HipEncoder("vit_small_patch16_224", init_state_dict("vit_small_patch16_224", seed=0, img_size=224), img_size=224, precision="bf16", device=dev)
+if PAIR:
+    enc.set_option("mlp_pair", 1); enc.set_option("cls_only_last", 0)
 x = torch.randn(B, 3, 224, 224, device=dev)
 for _ in range(3):
     enc.forward(x, normalize=True)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["EFFOCR_HIP_LIB"])
-NW, NS = 2048, 16
+NW, NS = 2048, 20
 buf = (ctypes.c_ulonglong * (NW * NS))()
 rc = lib.effocr_debug_mlp_stamps(buf, NW * NS)
 assert rc == 0, rc
 t = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NS).astype(np.int64)
 npan = (B * 197 + 127) // 128
 main = npan - npan % 256 if (npan % 256) * 2 <= 256 else npan
-t = t[8:main]                                  # (the CLS-only launch of the last block rewrote the first 8 rows)
+t = t[:(B * 197 + 63) // 64] if PAIR else t[8:main]   # (the CLS-only launch of the last block rewrote the first 8 rows)
 names = ["stagger wait", "requests issued + params to regs", "params -> LDS + barrier", "rows/attn/stage 0 landed", "projection MFMAs", "bias + LayerNorm",
          "A(0) + park", "rolled loop", "last A/B + gelu + B", "x stores issued", "second output", "stores acked"]
 tot = t[:, 11] - t[:, 1]
