@@ -754,6 +754,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     // reduction then adds no residual).
     sfor<0, OG>([&](auto G_) {
       constexpr int g = decltype(G_)::value;
+      if constexpr (g > 0 && g < 3) { MLP_STAMP_AT(16 + g) }   // (slots 17, 18: start of output groups 1, 2)
       if constexpr (MLP_ROWS_LATE && g + 1 < OG) {         // the next group's rows: requested now, landed under this group's MFMAs
         rows_to_acc(std::integral_constant<int, 4 * (g + 1)>{}, std::integral_constant<int, 4 * (g + 2)>{});
         __builtin_amdgcn_sched_barrier(0);

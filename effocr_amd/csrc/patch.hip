@@ -216,8 +216,16 @@ __global__ __launch_bounds__(256, 1) void patch_embed_kernel(PatchArgs a) {
 template <typename E, typename X>
 int launch_patch(const PatchArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.B * a.P;
+  const int64_t panels = (total + 127) / 128;
+  // Small calls (round 6): a 384-wide panel streams the whole 590 KB weight into ONE CU (42 us for 1 .. 16 crops, 2 .. 25 workgroups);
+  // as three 128-wide slices — same arithmetic per output, the pixels of a panel are re-read out of the L2 — a third of the weight
+  // stream and of the MFMAs per CU, on three times the CUs, while the slices still fit one round
+  if (a.D == 384 && panels * 3 <= device_cus()) {
+    hipLaunchKernelGGL((patch_embed_kernel<E, X, 128>), dim3((unsigned)(panels * 3)), dim3(256), 0, s, a);
+    return check_launch("patch_embed_fused");
+  }
   const int nsl = a.D > 384 ? a.D / 384 : 1;              // 384-wide output slices of a panel (ViT-B: 2)
-  const dim3 grid((unsigned)((total + 127) / 128 * nsl)), blk(256);
+  const dim3 grid((unsigned)(panels * nsl)), blk(256);
   switch (a.D) {
     case 128: hipLaunchKernelGGL((patch_embed_kernel<E, X, 128>), grid, blk, 0, s, a); break;
     case 256: hipLaunchKernelGGL((patch_embed_kernel<E, X, 256>), grid, blk, 0, s, a); break;

@@ -65,6 +65,16 @@ __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __r
   const char* xb = reinterpret_cast<const char*>(x) + rb * (D / 4) * 512 + tl * 16;
   const int c0 = wv * (D / 16) + part;
   f32x4 v[NQ];
+  // (REDUCE — the launch between two kernels of a small call: the norm's weight / bias requested with the first loads instead of behind the
+  // two statistics barriers, one exposed memory round trip less)
+  f32x4 gmv[REDUCE ? NQ : 1], btv[REDUCE ? NQ : 1];
+  if constexpr (REDUCE) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      gmv[i] = *reinterpret_cast<const f32x4*>(gamma + (c0 + 2 * i) * 4);
+      btv[i] = *reinterpret_cast<const f32x4*>(beta + (c0 + 2 * i) * 4);
+    }
+  }
   if constexpr (REDUCE) {
     const int64_t per_rb = (int64_t)(D / 4) * 32;
     const bool live = rb * 32 + tl < rows;
@@ -125,8 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_blocked_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int c = c0 + 2 * i;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
-    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c * 4);
+    const f32x4 gm = REDUCE ? gmv[REDUCE ? i : 0] : *reinterpret_cast<const f32x4*>(gamma + c * 4);
+    const f32x4 bt = REDUCE ? btv[REDUCE ? i : 0] : *reinterpret_cast<const f32x4*>(beta + c * 4);
     const u32x2 o = pack4<TO>((v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1],
                               (v[i][2] - mean) * rstd * gm[2] + bt[2], (v[i][3] - mean) * rstd * gm[3] + bt[3]);
     if (LN_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(ob + (size_t)(c >> 1) * 512));

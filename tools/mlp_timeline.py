@@ -36,6 +36,7 @@ print(f"{len(t)} whole panels; ticks per panel (after the start spread) mean {to
 for i in range(2, 12):
     seg = t[:, i] - t[:, i - 1]
     print(f"  {names[i]:42s} {seg.mean():9.0f}  {100 * seg.mean() / tot.mean():5.1f} %   (p10 {np.percentile(seg, 10):.0f}, p90 {np.percentile(seg, 90):.0f})")
+print(f"  projection by output group (stamps 17, 18): group 0 {(t[:, 17] - t[:, 3]).mean():.0f}, group 1 {(t[:, 18] - t[:, 17]).mean():.0f}, group 2 {(t[:, 4] - t[:, 18]).mean():.0f} ticks (96 MFMAs = 3 072 each)")
 print(f"  mid-stage waits of one wave, sum over the panel's {12 * 12 + 18} stages: vmcnt {t[:, 12].mean():.0f} ticks, barrier {t[:, 13].mean():.0f} ticks")
 xcc = (t[:, 15] >> 32) & 0xf                     # s_memtime is per XCD: concurrency inside each XCD (32 CUs), then averaged
 cm, mx, fr = [], [], []
