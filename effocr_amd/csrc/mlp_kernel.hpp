@@ -150,8 +150,13 @@ __shared__ __attribute__((aligned(16))) char mlp_smem[mlp_smem_bytes<384, 1536>(
 // p of the chunk — into all D outputs in phase B, whose ring stages are re-dealt as [output tile 2g + (w & 1)][k half w >> 1] so that every
 // wave finds its two tiles in every stage: 8 MFMAs per wave and stage in both phases, the SAME weight stream as a 128-token panel (a
 // stage still feeds all four waves).  The two partial sums of a tile meet through LDS (the drained ring) at the end; wave 2j writes.
-template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ, bool PAIR = false>
+// KEEP (PROJ forms that share a token tile between several accumulations: the split parts of a panel, the two waves of a PAIR): true =
+// this one keeps the new row x + bp + a.Wp^T in its fc2 accumulators (part 0 / wave 2j), false = its partial sums start at zero — the
+// first phase-B MFMA of every output tile takes the instruction's zero operand, so the row's 192 registers are dead behind the LayerNorm
+// (before: 576 read / multiply-by-0-or-1 / write instructions per part next to 21-46 spilled registers reloaded inside the chunk loop).
+template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ, bool PAIR = false, bool KEEP = true>
 __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) {
+  static_assert(KEEP || (PROJ && (PARTIAL || PAIR)), "mlp: KEEP = false is a split part / the second wave of a pair behind the projection");
   static_assert(mlp_smem_bytes<D, H>() <= (int)sizeof(mlp_smem), "mlp: LDS object too small");
   static_assert(!PAIR || (PROJ && !PARTIAL && NCW == H / 128 && D % 128 == 0), "mlp: the pair form is the whole MLP with the projection in front");
   char* smem = mlp_smem;
@@ -203,7 +208,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
   const int panel = (PARTIAL ? a.panel0 : 0) + bid / SPLIT;
   const int c0 = (bid % SPLIT) * NCW;        // first hidden chunk of this workgroup
-  const int pp = PAIR ? (w & 1) : 0;                     // PAIR: which half of a chunk's hidden features this wave carries
+  const int pp = PAIR ? (KEEP ? 0 : 1) : 0;              // PAIR: which half of a chunk's hidden features this wave carries (wave 2j: the KEEP body)
   const int64_t rb = PAIR ? (int64_t)bid * 2 + (w >> 1) : (int64_t)panel * 4 + w;   // this wave's 32-row block of x
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
@@ -718,7 +723,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       }, std::false_type{});
     });
   };
-  auto phase_b_h = [&](auto AFTER, const HSet& hs, HSet* hd, const int cb, auto K0_, auto K1_) __attribute__((always_inline)) {
+  auto phase_b_h = [&](auto AFTER, const HSet& hs, HSet* hd, const int cb, auto K0_, auto K1_, auto FIRSTB) __attribute__((always_inline)) {
+    constexpr bool zc = decltype(FIRSTB)::value && !KEEP;     // B(0) of a body that does not keep the row: every tile's first MFMA starts from zero
     sfor<0, SB>([&](auto SBI) {
       constexpr int sb = decltype(SBI)::value;
       constexpr int g = sb >> 1, kh = sb & 1;
@@ -728,6 +734,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         ring_stage_pair(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
           constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
           const V8 hb = __builtin_bit_cast(V8, hs.u[c4]);
+          if constexpr (zc && c4 == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc2[2 * sb + i] = Op16<E>::mfma(wfrag, hb, z);
+          } else
           acc2[2 * sb + i] = Op16<E>::mfma(wfrag, hb, acc2[2 * sb + i]);
           constexpr int n = sb * 8 + c4 * 2 + i, per = SB * 8 / 4;
           if constexpr (decltype(K1_)::value > decltype(K0_)::value && n % per == per / 2 && !(MLP_DIAG & 1)) fused_burst(*hd, cb, std::integral_constant<int, n / per>{});
@@ -736,6 +746,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
         const V8 hb = __builtin_bit_cast(V8, hs.u[4 * kh + c4]);
+        if constexpr (zc && kh == 0 && c4 == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, z);
+        } else
         acc2[4 * g + i] = Op16<E>::mfma(wfrag, hb, acc2[4 * g + i]);
         if constexpr (MLP_GELU_BURST == 2) {
           constexpr int n = sb * 16 + c4 * 4 + i, per = SB * 16 / 8;
@@ -770,20 +784,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     MLP_STAMP_AT(4)
     sfor<0, OT>([&](auto T_) { bias_mm(sBp, T_); });
     layernorm_to_xf();
-    if constexpr (!PARTIAL) sfor<0, OT>([&](auto T_) { bias_mm(sB2, T_); });   // (after the statistics: the LayerNorm is of the row without bias2; split parts: the reduction adds it)
+    if constexpr (!PARTIAL && KEEP) sfor<0, OT>([&](auto T_) { bias_mm(sB2, T_); });   // (after the statistics: the LayerNorm is of the row without bias2; split parts: the reduction adds it)
     if constexpr (PAIR) load_w_pair(wf, sW + (s & (R - 1)) * MLP_STAGE);
     else load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)                          // (not before: the 64 registers are free for the compiler up to here)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
-    if constexpr (PARTIAL || PAIR) {                     // straight-line (a branch over 192 accumulators makes the compiler spill them)
-      const float kf = (PAIR ? pp == 0 : c0 == 0) ? 1.f : 0.f;   // (PAIR: wave 2j keeps the row, wave 2j+1 starts its partial sums at zero)
-#pragma unroll
-      for (int t = 0; t < OT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[t][r] *= kf;
-    }
   }
 
   MLP_STAMP_AT(5)
@@ -811,8 +818,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       sfor<0, NOCT>([&](auto O_) { fused_burst(S2[0], cb0, O_); });
     }
     phase_a_h(std::integral_constant<int, 2 * SB>{}, nullptr, 0, K0_{}, K0_{});                                   // A(1)
-    phase_b_h(std::integral_constant<int, SB>{}, S2[0], &S2[1], cb0 + 128, K0_{}, KB_{});                        // B(0) + hand-over(1)
-    phase_b_h(std::integral_constant<int, 0>{}, S2[1], nullptr, 0, K0_{}, K0_{});                                 // B(1)
+    phase_b_h(std::integral_constant<int, SB>{}, S2[0], &S2[1], cb0 + 128, K0_{}, KB_{}, std::true_type{});      // B(0) + hand-over(1)
+    phase_b_h(std::integral_constant<int, 0>{}, S2[1], nullptr, 0, K0_{}, K0_{}, std::false_type{});              // B(1)
   } else {
   phase_a_h(Far{}, nullptr, 0, K0_{}, K0_{});                               // A(0)
   if constexpr (MLP_GELU_BURST == 2) {
@@ -824,29 +831,42 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   sfor<0, CO::NPARK>([&](auto K_) { gop(S2[0], cb0, K_); });              // park(0)
   MLP_STAMP_AT(6)
   phase_a_h(Far{}, &S2[0], cb0, KP_{}, KN_{});                            // A(1) + gelu(0)
-  auto pair_step = [&](auto PAR, auto AFTER_A, const int c) __attribute__((always_inline)) {   // chunk c, c & 1 == PAR
+  auto pair_step = [&](auto PAR, auto AFTER_A, const int c, auto FIRSTB) __attribute__((always_inline)) {   // chunk c, c & 1 == PAR; FIRSTB: c == 1 (its phase B is B(0))
     constexpr int par = decltype(PAR)::value;
     constexpr int after_b = decltype(AFTER_A)::value >= FAR ? FAR : decltype(AFTER_A)::value + SA;
-    phase_b_h(std::integral_constant<int, after_b>{}, S2[par ^ 1], &S2[par], cb0 + c * 128, K0_{}, KB_{});   // B(c-1) + ops(c)[0, KB)
+    phase_b_h(std::integral_constant<int, after_b>{}, S2[par ^ 1], &S2[par], cb0 + c * 128, K0_{}, KB_{}, FIRSTB);   // B(c-1) + ops(c)[0, KB)
     phase_a_h(AFTER_A, &S2[par], cb0 + c * 128, KB_{}, KN_{});                                                // A(c+1) + ops(c)[KB, N)
   };
   {
     int c = 1;                                           // chunks 1 .. NC-3 rolled in pairs (static set roles), chunk NC-2 peeled (static stage counts)
+    if constexpr (KEEP) {
 #pragma unroll 1
-    for (; c + 1 <= NC - 3; c += 2) {
-      pair_step(std::integral_constant<int, 1>{}, Far{}, c);
-      pair_step(std::integral_constant<int, 0>{}, Far{}, c + 1);
+      for (; c + 1 <= NC - 3; c += 2) {
+        pair_step(std::integral_constant<int, 1>{}, Far{}, c, std::false_type{});
+        pair_step(std::integral_constant<int, 0>{}, Far{}, c + 1, std::false_type{});
+      }
+      if constexpr ((NC - 3) % 2 == 1) pair_step(std::integral_constant<int, 1>{}, Far{}, NC - 3, std::false_type{});
+    } else {                                             // chunk 1 peeled too: its phase B is B(0), whose MFMAs start the accumulators from zero
+      if constexpr (NC - 3 >= 1) {
+        pair_step(std::integral_constant<int, 1>{}, Far{}, 1, std::true_type{});
+        c = 2;
+#pragma unroll 1
+        for (; c + 1 <= NC - 3; c += 2) {
+          pair_step(std::integral_constant<int, 0>{}, Far{}, c, std::false_type{});
+          pair_step(std::integral_constant<int, 1>{}, Far{}, c + 1, std::false_type{});
+        }
+        if constexpr ((NC - 3) >= 2 && (NC - 4) % 2 == 1) pair_step(std::integral_constant<int, 0>{}, Far{}, NC - 3, std::false_type{});
+      }
     }
-    if constexpr ((NC - 3) % 2 == 1) pair_step(std::integral_constant<int, 1>{}, Far{}, NC - 3);
   }
   MLP_STAMP_AT(7)
-  pair_step(std::integral_constant<int, (NC - 2) & 1>{}, std::integral_constant<int, 2 * SB>{}, NC - 2);      // B(NC-3) | A(NC-1)
-  phase_b_h(std::integral_constant<int, SB>{}, S2[(NC - 2) & 1], &S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K0_{}, KB_{});   // B(NC-2)
+  pair_step(std::integral_constant<int, (NC - 2) & 1>{}, std::integral_constant<int, 2 * SB>{}, NC - 2, std::integral_constant<bool, NC == 3>{});      // B(NC-3) | A(NC-1)
+  phase_b_h(std::integral_constant<int, SB>{}, S2[(NC - 2) & 1], &S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K0_{}, KB_{}, std::false_type{});   // B(NC-2)
   if constexpr (MLP_GELU_BURST == 2) {
   } else if constexpr (MLP_GELU_BURST == 1 && !(MLP_DIAG & 1)) sfor<0, 8>([&](auto O_) { gelu_burst(S2[(NC - 1) & 1], O_); });
   else if constexpr (!(MLP_DIAG & 1))
   sfor<KB, CO::N>([&](auto K_) { gop(S2[(NC - 1) & 1], cb0 + (NC - 1) * 128, K_); });
-  phase_b_h(std::integral_constant<int, 0>{}, S2[(NC - 1) & 1], nullptr, 0, K0_{}, K0_{});                     // B(NC-1)
+  phase_b_h(std::integral_constant<int, 0>{}, S2[(NC - 1) & 1], nullptr, 0, K0_{}, K0_{}, std::false_type{});  // B(NC-1)
   }
   MLP_STAMP_AT(8)
   // ---- epilogue.  lane = token r31 of row block rb; registers 4q..4q+3 of tile t = fp32 chunk cq(t, q) of the row (W2's
@@ -962,14 +982,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
     mlp_fused_body<E, D, H, H / 128, false, PROJ>(a, (int)blockIdx.x);
   } else {
     if ((int)blockIdx.x < a.main_wgs) mlp_fused_body<E, D, H, H / 128, false, PROJ>(a, (int)blockIdx.x);
-    else mlp_fused_body<E, D, H, TNCW, true, PROJ>(a, (int)blockIdx.x - a.main_wgs);
+    else {
+      const int b = (int)blockIdx.x - a.main_wgs;
+      if constexpr (PROJ) {                              // part 0 of a panel keeps the new row, the others start at zero (KEEP)
+        if (b % ((H / 128) / TNCW) == 0) mlp_fused_body<E, D, H, TNCW, true, true, false, true>(a, b);
+        else mlp_fused_body<E, D, H, TNCW, true, true, false, false>(a, b);
+      } else mlp_fused_body<E, D, H, TNCW, true, PROJ>(a, b);
+    }
   }
 }
 
 // 64-token panels, wave pairs (PAIR above): one workgroup per two row blocks
 template <typename E, int D, int H>
 __global__ __launch_bounds__(256, 1) void mlp_pair_kernel(MlpArgs a) {
-  mlp_fused_body<E, D, H, H / 128, false, true, true>(a, (int)blockIdx.x);
+  if ((wave_id() & 1) == 0) mlp_fused_body<E, D, H, H / 128, false, true, true, true>(a, (int)blockIdx.x);    // (both bodies pass the same barriers)
+  else mlp_fused_body<E, D, H, H / 128, false, true, true, false>(a, (int)blockIdx.x);
 }
 
 // x[row block rb0 + i] = (add_x ? x : 0) + bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot

@@ -120,7 +120,10 @@ class HipEncoder:
     # 384 crops 83.5 -> 91.3 k as three, 512 crops 90.9 -> 93.5 k; 160 crops and below lose (72.3 -> 59.4 k), 640 and above do not gain.  Why: 256 crops = 394 fused-MLP
     # panels = 1.54 rounds of 256 CUs — the second round runs on 54 % of the chip — while two 128-crop sub-batches out of phase fill each
     # other's idle CUs (one's 197-panel MLP beside the other's per-image kernel).
-    SPLIT_MIN, SPLIT_MAX = 176, 576
+    # Re-measured with the 64-token pair panels in the library (round 6, second half; gpurun_out/r6d_split_sweep.txt): 168 crops 66.7 -> 76.4 k as
+    # two, 240 / 249 / 256 crops 89.6 / 92.8 / 92.0 k as two against 75.1 / 75.6 / 89.9 k as three (sub-batches of 80-85 crops are pair-panel
+    # calls now: good alone, but their 160-170 workgroups leave the other sub-batches no idle CUs), 288 crops 89.1 (two) / 92.6 k (three).
+    SPLIT_MIN, SPLIT_MAX, SPLIT_THREE = 168, 576, 272
 
     def _split_plan(self, B):
         if not (self.split_streams and self.arch in ("vit_small_patch16_224", "vit_base_patch16_224") and self.precision in _CROP_DTYPE) or self._profiling:
@@ -134,7 +137,7 @@ class HipEncoder:
             return 2 if B >= 192 else 1
         if not (self.SPLIT_MIN <= B < self.SPLIT_MAX):
             return 1
-        return 2 if B < 240 else 3                                            # tools/split_sweep.py (profiles/r06_split_sweep.txt)
+        return 2 if B < self.SPLIT_THREE else 3                               # tools/split_sweep.py (profiles/r06_split_sweep.txt)
 
     def _forward_into(self, x, emb, normalize):
         """Enqueue one forward on torch's current stream of THIS thread.  The engine lock covers the workspace table only: the library's

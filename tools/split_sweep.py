@@ -11,7 +11,8 @@ arch = "vit_small_patch16_224"
 enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=224), precision="bf16", device=dev)
 idx = IndexFlatIP(384, device=dev)
 idx.add(torch.nn.functional.normalize(torch.randn(10000, 384, generator=torch.Generator().manual_seed(0)), dim=1))
-for B in (160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024):
+SIZES = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024)
+for B in SIZES:
     x = torch.randn(B, 3, 224, 224, device=dev)
     row = []
     for S in (1, 2, 3, 4):
