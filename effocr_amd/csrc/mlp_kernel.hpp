@@ -53,6 +53,9 @@
 #ifndef MLP_DIAG
 #define MLP_DIAG 0                                       // timing ablations, WRONG results, never shipped (tools/ab_build.sh): 1 no hand-over ops,
 #endif                                                   // 2 no W-fragment reads in the steady state, 4 no steady-state DMA, 8 no mid-stage barrier
+#ifndef MLP_LN_PK
+#define MLP_LN_PK 1                                      // LayerNorm arithmetic (norm2 and the second output) as packed fp32 pairs: nothing runs on the matrix pipe beside it, and a
+#endif                                                   // v_pk_* issues like a scalar instruction (4.96 vs 4.7 cycles, tools/ubench/pk_burst.hip) for two values
 #ifndef MLP_PRE_STAGES
 #define MLP_PRE_STAGES 3                                 // ring stages requested in front of the prologue's wait (the rest behind its barrier)
 #endif
@@ -412,14 +415,31 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       for (int i = 0; i < 2 * NXF; ++i) asm volatile("" : "+v"(xv[i]));
     }
   };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto layernorm_to_xf = [&]() __attribute__((always_inline)) {
     float sm = 0.f;
     pin_row();
+    if constexpr (MLP_LN_PK) {
+      f32x2 s2 = {0.f, 0.f};
+      sfor<0, 2 * NXF>([&](auto I_) { const f32x4 v = row(I_); s2 += f32x2{v[0], v[1]}; s2 += f32x2{v[2], v[3]}; });
+      sm = s2[0] + s2[1];
+    } else
     sfor<0, 2 * NXF>([&](auto I_) { const f32x4 v = row(I_); sm += (v[0] + v[1]) + (v[2] + v[3]); });
     sm += __shfl_xor(sm, 32, 64);
     const float mean = sm * (1.0f / D);
     float ss = 0.f;
     pin_row();
+    if constexpr (MLP_LN_PK) {                             // still two passes: exact statistics of the fp32 row
+      f32x2 q2 = {0.f, 0.f};
+      const f32x2 nm = {-mean, -mean};
+      sfor<0, 2 * NXF>([&](auto I_) {
+        const f32x4 v = row(I_);
+        const f32x2 d0 = f32x2{v[0], v[1]} + nm, d1 = f32x2{v[2], v[3]} + nm;
+        q2 = __builtin_elementwise_fma(d0, d0, q2);
+        q2 = __builtin_elementwise_fma(d1, d1, q2);
+      });
+      ss = q2[0] + q2[1];
+    } else
     sfor<0, 2 * NXF>([&](auto I_) {
       const f32x4 v = row(I_);
 #pragma unroll
@@ -427,6 +447,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     });
     ss += __shfl_xor(ss, 32, 64);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+    const f32x2 r2 = {rstd, rstd}, nm2 = {-mean, -mean};
     pin_row();
     sfor<0, NXF>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
@@ -437,6 +458,11 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         const f32x4 gm = *reinterpret_cast<const f32x4*>(sG + c * 4);
         const f32x4 bt = *reinterpret_cast<const f32x4*>(sBt + c * 4);
         const f32x4 v = j == 0 ? row(std::integral_constant<int, 2 * t>{}) : row(std::integral_constant<int, 2 * t + 1>{});
+        if constexpr (MLP_LN_PK) {                         // ((v - mean) rstd) gamma + beta, two values per instruction (same operations per value)
+          const f32x2 o0 = __builtin_elementwise_fma((f32x2{v[0], v[1]} + nm2) * r2, f32x2{gm[0], gm[1]}, f32x2{bt[0], bt[1]});
+          const f32x2 o1 = __builtin_elementwise_fma((f32x2{v[2], v[3]} + nm2) * r2, f32x2{gm[2], gm[3]}, f32x2{bt[2], bt[3]});
+          pk[j] = pack4<E>(o0[0], o0[1], o1[0], o1[1]);
+        } else
         pk[j] = pack4<E>((v[0] - mean) * rstd * gm[0] + bt[0], (v[1] - mean) * rstd * gm[1] + bt[1],
                          (v[2] - mean) * rstd * gm[2] + bt[2], (v[3] - mean) * rstd * gm[3] + bt[3]);
         if constexpr (!PARTIAL && !BIAS_MM) {
@@ -936,6 +962,19 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       sm += __shfl_xor(sm, 32, 64);
       const float mean = sm * (1.0f / D);
       float ss = 0.f;
+      if constexpr (MLP_LN_PK) {
+        f32x2 q2 = {0.f, 0.f};
+        const f32x2 nm = {-mean, -mean};
+        sfor<0, OT>([&](auto T_) {
+          constexpr int t = decltype(T_)::value;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 d = f32x2{acc2[t][r], acc2[t][r + 1]} + nm;
+            q2 = __builtin_elementwise_fma(d, d, q2);
+          }
+        });
+        ss = q2[0] + q2[1];
+      } else
       sfor<0, OT>([&](auto T_) {
         constexpr int t = decltype(T_)::value;
 #pragma unroll
@@ -943,6 +982,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       });
       ss += __shfl_xor(ss, 32, 64);
       const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+      const f32x2 r2 = {rstd, rstd}, nm2 = {-mean, -mean};
       char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
       sfor<0, OT>([&](auto T_) {
         constexpr int t = decltype(T_)::value;
@@ -954,6 +994,11 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
             const int q = 2 * p + j, c = cq(t, q);       // fp32 chunk c = features 4c..4c+3 = half j of 16-bit chunk c >> 1
             const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
             const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+            if constexpr (MLP_LN_PK) {
+              const f32x2 o0 = __builtin_elementwise_fma((f32x2{acc2[t][4 * q], acc2[t][4 * q + 1]} + nm2) * r2, f32x2{gm[0], gm[1]}, f32x2{bt[0], bt[1]});
+              const f32x2 o1 = __builtin_elementwise_fma((f32x2{acc2[t][4 * q + 2], acc2[t][4 * q + 3]} + nm2) * r2, f32x2{gm[2], gm[3]}, f32x2{bt[2], bt[3]});
+              pk[j] = pack4<E>(o0[0], o0[1], o1[0], o1[1]);
+            } else
             pk[j] = pack4<E>((acc2[t][4 * q] - mean) * rstd * gm[0] + bt[0], (acc2[t][4 * q + 1] - mean) * rstd * gm[1] + bt[1],
                              (acc2[t][4 * q + 2] - mean) * rstd * gm[2] + bt[2], (acc2[t][4 * q + 3] - mean) * rstd * gm[3] + bt[3]);
           }
