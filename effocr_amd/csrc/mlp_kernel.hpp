@@ -712,9 +712,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       if constexpr (n == 4) stage_mid(std::integral_constant<bool, (decltype(REM)::value >= R - 2)>{});
       mfma1(std::integral_constant<int, c4>{}, std::integral_constant<int, i>{}, wf.w[n & 3]);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (n < 4) wf.w[n & 3] = *reinterpret_cast<const V8*>(st + wo2 + (i * 8 + 2 * (c4 + 2)) * 512);
+      if constexpr (MLP_DIAG & 2) asm volatile("" : "+v"(wf.w[n & 3]));
+      else if constexpr (n < 4) wf.w[n & 3] = *reinterpret_cast<const V8*>(st + wo2 + (i * 8 + 2 * (c4 + 2)) * 512);
       else if constexpr (next) wf.w[n & 3] = *reinterpret_cast<const V8*>(stn + wo2 + (i * 8 + 2 * (c4 - 2)) * 512);
-      if constexpr (more && n >= 4) issue_piece_asm(s + R - 1, std::integral_constant<int, n - 4>{});   // behind the barrier: slot of stage s-1 is free
+      if constexpr (more && n >= 4 && !(MLP_DIAG & 4)) issue_piece_asm(s + R - 1, std::integral_constant<int, n - 4>{});   // behind the barrier: slot of stage s-1 is free
     });
     ++s;
   };
