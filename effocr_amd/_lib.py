@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("EFFOCR_HIP_LIB") or os.path.join(_HERE, "libeffocr_hip
 # Never loaded by the engines on their own; tests that compare those paths switch to it with use_library().
 SO_PATH_AB = os.path.join(_HERE, "libeffocr_hip_ab.so")
 
-ABI_VERSION = 8          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
+ABI_VERSION = 9          # == EFFOCR_ABI_VERSION of include/effocr_hip.h (tests/test_cabi.py checks the pair)
 PREC = {"bf16": 0, "fp16": 1, "fp32": 2}
 EPI = {"bias": 0, "bias_gelu": 1, "bias_resid": 2}
 

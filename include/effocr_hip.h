@@ -29,7 +29,7 @@ extern "C" {
 /* bumped whenever an exported signature or the meaning of an argument changes (round 1: 1; round 2 added
  * arguments to effocr_op_mlp_blocked without a bump — callers must treat 1 as "unknown layout"); a caller built
  * against another value must refuse to call into the library (effocr_amd/_lib.py does) */
-#define EFFOCR_ABI_VERSION 8
+#define EFFOCR_ABI_VERSION 9
 
 enum effocr_status {
   EFFOCR_OK = 0,

@@ -14,6 +14,7 @@ CLASSES = [  # (substring of the mangled/demangled kernel name, readable class)
     ("layernorm_blocked_kernel", "layernorm_blocked"), ("conv_igemm", "conv_igemm"),
     # mlp_fused_kernel<E, D, H, TNCW, PROJ>: whole panels + the split parts of the tail panels (TNCW chunks each) in one launch
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb1", "proj_mlp_main"),
+    ("mlp_fused_kernelIDF16bLi384ELi1536ELi2ELb1", "proj_mlp_main"), ("mlp_pair_kernel", "proj_mlp_pair"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb1", "proj_mlp_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi0ELb0", "mlp_fused_main"),
     ("mlp_fused_kernelIDF16bLi384ELi1536ELi3ELb0", "mlp_fused_main"), ("mlp_fused_kernelIDF16bLi384ELi1536ELi6ELb0", "mlp_fused_main"),
     ("mlp_reduce_kernel", "mlp_fused_reduce"), ("gather_cls", "gather_cls"),
