@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
     half = lane >> 5;
   };
   const int w = wave_id();
+  QA_STAMP_AT(14)                                        // kernel entry (tools/qa_timeline.py: entry -> first head = the prologue)
   const int T = a.T;
   int64_t tok0 = 0;                                      // first token of the current image
   // Workgroups are persistent (grid = min(images, CUs)): image blockIdx.x, + gridDim.x, ...  The weight stream of an
@@ -122,7 +123,24 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
   const int h0 = ((int)blockIdx.x >> 3) % NH;            // blocks b, b+8, ... share an XCD (and its L2)
   const char* Wb = static_cast<const char*>(a.Wb);
 
-  for (int n = tid; n < 3 * D; n += 256) sBias[n] = a.bias[n];
+  // The qkv bias goes straight to LDS by LDS-DMA (16-byte units, inline asm: the compiler sees no LDS-DMA and no load).  As a loop of
+  // load -> ds_write it was FIVE serialised memory round trips (s_waitcnt vmcnt(0) in every iteration) in front of the first request for
+  // the image's rows: 9.9-11.3 k ticks between kernel entry and the first head of a small call (tools/qa_timeline.py), a quarter of a
+  // one-head workgroup's life.  The pieces are the oldest entries of the in-order VM queue: the first stage's counted wait + barrier cover them.
+  {
+    const unsigned sB_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sBias;
+#pragma unroll
+    for (int j = 0; j < (3 * D / 4 + 255) / 256; ++j) {
+      const int u = j * 256 + tid;                         // 16-byte unit of the bias image
+      const char* src = reinterpret_cast<const char*>(a.bias) + (size_t)u * 16;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_lds + (unsigned)(j * 256 + (tid >> 6) * 64) * 16u));
+      if (u < 3 * D / 4)
+        asm volatile("s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(dst) : "memory", "m0");
+    }
+  }
 
   // ---- ring: global stage g = (head, q|k|v, k slice).  Wave w copies row block w>>1, k chunks (w&1)*8..+8 of the
   // stage: 4 pieces of 1 KB (two adjacent 512-byte cells each).  (ih, isec, ikt) = the next stage to be issued.
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void qkvattn_kernel(QkvAttnArgs a) {
       QA_STAMP_AT(15)
     };
 
-    __syncthreads();                                     // parameters visible before the ring starts filling
+    // (no barrier here: the bias pieces above are older than everything requested below, stage 0's counted wait + barrier make them visible)
     load_frags(slot0);                                   // oldest in the in-order VM queue
 #pragma unroll
     for (int s0 = 0; s0 < R - 1; ++s0) {
@@ -548,6 +566,7 @@ int qkv_attn_fused(int prec, const QkvAttnArgs& a, hipStream_t s) {
   if (a.B <= 0) return EFFOCR_OK;
   if (!qkv_attn_supported(prec, a.D, a.T)) return fail(EFFOCR_EUNSUPPORTED, "qkv_attn_fused: unsupported (precision, embed dim, tokens)");
   if (a.rows_alloc % 32 || a.rows_alloc < (int64_t)a.B * a.T) return fail(EFFOCR_EINVAL, "qkv_attn_fused: rows_alloc must be a multiple of 32 >= batch * tokens");
+  if ((reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) return fail(EFFOCR_EINVAL, "qkv_attn_fused: the bias array must be 16-byte aligned (it reaches LDS by 16-byte DMA)");
   return prec == PREC_BF16 ? launch_qkvattn<__bf16>(a, s) : launch_qkvattn<_Float16>(a, s);
 }
 

@@ -399,7 +399,7 @@ int effocr_op_proj_mlp_blocked(int precision, float* x_blk_dev, const void* a_bl
  * wqkv_blk: attn.qkv.weight [3d, d] 16-bit fragment-blocked with the v rows (rows 2d..3d) P32-permuted (see
  * effocr_op_mlp_blocked: then a lane of the output tile holds 8 consecutive head dims = one 16-byte store); bias: attn.qkv.bias
  * with its v part permuted alike.  d in {128, 384}; tokens <= 64 or in 193..224.
- * The qkv tensor never exists in device memory. */
+ * The qkv tensor never exists in device memory.  The bias array must be 16-byte aligned (it reaches LDS by 16-byte DMA; EFFOCR_EINVAL otherwise). */
 int effocr_op_qkv_attn_blocked(int precision, const void* xn_blk_dev, const void* wqkv_blk_dev, const float* bias_dev,
                                void* out_blk_dev, int batch, int tokens, int d, int rows_alloc, void* stream);
 int effocr_op_layernorm_blocked(int out_precision, const float* x_blk_dev, int64_t rows, int d, const float* gamma_dev,

@@ -30,7 +30,8 @@ for w in range(4):
     tw = t[:, w]
     tw = tw[tw[:, 15] > tw[:, 0]]
     tot = tw[:, 15] - tw[:, 0]
-    print(f"wave {w}: {len(tw)} workgroups, ticks per head mean {tot.mean():.0f} (p10 {np.percentile(tot, 10):.0f}, p90 {np.percentile(tot, 90):.0f})")
+    print(f"wave {w}: {len(tw)} workgroups, ticks per head mean {tot.mean():.0f} (p10 {np.percentile(tot, 10):.0f}, p90 {np.percentile(tot, 90):.0f}); "
+          f"kernel entry -> start of the LAST head the workgroup ran (one head per workgroup in a small call: = the prologue) {(tw[:, 0] - tw[:, 14]).mean():.0f}")
     for a, b, n in names:
         if w == 3 and a >= 8:
             continue
