@@ -902,34 +902,98 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   asm volatile("" : "+v"(hf));                           // opaque: else the LayerNorm's 48 chunk offsets are kept (spilled) across the main loop for this
   auto cq = [&](int t, int q) __attribute__((always_inline)) { return 8 * t + 4 * (q >> 1) + 2 * hf + (q & 1); };
   if constexpr (PAIR) {
-    // The two partial sums of a token tile meet in LDS: the ring is drained (every stage consumed), wave 2j+1 parks its 16 OT values per
-    // lane as [tile][quad][lane] x 16 B (48 KB per pair at D = 384), everybody adds (wave 2j+1 its own copy: straight-line, its result is dropped).
+    // The two partial sums of a token tile meet in LDS, and each wave of the pair finishes HALF of the tile's output features: tiles
+    // 4g + 2p, 4g + 2p + 1 are wave p's ("own").  The ring is drained (every stage consumed): a wave parks the 16 x 6 values per lane of
+    // the tiles it does not own as [tile][quad][lane] x 16 B (the pair's 48 KB slab holds each tile once), adds its partner's for its
+    // own tiles, stores their part of x and — the row statistics exchanged through 1 KB behind the slabs — of the second output.
+    constexpr int PP = KEEP ? 0 : 1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // nobody still reads the last stages
     asm volatile("" ::: "memory");
     char* px = smem + (w >> 1) * (OT * 4 * 1024) + lane * 16;
-    if (pp == 1) {
-      sfor<0, OT>([&](auto T_) {
-        constexpr int t = decltype(T_)::value;
+    sfor<0, OT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      if constexpr (((t & 3) >> 1) != PP) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
           *reinterpret_cast<f32x4*>(px + (t * 4 + q) * 1024) = o;
         }
-      });
-    }
+      }
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    const bool live = rb * 32 + r31 < a.M;
+    char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
+    float sm = 0.f;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
+      if constexpr (((t & 3) >> 1) == PP) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(px + (t * 4 + q) * 1024);
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(px + (t * 4 + q) * 1024);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += v[e];
+          for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += v[e];
+          const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
+          sm += (o[0] + o[1]) + (o[2] + o[3]);
+          if (live) st_act<4>(reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512), o);
+        }
       }
     });
+    MLP_STAMP_AT(9)
+    if (a.xn_out) {                                      // (uniform: every wave passes the two barriers below)
+      float* sS = reinterpret_cast<float*>(smem + 2 * (OT * 4 * 1024));   // [sum | sum of squares][wave][token]
+      sm += __shfl_xor(sm, 32, 64);
+      if (half == 0) sS[w * 32 + r31] = sm;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      sm += sS[(w ^ 1) * 32 + r31];                      // (own + partner's: the same sum in both waves)
+      const float mean = sm * (1.0f / D);
+      f32x2 q2 = {0.f, 0.f};
+      const f32x2 nm = {-mean, -mean};
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+        if constexpr (((t & 3) >> 1) == PP) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 d = f32x2{acc2[t][r], acc2[t][r + 1]} + nm;
+            q2 = __builtin_elementwise_fma(d, d, q2);
+          }
+        }
+      });
+      float ss = q2[0] + q2[1];
+      ss += __shfl_xor(ss, 32, 64);
+      if (half == 0) sS[128 + w * 32 + r31] = ss;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      ss += sS[128 + (w ^ 1) * 32 + r31];
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+      const f32x2 r2 = {rstd, rstd}, nm2 = {-mean, -mean};
+      char* nr = static_cast<char*>(a.xn_out) + rb * (D / 8) * 512 + r31 * 16;
+      sfor<0, OT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+        if constexpr (((t & 3) >> 1) == PP) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            u32x2 pk[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int q = 2 * p + j, c = cq(t, q);
+              const f32x4 gm = *reinterpret_cast<const f32x4*>(sGn + c * 4);
+              const f32x4 bt = *reinterpret_cast<const f32x4*>(sBn + c * 4);
+              const f32x2 o0 = __builtin_elementwise_fma((f32x2{acc2[t][4 * q], acc2[t][4 * q + 1]} + nm2) * r2, f32x2{gm[0], gm[1]}, f32x2{bt[0], bt[1]});
+              const f32x2 o1 = __builtin_elementwise_fma((f32x2{acc2[t][4 * q + 2], acc2[t][4 * q + 3]} + nm2) * r2, f32x2{gm[2], gm[3]}, f32x2{bt[2], bt[3]});
+              pk[j] = pack4<E>(o0[0], o0[1], o1[0], o1[1]);
+            }
+            const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+            if (live) st_act<8>(reinterpret_cast<u32x4*>(nr + (size_t)(4 * t + 2 * p + hf) * 512), o);
+          }
+        }
+      });
+    }
   }
   if constexpr (PARTIAL) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
@@ -943,7 +1007,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
-  } else if ((!PAIR || pp == 0) && rb * 32 + r31 < a.M) {
+  } else if (!PAIR && rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
     float sm = 0.f;
     sfor<0, OT>([&](auto T_) {
