@@ -83,7 +83,7 @@ struct effocr_encoder {
   int use_lnfold = 1;               // gemm3 path (ViT-B): LayerNorm folded into the residual producers' / qkv, fc1 consumers' epilogues (0: LayerNorm launches, A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int split6 = 1;                   // fused MLP: 6-way hidden split for calls of <= 27 crops (0: A/B switch)
-  int mlp_pair = 0;                 // fused MLP: 64-token panels on wave pairs: 0 = auto (43-83 crops), 1 = whenever they fit one round, -1 = never (A/B switch)
+  int mlp_pair = 0;                 // fused MLP: 64-token panels on wave pairs: 0 = auto (30-83 crops), 1 = whenever they fit one round, -1 = never (A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
   int panel_rows = 128;             // row-panel height: 128 (1 workgroup/CU) or 64 (2 workgroups/CU)

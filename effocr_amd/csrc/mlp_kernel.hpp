@@ -144,7 +144,8 @@ constexpr int MLP_RING = 8;
 template <int D, int H> constexpr int mlp_smem_bytes() { return MLP_RING * MLP_STAGE + (H + 6 * D) * 4; }
 // the workgroup's LDS: ONE object for both bodies of a kernel (whole panels / split parts) — a pointer parameter would make
 // the compiler lose the address space (and, measured, spill 370 registers in the LayerNorm)
-__shared__ __attribute__((aligned(16))) char mlp_smem[mlp_smem_bytes<384, 1536>()];
+constexpr int MLP_PAIR_XCH = 16384 + 1024;              // PAIR: 4 fragments x 4 waves of the LayerNorm's hand-over per round + the row statistics
+__shared__ __attribute__((aligned(16))) char mlp_smem[mlp_smem_bytes<384, 1536>() + MLP_PAIR_XCH];   // 163 840 B = the CU's 160 KB (one workgroup per CU anyway)
 
 // body of one workgroup: bid = its index among the workgroups of its kind (whole panels / split parts)
 // PAIR (round 6, calls of 33-83 crops: 64-token panels): the workgroup owns TWO 32-token tiles; the waves 2j, 2j+1 share tile j.  Both run
@@ -261,12 +262,14 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // registers 4q..4q+3 = fp32 chunk 8t + 4(q>>1) + 2half + (q&1) of the row = xv[4t + q].  The rows of the first output group
   // are requested here, the rest at the start of the projection (they land under its first group of MFMAs): no load latency
   // in the middle of the kernel and never more than 128 VGPRs of rows next to the 96 of the attention fragments.
+  // PAIR: wave p of a pair owns output tiles 4g + 2p, 4g + 2p + 1 — their rows, their share of the projection, of both LayerNorms and of the stores
+  auto own_tile = [&](int t) __attribute__((always_inline)) { return !PAIR || ((t & 3) >> 1) == pp; };
   auto load_rows = [&](int t0, int t1) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = t0; t < t1; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        xv[4 * t + q] = ld_act<1>(reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512));
+        if (own_tile(t)) xv[4 * t + q] = ld_act<1>(reinterpret_cast<const f32x4*>(xb + (size_t)(8 * t + 4 * (q >> 1) + 2 * half + (q & 1)) * 512));
   };
   auto rows_to_acc = [&](auto T0_, auto T1_) __attribute__((always_inline)) {
     constexpr int t0 = decltype(T0_)::value, t1 = decltype(T1_)::value;
@@ -276,7 +279,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] = xv[4 * t + q][e];
+        for (int e = 0; e < 4; ++e) if (own_tile(t)) acc2[t][4 * q + e] = xv[4 * t + q][e];
   };
   if constexpr (PROJ) {
     rows_to_acc(std::integral_constant<int, 0>{}, std::integral_constant<int, (MLP_ROWS_LATE && OG > 1) ? 4 : OT>{});
@@ -371,7 +374,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   asm volatile("" ::: "memory");
   if constexpr (PROJ) {
 #pragma unroll
-    for (int t = 0; t < ((MLP_ROWS_LATE && OG > 1) ? 4 : OT); ++t) asm volatile("" : "+a"(acc2[t]));
+    for (int t = 0; t < ((MLP_ROWS_LATE && OG > 1) ? 4 : OT); ++t) if (own_tile(t)) asm volatile("" : "+a"(acc2[t]));
 #pragma unroll
     for (int t = 0; t < NXF; ++t) asm volatile("" : "+v"(xf[t]));
   } else {
@@ -409,7 +412,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   auto pin_row = [&]() __attribute__((always_inline)) {
     if constexpr (PROJ) {
 #pragma unroll
-      for (int t = 0; t < OT; ++t) asm volatile("" : "+a"(acc2[t]));
+      for (int t = 0; t < OT; ++t) if (own_tile(t)) asm volatile("" : "+a"(acc2[t]));
     } else {                                             // (same for the VGPR copy: else (v - mean) of the variance pass is kept, i.e. spilled, for the last pass)
 #pragma unroll
       for (int i = 0; i < 2 * NXF; ++i) asm volatile("" : "+v"(xv[i]));
@@ -478,6 +481,82 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       if constexpr (!PARTIAL) __builtin_amdgcn_sched_barrier(0);   // in order: the row's registers become the accumulators' one chunk pair at a time
     });
   };
+  // PAIR: norm2 of a token tile by its two waves.  Each holds the new row's features of its own six tiles (fp32 chunks i with tile i >> 2
+  // own): partial sums of both statistics passes meet through 1 KB of LDS (own + partner's: the same sum in both waves), each normalises its
+  // own 12 operand fragments (fragment t' = tile t' >> 1) and the halves are exchanged through a 16 KB buffer in three rounds of four fragments
+  // per wave (round g: fragments 8g + 4p .. + 3; the ring keeps streaming underneath — that is why the buffer is this small).
+  auto layernorm_to_xf_pair = [&]() __attribute__((always_inline)) {
+    constexpr int PP = KEEP ? 0 : 1;
+    float* sS = reinterpret_cast<float*>(smem + mlp_smem_bytes<D, H>() + 16384);   // [sum | sum of squares][wave][token]
+    char* xch = smem + mlp_smem_bytes<D, H>();                                      // [wave][fragment j of the round][lane] x 16 B
+    pin_row();
+    f32x2 s2 = {0.f, 0.f};
+    sfor<0, 2 * NXF>([&](auto I_) {
+      if constexpr ((((decltype(I_)::value >> 2) & 3) >> 1) == PP) { const f32x4 v = row(I_); s2 += f32x2{v[0], v[1]}; s2 += f32x2{v[2], v[3]}; }
+    });
+    float sm = s2[0] + s2[1];
+    sm += __shfl_xor(sm, 32, 64);
+    if (half == 0) sS[w * 32 + r31] = sm;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    sm += sS[(w ^ 1) * 32 + r31];
+    const float mean = sm * (1.0f / D);
+    pin_row();
+    f32x2 q2 = {0.f, 0.f};
+    const f32x2 nm = {-mean, -mean};
+    sfor<0, 2 * NXF>([&](auto I_) {
+      if constexpr ((((decltype(I_)::value >> 2) & 3) >> 1) == PP) {
+        const f32x4 v = row(I_);
+        const f32x2 d0 = f32x2{v[0], v[1]} + nm, d1 = f32x2{v[2], v[3]} + nm;
+        q2 = __builtin_elementwise_fma(d0, d0, q2);
+        q2 = __builtin_elementwise_fma(d1, d1, q2);
+      }
+    });
+    float ss = q2[0] + q2[1];
+    ss += __shfl_xor(ss, 32, 64);
+    if (half == 0) sS[128 + w * 32 + r31] = ss;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ss += sS[128 + (w ^ 1) * 32 + r31];
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + a.eps);
+    const f32x2 r2 = {rstd, rstd};
+    pin_row();
+    sfor<0, NXF>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      if constexpr ((((t >> 1) & 3) >> 1) == PP) {
+        u32x2 pk[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = 4 * t + 2 * half + j;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(sG + c * 4);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(sBt + c * 4);
+          const f32x4 v = j == 0 ? row(std::integral_constant<int, 2 * t>{}) : row(std::integral_constant<int, 2 * t + 1>{});
+          const f32x2 o0 = __builtin_elementwise_fma((f32x2{v[0], v[1]} + nm) * r2, f32x2{gm[0], gm[1]}, f32x2{bt[0], bt[1]});
+          const f32x2 o1 = __builtin_elementwise_fma((f32x2{v[2], v[3]} + nm) * r2, f32x2{gm[2], gm[3]}, f32x2{bt[2], bt[3]});
+          pk[j] = pack4<E>(o0[0], o0[1], o1[0], o1[1]);
+        }
+        const u32x4 q = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+        xf[t] = __builtin_bit_cast(V8, q);
+      }
+    });
+    sfor<0, OG>([&](auto G_) {                             // hand-over, one output group per round
+      constexpr int g = decltype(G_)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<V8*>(xch + (w * 4 + j) * 1024 + lane * 16) = xf[8 * g + 4 * PP + j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[8 * g + 4 * (1 - PP) + j] = *reinterpret_cast<const V8*>(xch + ((w ^ 1) * 4 + j) * 1024 + lane * 16);
+      if constexpr (g + 1 < OG) {                          // the partner has read before the next round overwrites
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    });
+  };
   if constexpr (!PROJ) {
     layernorm_to_xf();
 #pragma unroll
@@ -520,7 +599,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #endif
   };
   WF wf;                                                 // the step's four W fragments (rolling refill, see ring_stage)
-  load_w(wf, sW, 0);                                     // (stage 0 landed in front of the prologue's barrier)
+  if constexpr (PAIR) {                                  // (stage 0 landed in front of the prologue's barrier)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) wf.w[n] = *reinterpret_cast<const V8*>(sW + wo2 + ((n & 1) * 8 + 2 * (n >> 1)) * 512);
+  } else load_w(wf, sW, 0);
   MLP_STAMP_AT(3)
 
   // ---- chunk hand-over registers: the set holds the 8 B-operand fragments (8 values each) of one chunk, first as
@@ -701,8 +783,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
 #pragma unroll
     for (int n = 0; n < 4; ++n) f.w[n] = *reinterpret_cast<const V8*>(st + wo2 + ((n & 1) * 8 + 2 * (n >> 1)) * 512);
   };
-  auto ring_stage_pair = [&](auto REM, auto&& mfma1) __attribute__((always_inline)) {
-    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1;
+  auto ring_stage_pair = [&](auto REM, auto&& mfma1, auto NOPF) __attribute__((always_inline)) {
+    constexpr bool more = decltype(REM)::value >= R - 1, next = decltype(REM)::value >= 1 && !decltype(NOPF)::value;
     int so = (s & (R - 1)) * MLP_STAGE, son = ((s + 1) & (R - 1)) * MLP_STAGE;
     asm volatile("" : "+s"(so), "+s"(son));
     const char* st = sW + so;
@@ -733,7 +815,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc1[i] = Op16<E>::mfma(wfrag, xf[0], z);
           } else acc1[i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc1[i]);
-        });
+        }, std::false_type{});
       } else
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
@@ -761,14 +843,14 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         ring_stage_pair(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
           constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
           const V8 hb = __builtin_bit_cast(V8, hs.u[c4]);
-          if constexpr (zc && c4 == 0) {
+          if constexpr (decltype(FIRSTB)::value && (sb & 1) != (KEEP ? 0 : 1) && c4 == 0) {   // B(0), a tile of the partner (tiles 2 sb, 2 sb + 1 are wave (sb & 1)'s): start from zero
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc2[2 * sb + i] = Op16<E>::mfma(wfrag, hb, z);
           } else
           acc2[2 * sb + i] = Op16<E>::mfma(wfrag, hb, acc2[2 * sb + i]);
           constexpr int n = sb * 8 + c4 * 2 + i, per = SB * 8 / 4;
           if constexpr (decltype(K1_)::value > decltype(K0_)::value && n % per == per / 2 && !(MLP_DIAG & 1)) fused_burst(*hd, cb, std::integral_constant<int, n / per>{});
-        });
+        }, std::false_type{});
       } else
       ring_stage(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
         constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
@@ -802,6 +884,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       }
       sfor<0, SA>([&](auto KS) {
         constexpr int ks = decltype(KS)::value;
+        if constexpr (PAIR) {                              // the wave's two tiles of the group: row blocks 2p, 2p + 1 of the stage, 8 MFMAs
+          constexpr int PP = KEEP ? 0 : 1;
+          ring_stage_pair(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
+            constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
+            acc2[4 * g + 2 * PP + i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc2[4 * g + 2 * PP + i]);
+          }, std::integral_constant<bool, (g == OG - 1 && ks == SA - 1)>{});
+        } else
         ring_stage(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
           constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
           acc2[4 * g + i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc2[4 * g + i]);
@@ -809,9 +898,16 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       });
     });
     MLP_STAMP_AT(4)
+    if constexpr (PAIR) {
+      constexpr int PP = KEEP ? 0 : 1;
+      sfor<0, OT>([&](auto T_) { if constexpr (((decltype(T_)::value & 3) >> 1) == PP) bias_mm(sBp, T_); });
+      layernorm_to_xf_pair();
+      sfor<0, OT>([&](auto T_) { if constexpr (((decltype(T_)::value & 3) >> 1) == PP) bias_mm(sB2, T_); });   // each tile's bias2 once: in its owner
+    } else {
     sfor<0, OT>([&](auto T_) { bias_mm(sBp, T_); });
     layernorm_to_xf();
     if constexpr (!PARTIAL && KEEP) sfor<0, OT>([&](auto T_) { bias_mm(sB2, T_); });   // (after the statistics: the LayerNorm is of the row without bias2; split parts: the reduction adds it)
+    }
     if constexpr (PAIR) load_w_pair(wf, sW + (s & (R - 1)) * MLP_STAGE);
     else load_w(wf, sW + (s & (R - 1)) * MLP_STAGE, 0);
 #pragma unroll
@@ -866,7 +962,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   };
   {
     int c = 1;                                           // chunks 1 .. NC-3 rolled in pairs (static set roles), chunk NC-2 peeled (static stage counts)
-    if constexpr (KEEP) {
+    if constexpr (KEEP && !PAIR) {
 #pragma unroll 1
       for (; c + 1 <= NC - 3; c += 2) {
         pair_step(std::integral_constant<int, 1>{}, Far{}, c, std::false_type{});
@@ -1148,12 +1244,13 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   // 4 (or 2) workgroups each, which write partial outputs to the caller's scratch; a small kernel reduces them.
   const int slots = device_cus();
   if constexpr (PROJ) {
-    // Calls of 34-83 crops (more 128-token panels than a fifth of the CUs, 64-token panels within one round): 64-token panels on wave
-    // pairs — no partial sums in HBM, no reduction launch.  tools/pair_sweep.py, same box: 40 / 48 / 64 / 80 crops 0.90 / 0.90 / 0.90 / 0.91 of the
-    // split parts' call time, 32 crops 0.99, 24 crops 1.03 (there the 4- / 6-way parts win: a sixth of the weight stream per CU).
+    // Calls of 30-83 crops (47+ 128-token panels, 64-token panels within one round): 64-token panels on wave pairs — no partial sums in
+    // HBM, no reduction launch.  tools/pair_sweep.py, same box, final form (projection, both LayerNorms and the stores split between the
+    // two waves of a pair): 40 / 48 / 64 / 80 crops 0.88 / 0.87 / 0.86 / 0.84 of the split parts' call time, 32 crops 0.97, 28 crops 1.00,
+    // 24 crops 1.00, 16 crops 1.07 (there the 4- / 6-way parts win: a sixth of the weight stream per CU).
     const int np64 = (a.M + 63) / 64;
     const bool fits = np64 <= slots && a.rows_alloc >= np64 * 64;
-    if (fits && (a.pair > 0 || (a.pair == 0 && !a.no_tail_split && npanels * 5 > slots))) {
+    if (fits && (a.pair > 0 || (a.pair == 0 && !a.no_tail_split && npanels * 11 > slots * 2))) {
       a.panel0 = 0; a.main_wgs = np64; a.stagger_wgs = 0; a.tail_rb = 0;
       hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536>), dim3((unsigned)np64), dim3(256), 0, s, a);
       return check_launch("mlp_pair");

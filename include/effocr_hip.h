@@ -134,7 +134,7 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *                 (0: all tokens, A/B switch)
  *   "split6"      [1] fused MLP: calls of <= 27 crops cut their panels 6-way over the hidden dimension (0: 4-way)
  *   "mlp_pair"    [0] fused proj+MLP: 64-token panels whose wave pairs split a chunk's hidden features (no partial sums in HBM, no
- *                 reduction launch): 0 = for calls of 34..83 crops, 1 = whenever the 64-token panels fit one round of CUs, -1 = never
+ *                 reduction launch): 0 = for calls of 30..83 crops, 1 = whenever the 64-token panels fit one round of CUs, -1 = never
  *   "mlp_stagger" [3500] fused MLP kernel: the first round of workgroups starts spread over 32 x this many clock ticks, so
  *                 that the CUs do not request / store their rows all at the same moment (0 = off)
  *   "mlp_stagger_min_rounds" [2] ... for launches of at least this many rounds of CUs (512-crop calls: +7.7 %; no effect below two)

@@ -17,7 +17,7 @@ for mode in (-1, 1):
     encs[mode] = HipEncoder(arch, sd, precision=prec, device=dev)
     encs[mode].set_option("mlp_pair", mode)
 def rel(a, b): return ((a - b).abs().max() / b.abs().max()).item()
-for B in (16, 24, 32, 40, 48, 56, 64, 72, 80, 83):
+for B in (8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 83):
     x = torch.randn(B, 3, 224, 224, device=dev, generator=torch.Generator(device=dev).manual_seed(B))
     r = ref.forward(x, normalize=True)
     out = {}
