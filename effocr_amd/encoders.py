@@ -123,7 +123,15 @@ class HipEncoder:
     # Re-measured with the 64-token pair panels in the library (round 6, second half; gpurun_out/r6d_split_sweep.txt): 168 crops 66.7 -> 76.4 k as
     # two, 240 / 249 / 256 crops 89.6 / 92.8 / 92.0 k as two against 75.1 / 75.6 / 89.9 k as three (sub-batches of 80-85 crops are pair-panel
     # calls now: good alone, but their 160-170 workgroups leave the other sub-batches no idle CUs), 288 crops 89.1 (two) / 92.6 k (three).
-    SPLIT_MIN, SPLIT_MAX, SPLIT_THREE = 168, 576, 272
+    # Third pass, with the FINAL pair panels (projection / LayerNorm / stores split between the waves of a pair: 30-83-crop sub-batches cost 0.83-0.88 of
+    # what they did; profiles/r06d_split_sweep.txt, k crops/s as 1 / 2 / 3 parts): 84: 64.1 / 59.2 / 47.7; 90: 63.7 / 67.1 / 67.8; 96: 67.5 / 71.3 / 68.2;
+    # 104: 72.4 / 75.1 / 69.9; 112: 76.0 / 68.1 / 70.6; 120: 79.3 / 72.2 / 71.8; 128: 82.2 / 74.5 / 73.4; 136: 69.5 / 75.4 / 76.7; 144: 71.4 / 74.4 / 77.8;
+    # 152: 73.3 / 76.4 / 80.0; 160: 74.5 / 77.9 / 76.6; 168: 64.7 / 76.2 / 78.8; 176: 66.6 / 80.9 / 78.0; 184: 68.0 / 85.3 / 78.7; 256: 83.3 / 90.7 / 92.8 (noise:
+    # 92.0 / 89.9 in the second pass); 272: 83.1 / 84.7 / 94.1.  Above 128 images the per-image kernel loses its head split, below ~110 crops the
+    # 128-token panels fill less than 2/3 of the CUs: in both ranges two or three pair-panel sub-batches side by side win 5-10 %.
+    SPLIT_MIN, SPLIT_MAX, SPLIT_THREE = 88, 576, 272
+    SPLIT_SINGLE = (108, 132)                                # ... except here: one call (112-128 crops: 172-197 panels, heads split 2-way, fill the chip best)
+    SPLIT_THREE_MID = (132, 160)                             # three sub-batches of 44-53 crops
 
     def _split_plan(self, B):
         if not (self.split_streams and self.arch in ("vit_small_patch16_224", "vit_base_patch16_224") and self.precision in _CROP_DTYPE) or self._profiling:
@@ -135,9 +143,11 @@ class HipEncoder:
             # 26.1 -> 26.8 k, 1024 crops 26.85 -> 27.3 k (three parts lose): the HBM-bound attention / residual epilogues of one beside the
             # matrix-bound linears of the other
             return 2 if B >= 192 else 1
-        if not (self.SPLIT_MIN <= B < self.SPLIT_MAX):
+        if not (self.SPLIT_MIN <= B < self.SPLIT_MAX) or self.SPLIT_SINGLE[0] <= B < self.SPLIT_SINGLE[1]:
             return 1
-        return 2 if B < self.SPLIT_THREE else 3                               # tools/split_sweep.py (profiles/r06_split_sweep.txt)
+        if self.SPLIT_THREE_MID[0] <= B < self.SPLIT_THREE_MID[1]:
+            return 3
+        return 2 if B < self.SPLIT_THREE else 3                               # tools/split_sweep.py (profiles/r06d_split_sweep.txt)
 
     def _forward_into(self, x, emb, normalize):
         """Enqueue one forward on torch's current stream of THIS thread.  The engine lock covers the workspace table only: the library's

@@ -366,9 +366,9 @@ def test_pair_panels_match_the_split_parts(dev, prec, B):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
-@pytest.mark.parametrize("B", [168, 271, 272, 575])
+@pytest.mark.parametrize("B", [96, 144, 168, 271, 272, 575])
 def test_stream_split_calls_equal_their_sub_batches(dev, prec, B):
-    """Round 6: calls of 168..575 crops run as 2 (< 272) / 3 concurrent sub-batches on side streams (HipEncoder._forward_split; 16-bit ViT-S).
+    """Round 6: calls of 88..107 and 132..575 crops run as 2 / 3 concurrent sub-batches (HipEncoder._split_plan: 88-107 two, 132-159 three, 160-271 two, 272-575 three) on side streams (HipEncoder._forward_split; 16-bit ViT-S).
     The split call must be BIT-identical to the sub-batches run as calls of their own (same kernels at the same call sizes), agree with
     the unsplit call of the same crops within the mode's call-size bound, join back onto the caller's stream (the result is readable right
     away), and report a non-finite sub-batch through check_status (the status words live in the side streams' workspaces)."""
@@ -378,7 +378,8 @@ def test_stream_split_calls_equal_their_sub_batches(dev, prec, B):
     enc = HipEncoder(arch, sd, precision=prec, device=dev)
     x = torch.randn(B, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(B), device=dev)
     parts = enc._split_plan(B)
-    assert parts == (1 if prec == "fp32" else (2 if B < 272 else 3))
+    assert parts == (1 if prec == "fp32" else {96: 2, 144: 3, 168: 2, 271: 2, 272: 3, 575: 3}[B])
+    assert enc._split_plan(87) == 1 and enc._split_plan(120) == 1 and enc._split_plan(128) == 1 and enc._split_plan(576) == 1
     got = enc.forward(x, normalize=True)
     first = got.clone()                                                  # readable on the caller's stream without a synchronise
     enc.split_streams = False
@@ -596,7 +597,8 @@ def test_profiler_reports_times_work_and_shader_clocks(dev):
     from effocr_amd.encoders import HipEncoder
     arch = "vit_small_patch16_224"
     enc = HipEncoder(arch, init_state_dict(arch, seed=0, img_size=224), precision="bf16", device=dev)
-    x = torch.randn(160, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(2), device=dev)
+    x = torch.randn(120, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(2), device=dev)   # (a size that runs as ONE call: the profiler serialises, the split plan does not apply to a profiled forward)
+    assert enc._split_plan(120) == 1
     ref = enc.forward(x, normalize=True)
     enc.profile_begin()
     got = enc.forward(x, normalize=True)
