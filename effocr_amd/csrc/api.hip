@@ -83,6 +83,7 @@ struct effocr_encoder {
   int use_lnfold = 1;               // gemm3 path (ViT-B): LayerNorm folded into the residual producers' / qkv, fc1 consumers' epilogues (0: LayerNorm launches, A/B switch)
   int tail_split = 1;               // cut the panels of the last, partially filled round along N (0: A/B switch)
   int split6 = 1;                   // fused MLP: 6-way hidden split for calls of <= 27 crops (0: A/B switch)
+  int pair_parts = 1;               // fused MLP: calls of <= 27 crops as 3-way split 64-token pair panels (0: the 6- / 4-way 128-token parts; A/B switch)
   int mlp_pair = 0;                 // fused MLP: 64-token panels on wave pairs: 0 = auto (30-83 crops), 1 = whenever they fit one round, -1 = never (A/B switch)
   int use_blocked = 1;              // fragment-blocked activation layout on the panel path (0: row-major, A/B switch)
   int use_gemm2 = 1;                // 1: glds-ring K-streaming GEMM for fc2 / patch embed, 0: register-staged gemm.hip
@@ -517,7 +518,7 @@ int vit_forward(effocr_encoder* e, const void* x, int x16, int B, float* emb, in
         MlpArgs m{};
         m.x = xs; m.gamma = F(L.ln2w); m.beta = F(L.ln2b); m.eps = 1e-6f; m.W1b = wb + L.fc1w_b; m.b1 = F(L.fc1b);
         m.W2p = wb + L.fc2w_pp; m.b2 = F(L.fc2b_p); m.b2_logical = F(L.fc2b); m.M = M; m.D = D; m.H = e->vit.mlp; m.rows_alloc = (int)w.rows;
-        m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split; m.no_split6 = !e->split6; m.pair = e->mlp_pair; m.stagger = e->mlp_stagger; m.stagger_min_rounds = e->mlp_stagger_min_rounds;   // the hidden buffer is free on this path
+        m.partial = reinterpret_cast<float*>(hb); m.partial_bytes = w.hbytes; m.no_tail_split = !e->tail_split; m.no_split6 = !e->split6; m.pair = e->mlp_pair; m.no_pair_parts = !e->pair_parts; m.stagger = e->mlp_stagger; m.stagger_min_rounds = e->mlp_stagger_min_rounds;   // the hidden buffer is free on this path
         if (projf) {                                     // attn.proj + residual runs inside the same kernel, in front
           m.A = att; m.Wpp = wb + L.projw_pp; m.bp = F(L.projb_p);
           if (i + 1 == e->vit.depth && e->cls_only_last) {
@@ -810,6 +811,7 @@ int effocr_encoder_set_option(effocr_encoder_t* enc, const char* name, int value
   if (n == "tail_split") { enc->tail_split = value; return EFFOCR_OK; }
   if (n == "split6") { enc->split6 = value; return EFFOCR_OK; }
   if (n == "mlp_pair") { enc->mlp_pair = value; return EFFOCR_OK; }
+  if (n == "pair_parts") { enc->pair_parts = value; return EFFOCR_OK; }
   if (n == "use_gemm3") { enc->use_gemm3 = value; return EFFOCR_OK; }
   if (n == "use_lnfold") { enc->use_lnfold = value; return EFFOCR_OK; }
   if (n == "use_mlp") { enc->use_mlp = value; return EFFOCR_OK; }

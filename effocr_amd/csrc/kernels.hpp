@@ -55,6 +55,7 @@ struct MlpArgs {
   float* partial; size_t partial_bytes;   // optional scratch for the tail split (>= 4 * 64 * 128 * D * 4 bytes covers every case)
   int no_tail_split;                // 1: single launch (A/B switch)
   int no_split6;                    // 1: never the 6-way split of calls of <= 27 crops (A/B switch)
+  int no_pair_parts;                // 1: never the 3-way "pair parts" of calls of <= 27 crops (A/B switch: the 6- / 4-way 128-token parts instead)
   int pair;                         // 64-token panels on wave pairs (mlp_kernel.hpp PAIR; projection form only): 0 = where the launcher finds them faster, 1 = whenever they fit one round of CUs, -1 = never
   int panel0, tail_rb, stagger_wgs, main_wgs; // set by the launcher
   int stagger;                      // > 0: the first round of workgroups starts spread over 32 x stagger clock ticks (see mlp_kernel.hpp)

@@ -158,11 +158,16 @@ __shared__ __attribute__((aligned(16))) char mlp_smem[mlp_smem_bytes<384, 1536>(
 // this one keeps the new row x + bp + a.Wp^T in its fc2 accumulators (part 0 / wave 2j), false = its partial sums start at zero — the
 // first phase-B MFMA of every output tile takes the instruction's zero operand, so the row's 192 registers are dead behind the LayerNorm
 // (before: 576 read / multiply-by-0-or-1 / write instructions per part next to 21-46 spilled registers reloaded inside the chunk loop).
-template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ, bool PAIR = false, bool KEEP = true>
+// PPW (PAIR only) = which wave of the pair this body is (w & 1): a compile-time constant, the kernel branches per wave.  PAIR && PARTIAL
+// ("pair parts", calls of <= 27 crops): the 64-token panel's hidden chunks are ALSO dealt over (H / 128) / NCW workgroups — half the
+// projection / LayerNorm work per wave of a 128-token part, half as many partial sums for the reduction launch; KEEP then says whether this
+// part keeps the row in the tiles its wave owns (part 0) or starts every tile from zero.
+template <typename E, int D, int H, int NCW, bool PARTIAL, bool PROJ, bool PAIR = false, bool KEEP = true, int PPW = 0>
 __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) {
   static_assert(KEEP || (PROJ && (PARTIAL || PAIR)), "mlp: KEEP = false is a split part / the second wave of a pair behind the projection");
   static_assert(mlp_smem_bytes<D, H>() <= (int)sizeof(mlp_smem), "mlp: LDS object too small");
-  static_assert(!PAIR || (PROJ && !PARTIAL && NCW == H / 128 && D % 128 == 0), "mlp: the pair form is the whole MLP with the projection in front");
+  static_assert(!PAIR || (PROJ && D % 128 == 0 && (PARTIAL || (NCW == H / 128 && KEEP))), "mlp: the pair form has the projection in front; whole MLP, or split parts");
+  static_assert(PAIR || PPW == 0, "mlp: PPW is the pair form's wave index");
   char* smem = mlp_smem;
   typedef typename Op16<E>::V8 V8;
   constexpr int KC = D / 8;                              // 16-B k chunks per xn row
@@ -212,8 +217,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   constexpr int SPLIT = (H / 128) / NCW;                 // workgroups per panel
   const int panel = (PARTIAL ? a.panel0 : 0) + bid / SPLIT;
   const int c0 = (bid % SPLIT) * NCW;        // first hidden chunk of this workgroup
-  const int pp = PAIR ? (KEEP ? 0 : 1) : 0;              // PAIR: which half of a chunk's hidden features this wave carries (wave 2j: the KEEP body)
-  const int64_t rb = PAIR ? (int64_t)bid * 2 + (w >> 1) : (int64_t)panel * 4 + w;   // this wave's 32-row block of x
+  const int pp = PAIR ? PPW : 0;                         // PAIR: which half of a chunk's hidden features (and which output tiles) this wave carries
+  const int64_t rb = PAIR ? (int64_t)panel * 2 + (w >> 1) : (int64_t)panel * 4 + w;   // this wave's 32-row block of x
   const char* W1 = static_cast<const char*>(a.W1b);
   const char* W2 = static_cast<const char*>(a.W2p);
 
@@ -486,7 +491,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
   // own 12 operand fragments (fragment t' = tile t' >> 1) and the halves are exchanged through a 16 KB buffer in three rounds of four fragments
   // per wave (round g: fragments 8g + 4p .. + 3; the ring keeps streaming underneath — that is why the buffer is this small).
   auto layernorm_to_xf_pair = [&]() __attribute__((always_inline)) {
-    constexpr int PP = KEEP ? 0 : 1;
+    constexpr int PP = PPW;
     float* sS = reinterpret_cast<float*>(smem + mlp_smem_bytes<D, H>() + 16384);   // [sum | sum of squares][wave][token]
     char* xch = smem + mlp_smem_bytes<D, H>();                                      // [wave][fragment j of the round][lane] x 16 B
     pin_row();
@@ -843,7 +848,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         ring_stage_pair(std::integral_constant<int, rem>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
           constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
           const V8 hb = __builtin_bit_cast(V8, hs.u[c4]);
-          if constexpr (decltype(FIRSTB)::value && (sb & 1) != (KEEP ? 0 : 1) && c4 == 0) {   // B(0), a tile of the partner (tiles 2 sb, 2 sb + 1 are wave (sb & 1)'s): start from zero
+          if constexpr (decltype(FIRSTB)::value && ((sb & 1) != PPW || !KEEP) && c4 == 0) {   // B(0): a tile of the partner (tiles 2 sb, 2 sb + 1 are wave (sb & 1)'s), or a part that keeps no row: start from zero
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc2[2 * sb + i] = Op16<E>::mfma(wfrag, hb, z);
           } else
@@ -885,7 +890,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       sfor<0, SA>([&](auto KS) {
         constexpr int ks = decltype(KS)::value;
         if constexpr (PAIR) {                              // the wave's two tiles of the group: row blocks 2p, 2p + 1 of the stage, 8 MFMAs
-          constexpr int PP = KEEP ? 0 : 1;
+          constexpr int PP = PPW;
           ring_stage_pair(std::integral_constant<int, FAR>{}, [&](auto C4, auto I, const V8& wfrag) __attribute__((always_inline)) {
             constexpr int c4 = decltype(C4)::value, i = decltype(I)::value;
             acc2[4 * g + 2 * PP + i] = Op16<E>::mfma(wfrag, xf[ks * 4 + c4], acc2[4 * g + 2 * PP + i]);
@@ -899,10 +904,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     });
     MLP_STAMP_AT(4)
     if constexpr (PAIR) {
-      constexpr int PP = KEEP ? 0 : 1;
+      constexpr int PP = PPW;
       sfor<0, OT>([&](auto T_) { if constexpr (((decltype(T_)::value & 3) >> 1) == PP) bias_mm(sBp, T_); });
       layernorm_to_xf_pair();
-      sfor<0, OT>([&](auto T_) { if constexpr (((decltype(T_)::value & 3) >> 1) == PP) bias_mm(sB2, T_); });   // each tile's bias2 once: in its owner
+      if constexpr (!PARTIAL) sfor<0, OT>([&](auto T_) { if constexpr (((decltype(T_)::value & 3) >> 1) == PP) bias_mm(sB2, T_); });   // each tile's bias2 once: in its owner (pair parts: the reduction adds it)
     } else {
     sfor<0, OT>([&](auto T_) { bias_mm(sBp, T_); });
     layernorm_to_xf();
@@ -1002,7 +1007,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     // 4g + 2p, 4g + 2p + 1 are wave p's ("own").  The ring is drained (every stage consumed): a wave parks the 16 x 6 values per lane of
     // the tiles it does not own as [tile][quad][lane] x 16 B (the pair's 48 KB slab holds each tile once), adds its partner's for its
     // own tiles, stores their part of x and — the row statistics exchanged through 1 KB behind the slabs — of the second output.
-    constexpr int PP = KEEP ? 0 : 1;
+    constexpr int PP = PPW;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // nobody still reads the last stages
     asm volatile("" ::: "memory");
@@ -1022,6 +1027,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
     asm volatile("" ::: "memory");
     const bool live = rb * 32 + r31 < a.M;
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
+    // (pair parts: the own tiles' sums go to the scratch [part][row block][D/4 chunks][32][16 B]; together the two waves write the whole row)
+    char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(bid % SPLIT) * a.tail_rb + (rb - (int64_t)a.panel0 * 2)) * (D / 4)) * 512 + r31 * 16;
     float sm = 0.f;
     sfor<0, OT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
@@ -1033,12 +1040,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
           for (int e = 0; e < 4; ++e) acc2[t][4 * q + e] += v[e];
           const f32x4 o = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
           sm += (o[0] + o[1]) + (o[2] + o[3]);
-          if (live) st_act<4>(reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512), o);
+          if constexpr (PARTIAL) *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
+          else if (live) st_act<4>(reinterpret_cast<f32x4*>(xr + (size_t)cq(t, q) * 512), o);
         }
       }
     });
     MLP_STAMP_AT(9)
-    if (a.xn_out) {                                      // (uniform: every wave passes the two barriers below)
+    if (!PARTIAL && a.xn_out) {                                      // (uniform: every wave passes the two barriers below)
       float* sS = reinterpret_cast<float*>(smem + 2 * (OT * 4 * 1024));   // [sum | sum of squares][wave][token]
       sm += __shfl_xor(sm, 32, 64);
       if (half == 0) sS[w * 32 + r31] = sm;
@@ -1091,7 +1099,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
       });
     }
   }
-  if constexpr (PARTIAL) {
+  if constexpr (PARTIAL && !PAIR) {
     // fp32 partial sums -> scratch [part][tail row block][D/4 chunks][32][16 B]
     const int64_t rbl = rb - (int64_t)a.panel0 * 4;
     char* pr = reinterpret_cast<char*>(a.partial) + (((int64_t)(bid % SPLIT) * a.tail_rb + rbl) * (D / 4)) * 512 + r31 * 16;
@@ -1103,7 +1111,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a, const int bid) 
         *reinterpret_cast<f32x4*>(pr + (size_t)cq(t, q) * 512) = o;
       }
     });
-  } else if (!PAIR && rb * 32 + r31 < a.M) {
+  } else if (!PAIR && !PARTIAL && rb * 32 + r31 < a.M) {
     char* xr = reinterpret_cast<char*>(a.x) + rb * (D / 4) * 512 + r31 * 16;
     float sm = 0.f;
     sfor<0, OT>([&](auto T_) {
@@ -1199,10 +1207,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpArgs a) {
 }
 
 // 64-token panels, wave pairs (PAIR above): one workgroup per two row blocks
-template <typename E, int D, int H>
+// TNCW = 0: the whole MLP of a 64-token panel per workgroup; TNCW > 0 ("pair parts"): (H / 128) / TNCW workgroups per panel with TNCW hidden
+// chunks each, fp32 partial sums to the scratch, reduced by the reduction + LayerNorm launch like the 128-token parts'
+template <typename E, int D, int H, int TNCW>
 __global__ __launch_bounds__(256, 1) void mlp_pair_kernel(MlpArgs a) {
-  if ((wave_id() & 1) == 0) mlp_fused_body<E, D, H, H / 128, false, true, true, true>(a, (int)blockIdx.x);    // (both bodies pass the same barriers)
-  else mlp_fused_body<E, D, H, H / 128, false, true, true, false>(a, (int)blockIdx.x);
+  const bool w1 = (wave_id() & 1) != 0;                    // (every body passes the same barriers)
+  if constexpr (TNCW == 0) {
+    if (!w1) mlp_fused_body<E, D, H, H / 128, false, true, true, true, 0>(a, (int)blockIdx.x);
+    else mlp_fused_body<E, D, H, H / 128, false, true, true, true, 1>(a, (int)blockIdx.x);
+  } else {
+    const bool keep = (int)blockIdx.x % ((H / 128) / TNCW) == 0;   // part 0 of a panel keeps the new row (in the tiles each of its waves owns)
+    if (keep) {
+      if (!w1) mlp_fused_body<E, D, H, TNCW, true, true, true, true, 0>(a, (int)blockIdx.x);
+      else mlp_fused_body<E, D, H, TNCW, true, true, true, true, 1>(a, (int)blockIdx.x);
+    } else {
+      if (!w1) mlp_fused_body<E, D, H, TNCW, true, true, true, false, 0>(a, (int)blockIdx.x);
+      else mlp_fused_body<E, D, H, TNCW, true, true, true, false, 1>(a, (int)blockIdx.x);
+    }
+  }
 }
 
 // x[row block rb0 + i] = (add_x ? x : 0) + bias2 + sum over parts (fixed order) of the partial outputs; one thread per 16-byte chunk slot
@@ -1252,8 +1274,28 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
     const bool fits = np64 <= slots && a.rows_alloc >= np64 * 64;
     if (fits && (a.pair > 0 || (a.pair == 0 && !a.no_tail_split && npanels * 11 > slots * 2))) {
       a.panel0 = 0; a.main_wgs = np64; a.stagger_wgs = 0; a.tail_rb = 0;
-      hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536>), dim3((unsigned)np64), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 0>), dim3((unsigned)np64), dim3(256), 0, s, a);
       return check_launch("mlp_pair");
+    }
+    // Calls of <= 27 crops: "pair parts" — the 64-token panels' hidden chunks dealt 3-way (4 chunks per workgroup) instead of 128-token
+    // panels dealt 6-way: half the projection / LayerNorm per wave, three partial sums per row for the reduction launch instead of six.
+    // (<= 13 crops: 6-way, two chunks per workgroup — the parts' fixed share is small enough now for the shorter chunk phase to pay)
+    const int pparts = (np64 * 6 <= slots && !a.no_split6) ? 6 : 3;
+    if (fits && np64 * 3 <= slots && a.pair >= 0 && !a.no_pair_parts && !a.no_tail_split && a.partial &&
+        a.partial_bytes >= (size_t)pparts * np64 * 64 * a.D * sizeof(float)) {
+      a.panel0 = 0; a.main_wgs = 0; a.stagger_wgs = 0; a.tail_rb = np64 * 2;
+      if (pparts == 6) hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 2>), dim3((unsigned)(np64 * 6)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 4>), dim3((unsigned)(np64 * 3)), dim3(256), 0, s, a);
+      int rc = check_launch("mlp_pair_parts");
+      if (rc) return rc;
+      const int prec = std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16;
+      if (a.xn_out && MLP_FUSED_REDUCE_LN)
+        return reduce_layernorm_rows_blocked(prec, a.x, (int64_t)a.M, a.D, a.partial, a.b2_logical, pparts, a.tail_rb, 0, a.gamma_n, a.beta_n, a.eps, a.xn_out, s);
+      const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
+      hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((slots4 + 255) / 256)), dim3(256), 0, s, a.x, a.partial, a.b2_logical, (int64_t)0, a.tail_rb, a.D, pparts, (int64_t)a.M, 0);
+      rc = check_launch("mlp_reduce");
+      if (rc || !a.xn_out) return rc;
+      return layernorm_rows_blocked(prec, a.x, (int64_t)a.M, a.D, a.gamma_n, a.beta_n, a.eps, a.xn_out, s);
     }
   }
   const int tail = a.no_tail_split ? 0 : npanels % slots;

@@ -567,6 +567,7 @@ int launch_reduce_ln_blocked(float* x, int64_t rows, int D, const float* partial
   const dim3 grid((unsigned)((rows + 31) / 32));
   const LnReduce rd{partial, b2, x, nparts, tail_rb, add_x};
   if (D == 384 && nparts == 6) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true, 6>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
+  else if (D == 384 && nparts == 3) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true, 3>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
   else if (D == 384 && nparts == 4) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true, 4>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
   else if (D == 384 && nparts == 2) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true, 2>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);
   else if (D == 384) hipLaunchKernelGGL((layernorm_blocked_kernel<384, TO, true>), grid, dim3(256), 0, s, x, rows, gamma, beta, eps, out, rd);

@@ -356,13 +356,43 @@ def test_pair_panels_match_the_split_parts(dev, prec, B):
     assert e_pair <= REL[prec] and e_parts <= REL[prec]
     assert row_l2_err(forced.cpu(), ref.cpu()) <= REL[prec]
     enc.set_option("mlp_pair", 0)
-    for Bo in (29, 84):                                   # outside the range the automatic choice is the split parts
+    enc.set_option("pair_parts", 0)                       # (the class-token rows of the last block are a <= 27-row call: "pair parts", tested below)
+    for Bo in (29, 84):                                   # outside the range the automatic choice is the 128-token split parts / whole panels
         xo = torch.randn(Bo, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(Bo), device=dev)
         a = enc.forward(xo, normalize=True).clone()
         enc.set_option("mlp_pair", -1)
         b = enc.forward(xo, normalize=True).clone()
         enc.set_option("mlp_pair", 0)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("B", [1, 16, 27])
+def test_pair_parts_match_the_128_token_parts(dev, prec, B):
+    """Round 6: calls of <= 27 crops deal the hidden chunks of their 64-token pair panels over three workgroups (4 chunks each; option
+    pair_parts) instead of 128-token panels over six: half the projection / LayerNorm per wave, three partial sums per row for the reduction
+    launch.  Same arithmetic per token up to the order of the fp32 partial sums: both forms within the mode's bound of the library's exact-fp32
+    mode, per-row L2 too; the default IS the pair parts (different bits), and 28 crops — 88 pair panels x 3 > 256 CUs — are not."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    sd = init_state_dict(arch, seed=3, img_size=224)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(100 + B), device=dev)
+    ref = HipEncoder(arch, sd, precision="fp32", device=dev).forward(x, normalize=True)
+    enc = HipEncoder(arch, sd, precision=prec, device=dev)
+    auto = enc.forward(x, normalize=True).clone()
+    enc.set_option("pair_parts", 0)
+    parts = enc.forward(x, normalize=True).clone()
+    enc.check_status()
+    e_pp, e_parts = rel_err(auto.cpu(), ref.cpu()), rel_err(parts.cpu(), ref.cpu())
+    print(f"{B} crops {prec}: pair parts {e_pp:.2e}, 128-token parts {e_parts:.2e} of the fp32 mode; one against the other {rel_err(auto.cpu(), parts.cpu()):.2e}")
+    assert not torch.equal(auto, parts)
+    assert e_pp <= REL[prec] and e_parts <= REL[prec] and row_l2_err(auto.cpu(), ref.cpu()) <= REL[prec]
+    enc.set_option("cls_only_last", 0)                    # (else the class-token rows of a 28-crop call are still a pair-parts launch)
+    x28 = torch.randn(28, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(28), device=dev)
+    b = enc.forward(x28, normalize=True).clone()
+    enc.set_option("pair_parts", 1)
+    a = enc.forward(x28, normalize=True).clone()
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
