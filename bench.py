@@ -529,7 +529,7 @@ def small_batch_extras(a, enc, knn, sd, dev):
     x64 = torch.randn(64, 3, 224, 224, device=dev)
     t = _time_gpu(lambda: knn(enc.forward(x64, normalize=True), k=a.k), dev, 30)
     out["b64_device_resident"] = {"crops_per_s": round(64 / t, 1), "ms_per_call": round(1e3 * t, 3),
-                                  "note": "calls of 30..83 crops run the fused proj+MLP on 64-token wave-pair panels (no partial sums in HBM, no reduction launch; option mlp_pair)"}
+                                  "note": "calls of 37..83 crops run the fused proj+MLP on 64-token wave-pair panels (no partial sums in HBM, no reduction launch; option mlp_pair); <= 36 crops: the pair panels' hidden chunks over 6 / 3 / 2 workgroups + the reduction launch (option pair_parts)"}
     # the torch driver's call: ONE text line = B characters (infer_effocr.py:313-319, k = 10): per-call latency at 1 / 8 / 16 / 32 crops, the
     # encoder's launch count (in-library profiler) and the floor of the launch chain = the 1-crop call (every kernel at its minimum duration)
     per_line = {}

@@ -64,6 +64,10 @@
 #endif
 
 namespace effocr {
+// the pair kernels (mlp_pair_kernel<E, 384, 1536, TNCW>, TNCW = 0 / 2 / 4 / 6) are instantiated in translation units of their own
+// (mlp_bf16pair.hip, mlp_f16pair.hip: the fused-MLP objects compile in parallel; one unit with all 24 bodies took 5 minutes)
+int mlp_pair_launch_bf16(const MlpArgs& a, int tncw, unsigned grid, hipStream_t s);
+int mlp_pair_launch_f16(const MlpArgs& a, int tncw, unsigned grid, hipStream_t s);
 namespace {
 
 // -DMLP_STAMP (tools/ab_build.sh variant, never shipped): wave 0 of every whole-panel workgroup records s_memtime at the panel's
@@ -1250,6 +1254,18 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(float* x, const float* 
   *xp = v;
 }
 
+template <typename E>
+int launch_mlp_pair(const MlpArgs& a, int tncw, unsigned grid, hipStream_t s) {
+  switch (tncw) {
+    case 0: hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 0>), dim3(grid), dim3(256), 0, s, a); return check_launch("mlp_pair");
+    case 2: hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 2>), dim3(grid), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 4>), dim3(grid), dim3(256), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 6>), dim3(grid), dim3(256), 0, s, a); break;
+    default: return fail(EFFOCR_EINVAL, "mlp_pair: hidden chunks per part must be 0 (whole), 2, 4 or 6");
+  }
+  return check_launch("mlp_pair_parts");
+}
+
 template <typename E, bool PROJ>
 int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
   MlpArgs a = a_in;
@@ -1272,23 +1288,18 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
     // 24 crops 1.00, 16 crops 1.07 (there the 4- / 6-way parts win: a sixth of the weight stream per CU).
     const int np64 = (a.M + 63) / 64;
     const bool fits = np64 <= slots && a.rows_alloc >= np64 * 64;
-    if (fits && (a.pair > 0 || (a.pair == 0 && !a.no_tail_split && npanels * 11 > slots * 2))) {
-      a.panel0 = 0; a.main_wgs = np64; a.stagger_wgs = 0; a.tail_rb = 0;
-      hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 0>), dim3((unsigned)np64), dim3(256), 0, s, a);
-      return check_launch("mlp_pair");
-    }
-    // Calls of <= 27 crops: "pair parts" — the 64-token panels' hidden chunks dealt 3-way (4 chunks per workgroup) instead of 128-token
-    // panels dealt 6-way: half the projection / LayerNorm per wave, three partial sums per row for the reduction launch instead of six.
+    // Calls of <= 41 crops: "pair parts" — the 64-token panels' hidden chunks dealt over as many workgroups as fit one round: 6 (<= 13 crops),
+    // 3 (<= 27) or 2 (<= 36 crops = 112 pair panels: beyond, the whole-pair form below is faster — same box, encoder only, 2-way parts vs whole pair
+    // panels: 28 / 32 / 36 / 40 crops 0.751 / 0.774 / 0.809 / 0.853 vs 0.819 / 0.808 / 0.814 / 0.824 ms) instead of 128-token panels dealt 6- / 4-way:
+    // half the projection / LayerNorm per wave, half the partial sums for the reduction launch.
     // (<= 13 crops: 6-way, two chunks per workgroup — the parts' fixed share is small enough now for the shorter chunk phase to pay)
-    const int pparts = (np64 * 6 <= slots && !a.no_split6) ? 6 : 3;
-    if (fits && np64 * 3 <= slots && a.pair >= 0 && !a.no_pair_parts && !a.no_tail_split && a.partial &&
+    const int pparts = (np64 * 6 <= slots && !a.no_split6) ? 6 : np64 * 3 <= slots ? 3 : 2;
+    if (fits && (pparts > 2 || np64 * 16 <= slots * 7) && a.pair == 0 && !a.no_pair_parts && !a.no_tail_split && a.partial &&
         a.partial_bytes >= (size_t)pparts * np64 * 64 * a.D * sizeof(float)) {
       a.panel0 = 0; a.main_wgs = 0; a.stagger_wgs = 0; a.tail_rb = np64 * 2;
-      if (pparts == 6) hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 2>), dim3((unsigned)(np64 * 6)), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((mlp_pair_kernel<E, 384, 1536, 4>), dim3((unsigned)(np64 * 3)), dim3(256), 0, s, a);
-      int rc = check_launch("mlp_pair_parts");
-      if (rc) return rc;
       const int prec = std::is_same<E, __bf16>::value ? PREC_BF16 : PREC_FP16;
+      int rc = prec == PREC_BF16 ? mlp_pair_launch_bf16(a, 12 / pparts, (unsigned)(np64 * pparts), s) : mlp_pair_launch_f16(a, 12 / pparts, (unsigned)(np64 * pparts), s);
+      if (rc) return rc;
       if (a.xn_out && MLP_FUSED_REDUCE_LN)
         return reduce_layernorm_rows_blocked(prec, a.x, (int64_t)a.M, a.D, a.partial, a.b2_logical, pparts, a.tail_rb, 0, a.gamma_n, a.beta_n, a.eps, a.xn_out, s);
       const int64_t slots4 = (int64_t)a.tail_rb * (a.D / 4) * 32;
@@ -1296,6 +1307,10 @@ int launch_mlp(const MlpArgs& a_in, hipStream_t s) {
       rc = check_launch("mlp_reduce");
       if (rc || !a.xn_out) return rc;
       return layernorm_rows_blocked(prec, a.x, (int64_t)a.M, a.D, a.gamma_n, a.beta_n, a.eps, a.xn_out, s);
+    }
+    if (fits && (a.pair > 0 || (a.pair == 0 && !a.no_tail_split && npanels * 11 > slots * 2))) {
+      a.panel0 = 0; a.main_wgs = np64; a.stagger_wgs = 0; a.tail_rb = 0;
+      return std::is_same<E, __bf16>::value ? mlp_pair_launch_bf16(a, 0, (unsigned)np64, s) : mlp_pair_launch_f16(a, 0, (unsigned)np64, s);
     }
   }
   const int tail = a.no_tail_split ? 0 : npanels % slots;

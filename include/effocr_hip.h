@@ -133,10 +133,10 @@ int effocr_encoder_set_chunk(effocr_encoder_t* enc, int crops_per_chunk);
  *                 reaches the embedding (global_pool = 'token'); proj / LayerNorm / MLP act per row, so the result is the same
  *                 (0: all tokens, A/B switch)
  *   "split6"      [1] fused MLP: calls of <= 27 crops cut their panels 6-way over the hidden dimension (0: 4-way)
- *   "pair_parts"  [1] fused proj+MLP: calls of <= 27 crops (and the class-token rows of the last block) deal the hidden chunks of their
- *                 64-token pair panels over three workgroups + the reduction launch (0: 128-token panels over six / four)
+ *   "pair_parts"  [1] fused proj+MLP: calls of <= 36 crops (and the class-token rows of the last block) deal the hidden chunks of their
+ *                 64-token pair panels over 6 / 3 / 2 workgroups + the reduction launch (0: 128-token panels over six / four, whole pair panels from 30 crops)
  *   "mlp_pair"    [0] fused proj+MLP: 64-token panels whose wave pairs split a chunk's hidden features (no partial sums in HBM, no
- *                 reduction launch): 0 = for calls of 30..83 crops, 1 = whenever the 64-token panels fit one round of CUs, -1 = never
+ *                 reduction launch): 0 = for calls of 37..83 crops (below: "pair_parts"), 1 = whenever the 64-token panels fit one round of CUs, -1 = never
  *   "mlp_stagger" [3500] fused MLP kernel: the first round of workgroups starts spread over 32 x this many clock ticks, so
  *                 that the CUs do not request / store their rows all at the same moment (0 = off)
  *   "mlp_stagger_min_rounds" [2] ... for launches of at least this many rounds of CUs (512-crop calls: +7.7 %; no effect below two)

@@ -367,12 +367,13 @@ def test_pair_panels_match_the_split_parts(dev, prec, B):
 
 
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
-@pytest.mark.parametrize("B", [1, 16, 27])
+@pytest.mark.parametrize("B", [1, 16, 27, 36])
 def test_pair_parts_match_the_128_token_parts(dev, prec, B):
-    """Round 6: calls of <= 27 crops deal the hidden chunks of their 64-token pair panels over three workgroups (4 chunks each; option
-    pair_parts) instead of 128-token panels over six: half the projection / LayerNorm per wave, three partial sums per row for the reduction
-    launch.  Same arithmetic per token up to the order of the fp32 partial sums: both forms within the mode's bound of the library's exact-fp32
-    mode, per-row L2 too; the default IS the pair parts (different bits), and 28 crops — 88 pair panels x 3 > 256 CUs — are not."""
+    """Round 6: calls of <= 36 crops deal the hidden chunks of their 64-token pair panels over 6 (<= 13 crops), 3 (<= 27) or 2 workgroups
+    (option pair_parts) instead of 128-token panels over six / four — or, from 30 crops on, whole pair panels: half the projection / LayerNorm
+    per wave, half the partial sums for the reduction launch.  Same arithmetic per token up to the order of the fp32 partial sums: both
+    selections within the mode's bound of the library's exact-fp32 mode, per-row L2 too; the default IS the pair parts (different bits), and 42
+    crops — 130 pair panels — are not (from 37 crops on whole pair panels are faster)."""
     from effocr_amd.encoders import HipEncoder
     arch = "vit_small_patch16_224"
     sd = init_state_dict(arch, seed=3, img_size=224)
@@ -387,11 +388,11 @@ def test_pair_parts_match_the_128_token_parts(dev, prec, B):
     print(f"{B} crops {prec}: pair parts {e_pp:.2e}, 128-token parts {e_parts:.2e} of the fp32 mode; one against the other {rel_err(auto.cpu(), parts.cpu()):.2e}")
     assert not torch.equal(auto, parts)
     assert e_pp <= REL[prec] and e_parts <= REL[prec] and row_l2_err(auto.cpu(), ref.cpu()) <= REL[prec]
-    enc.set_option("cls_only_last", 0)                    # (else the class-token rows of a 28-crop call are still a pair-parts launch)
-    x28 = torch.randn(28, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(28), device=dev)
-    b = enc.forward(x28, normalize=True).clone()
+    enc.set_option("cls_only_last", 0)                    # (else the class-token rows of a 42-crop call are still a pair-parts launch)
+    x42 = torch.randn(42, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(42), device=dev)
+    b = enc.forward(x42, normalize=True).clone()
     enc.set_option("pair_parts", 1)
-    a = enc.forward(x28, normalize=True).clone()
+    a = enc.forward(x42, normalize=True).clone()
     assert torch.equal(a, b)
 
 

@@ -13,7 +13,7 @@ from effocr_amd.weights import init_state_dict
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda:0")
 enc = HipEncoder("vit_small_patch16_224", init_state_dict("vit_small_patch16_224", seed=0, img_size=224), img_size=224, precision="bf16", device=dev)
-enc.set_option("cls_only_last", 0)             # every block's launch has the same shape: the last one's stamps are those of a middle block
+enc.set_option("cls_only_last", 0); enc.set_option("pair_parts", 0); enc.set_option("mlp_pair", -1)   # the 128-token split parts             # every block's launch has the same shape: the last one's stamps are those of a middle block
 x = torch.randn(B, 3, 224, 224, device=dev)
 for _ in range(5):
     enc.forward(x, normalize=True)
@@ -21,6 +21,8 @@ torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["EFFOCR_HIP_LIB"])
 NW, NS = 2048, 20
 buf = (ctypes.c_ulonglong * (NW * NS))()
+# (calls of <= 36 crops run "pair parts" — kernels of mlp_bf16pair.hip, whose stamp table is read by effocr_debug_mlp_pair_stamps; this tool measures the
+#  128-token parts: pair_parts = 0, mlp_pair = -1 above)
 rc = lib.effocr_debug_mlp_stamps(buf, NW * NS)
 assert rc == 0, rc
 t = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NS).astype(np.int64)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-panel timeline of the fused proj+MLP kernel from a -DMLP_STAMP build (tools/ab_build.sh stamp "-DMLP_STAMP" mlp_bf16p.hip):
+"""Per-panel timeline of the fused proj+MLP kernel from a -DMLP_STAMP build (tools/ab_build.sh stamp "-DMLP_STAMP" mlp_bf16p.hip mlp_bf16pair.hip):
    EFFOCR_HIP_LIB=$PWD/tools/ab/lib_stamp.so python tools/mlp_timeline.py [batch]
 Prints the mean share of each segment of a whole panel (s_memtime ticks, wave 0) and the per-CU turn-around between workgroups."""
 import ctypes, os, sys
@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["EFFOCR_HIP_LIB"])
 NW, NS = 2048, 20
 buf = (ctypes.c_ulonglong * (NW * NS))()
-rc = lib.effocr_debug_mlp_stamps(buf, NW * NS)
+rc = (lib.effocr_debug_mlp_pair_stamps if PAIR else lib.effocr_debug_mlp_stamps)(buf, NW * NS)   # (the pair kernels live in a translation unit of their own: its table)
 assert rc == 0, rc
 t = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NS).astype(np.int64)
 npan = (B * 197 + 127) // 128
