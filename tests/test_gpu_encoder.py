@@ -330,6 +330,27 @@ def test_embedding_does_not_depend_on_the_call_size(dev, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_embedding_across_the_kernel_selection_boundaries(dev, prec):
+    """The fused proj+MLP changes its form with the call size (round 6): 6-way pair parts up to 13 crops, 3-way up to 27, 2-way up to 36, whole
+    64-token pair panels up to 83, 128-token panels above (two pair-panel sub-batches from 88 on).  The SAME six crops inside calls on both sides
+    of every boundary: each embedding within the mode's bound of the library's exact-fp32 mode, and of the 6-crop call."""
+    from effocr_amd.encoders import HipEncoder
+    arch = "vit_small_patch16_224"
+    sd = init_state_dict(arch, seed=3, img_size=224)
+    x = torch.randn(96, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(77), device=dev)
+    ref = HipEncoder(arch, sd, precision="fp32", device=dev).forward(x[:6].contiguous(), normalize=True).cpu()
+    enc = HipEncoder(arch, sd, precision=prec, device=dev)
+    six = enc.forward(x[:6].contiguous(), normalize=True).cpu()
+    worst = {}
+    for B in (13, 14, 27, 28, 36, 37, 83, 84, 87, 88, 96):
+        e = enc.forward(x[:B].contiguous(), normalize=True)[:6].cpu()
+        worst[B] = (rel_err(e, ref), rel_err(e, six))
+        assert worst[B][0] <= REL[prec] and worst[B][1] <= REL[prec], (B, worst[B])
+    enc.check_status()
+    print(prec, {B: f"{a:.1e}/{b:.1e}" for B, (a, b) in worst.items()})
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
 @pytest.mark.parametrize("B", [30, 64, 83])
 def test_pair_panels_match_the_split_parts(dev, prec, B):
     """Round 6: calls of 30..83 crops run the fused proj+MLP on 64-token panels whose wave pairs split a chunk's hidden features
