@@ -27,6 +27,15 @@
 // (History, same-box A/B each: the round-2 form ran the GELU as 8-value bursts of packed FMAs behind single MFMAs — packed fp32 never
 // overlaps the matrix pipe, tools/ubench/mfma_fill.hip; slicing THAT form over the gaps was 1-2 % slower, parking half a chunk under
 // phase B's second k half 4 % slower; the scalar list is 7 % faster than the bursts.)
+// FORMS of the body (round 6; launch_mlp picks by the call's row count, every boundary is parity-tested: tests/test_gpu_encoder.py
+// test_embedding_across_the_kernel_selection_boundaries):
+//   whole panels        128 tokens per workgroup, the whole MLP (the headline: 1576 panels per launch at 1024 crops)
+//   split parts         the 128-token panels of a partially filled LAST round cut 2 / 4 / 6-way over the hidden chunks (PARTIAL), fp32
+//                       partial sums + the reduction / LayerNorm launch; part 0 keeps the row (KEEP), the others start from zero
+//   pair panels         64 tokens per workgroup, the two waves of a pair share a token tile: hidden features of a chunk, output tiles of the
+//                       projection, both LayerNorms and the stores split between them, exchanged through LDS (PAIR; calls of 37-83 crops)
+//   pair parts          pair panels whose hidden chunks are also cut over 6 / 3 / 2 workgroups + the reduction launch (PAIR && PARTIAL;
+//                       calls of <= 13 / 27 / 36 crops and the class-token rows of the last block)
 // (kernel template + launcher; instantiated per operand type / projection flag in mlp_*.hip so that the four
 // variants compile in parallel: one translation unit took 200 s)
 #pragma once
